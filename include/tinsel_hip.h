@@ -1,0 +1,298 @@
+/*
+ * tinsel_hip.h -- C-ABI of the MI355X (gfx950) path-tracing back-end for Tinsel.
+ *
+ * This is the drop-in boundary. It replaces what the reference does behind
+ *     Renderer* CreateGpuRenderer(const Scene* s);            (reference src/render.h:79)
+ *     struct Renderer { Init(w,h); Render(cam, opts, out); }  (reference src/render.h:66-73)
+ * which the reference implements with CUDA in src/render.cu:978-1110.
+ *
+ * Everything that crosses this ABI is plain pointers + sizes.  The POD records
+ * below are *layout mirrors* of the reference structs (sizes/offsets asserted at
+ * the bottom of this file), so a Tinsel maintainer passes `&scene->primitives[0]`,
+ * `scene->bvh.nodes`, `&camera`, `&options` unchanged -- see INTEGRATION.md for
+ * the ~40-line `HipRenderer : Renderer` shim (shim/hip_renderer.cpp).
+ *
+ * No torch types, no C++ types, no exceptions cross this boundary.  All entry
+ * points return 0 on success / non-zero on failure (or NULL for constructors) and
+ * leave a message retrievable with tinsel_hip_last_error().
+ */
+#ifndef TINSEL_HIP_H
+#define TINSEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* POD mirrors of the reference structs                                       */
+
+typedef struct tinsel_vec3 { float x, y, z; } tinsel_vec3;          /* maths.h:214-234  (12 B) */
+typedef struct tinsel_vec4 { float x, y, z, w; } tinsel_vec4;       /* maths.h:290-312  (16 B), Color/Quat alike */
+
+typedef struct tinsel_transform {                                   /* maths.h:575-589  (32 B) */
+    tinsel_vec3 p;
+    tinsel_vec4 r;      /* quaternion x,y,z,w */
+    float s;
+} tinsel_transform;
+
+typedef struct tinsel_bvh_node {                                    /* bvh.h:9-20       (32 B) */
+    tinsel_vec3 lower;
+    tinsel_vec3 upper;
+    uint32_t left_index;            /* leaf: item index */
+    uint32_t right_index_leaf;      /* bits 0..30 = rightIndex, bit 31 = leaf */
+} tinsel_bvh_node;
+
+typedef struct tinsel_camera {                                      /* scene.h:11-30    (40 B) */
+    tinsel_vec3 position;
+    tinsel_vec4 rotation;
+    float fov;
+    float shutter_start;
+    float shutter_end;
+} tinsel_camera;
+
+typedef struct tinsel_texture {                                     /* scene.h:33-42    (24 B) */
+    float* data;
+    int32_t width, height, depth;
+    int32_t _pad;
+} tinsel_texture;
+
+typedef struct tinsel_material {                                    /* scene.h:45-100   (128 B) */
+    tinsel_vec3 emission;
+    tinsel_vec3 color;
+    tinsel_vec3 absorption;
+    float eta;
+    float metallic;
+    float subsurface;
+    float specular;
+    float roughness;
+    float specular_tint;
+    float anisotropic;
+    float sheen;
+    float sheen_tint;
+    float clearcoat;
+    float clearcoat_gloss;
+    float transmission;
+    int32_t _pad0;
+    tinsel_texture bump_map;
+    float bump;
+    tinsel_vec3 bump_tile;
+} tinsel_material;
+
+enum { TINSEL_GEOM_SPHERE = 0, TINSEL_GEOM_PLANE = 1, TINSEL_GEOM_MESH = 2 };   /* scene.h:102-107 */
+
+typedef struct tinsel_mesh_geometry {                               /* scene.h:119-135  (64 B) */
+    const tinsel_vec3* positions;
+    const tinsel_vec3* normals;
+    const int32_t* indices;
+    const tinsel_bvh_node* nodes;
+    const float* cdf;
+    int32_t num_vertices;
+    int32_t num_indices;
+    int32_t num_nodes;
+    float area;
+    uint64_t id;
+} tinsel_mesh_geometry;
+
+typedef struct tinsel_primitive {                                   /* scene.h:138-159  (272 B) */
+    tinsel_transform start_transform;
+    tinsel_transform end_transform;
+    int32_t type;
+    int32_t _pad0;
+    union {
+        struct { float radius; } sphere;
+        struct { float plane[4]; } plane;
+        tinsel_mesh_geometry mesh;
+    } geo;
+    tinsel_material material;
+    int32_t light_samples;
+    int32_t _pad1;
+} tinsel_primitive;
+
+enum { TINSEL_FILTER_BOX = 0, TINSEL_FILTER_GAUSSIAN = 1 };          /* render.h:7-11 */
+
+typedef struct tinsel_filter {                                      /* render.h:13-39   (16 B) */
+    int32_t type;
+    float width;
+    float falloff;
+    float offset;       /* taken verbatim from the caller, never recomputed (loader quirk, loader.cpp:74) */
+} tinsel_filter;
+
+enum { TINSEL_MODE_NORMALS = 0, TINSEL_MODE_COMPLEXITY = 1, TINSEL_MODE_PATHTRACE = 2 }; /* render.h:42-47 */
+
+typedef struct tinsel_options {                                     /* render.h:50-63   (48 B) */
+    int32_t mode;
+    int32_t width;
+    int32_t height;
+    tinsel_filter filter;
+    float exposure;
+    float limit;
+    float clamp;
+    int32_t max_depth;
+    int32_t max_samples;
+} tinsel_options;
+
+/* Flat view of a reference `Scene` (scene.h:183-215).  `Scene` itself holds
+ * std::vectors, so the C++ side of the shim walks it and fills this struct;
+ * nothing behind this ABI touches libstdc++ containers. */
+typedef struct tinsel_scene_desc {
+    const tinsel_primitive* primitives;     /* &scene->primitives[0]; mesh pointers are HOST pointers */
+    int32_t num_primitives;
+    int32_t num_bvh_nodes;                  /* scene->bvh.numNodes */
+    const tinsel_bvh_node* bvh_nodes;       /* scene->bvh.nodes (built by Scene::Build, scene.cpp:4-16) */
+    tinsel_vec3 sky_horizon;                /* scene->sky.horizon  (scene.h:163) */
+    tinsel_vec3 sky_zenith;                 /* scene->sky.zenith */
+    int32_t probe_valid;                    /* scene->sky.probe.valid (probe.h:81) */
+    int32_t probe_width;
+    int32_t probe_height;
+    int32_t _pad;
+    const tinsel_vec4* probe_data;          /* probe.data,  width*height RGBA32F */
+    const float* probe_pdf_x;               /* probe.pdfValuesX  [w*h] */
+    const float* probe_cdf_x;               /* probe.cdfValuesX  [w*h] */
+    const float* probe_pdf_y;               /* probe.pdfValuesY  [h]   */
+    const float* probe_cdf_y;               /* probe.cdfValuesY  [h]   */
+} tinsel_scene_desc;
+
+/* ------------------------------------------------------------------------- */
+/* The renderer object                                                        */
+
+typedef struct tinsel_hip tinsel_hip;       /* opaque */
+
+/* Pipeline selection (tinsel_hip_set_pipeline).  WAVEFRONT is the product path;
+ * MEGAKERNEL is kept as an A/B arm with identical per-path arithmetic. */
+enum { TINSEL_PIPELINE_WAVEFRONT = 0, TINSEL_PIPELINE_MEGAKERNEL = 1 };
+
+/* Replaces GpuRenderer::GpuRenderer (render.cu:989-1053): deep-copies the scene
+ * to device `device_index` (dedupes meshes by MeshGeometry::id, re-lays BVHs out
+ * for 64-B two-child records, pre-gathers triangles).  The desc and everything it
+ * points to may be freed once this returns. */
+tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* scene, int device_index);
+
+/* Replaces GpuRenderer::~GpuRenderer (render.cu:1055-1068). */
+void tinsel_hip_destroy(tinsel_hip* r);
+
+/* Replaces GpuRenderer::Init (render.cu:1070-1075): (re)allocates and zeroes the
+ * W*H float4 accumulation buffer. */
+int tinsel_hip_init(tinsel_hip* r, int width, int height);
+
+/* Replaces GpuRenderer::Render (render.cu:1077-1103) with `passes` == 1: adds one
+ * sample per pixel per pass to the device accumulator, then copies the running sum
+ * (rgb*w, w) to `out_rgba` (W*H*4 floats, host memory).  `out_rgba` may be NULL
+ * to skip the D2H copy (the accumulator stays resident in HBM). */
+int tinsel_hip_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options,
+                      float* out_rgba, int passes);
+
+/* Same, but never touches host memory: enqueues `passes` passes on `stream`
+ * (a hipStream_t, may be NULL for the default stream) and returns without
+ * synchronising.  Used by bench.py / multi-GPU hosts that own the stream. */
+int tinsel_hip_render_async(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options,
+                            int passes, void* stream);
+
+/* Device pointer to the W*H*4 float accumulation buffer (for an RCCL reduce by the
+ * host language, e.g. torch.distributed).  Valid until the next init/destroy. */
+float* tinsel_hip_accum_device_ptr(tinsel_hip* r);
+
+/* Blocking copy of the accumulator to host (W*H*4 floats). */
+int tinsel_hip_read_accum(tinsel_hip* r, float* out_rgba);
+
+/* Pixel-tile sharding for multi-GPU: this renderer traces only paths whose
+ * generating pixel lies in a tile t with (t % world) == rank, tiles of
+ * `tile`x`tile` pixels in raster order.  Seeds depend on (pixel, pass) only, so
+ * the sum over ranks of the accumulators equals the world==1 image up to float
+ * summation order.  Default: rank 0 of 1. */
+int tinsel_hip_set_shard(tinsel_hip* r, int rank, int world, int tile);
+
+int tinsel_hip_set_pipeline(tinsel_hip* r, int pipeline);
+
+/* The per-pass seed is the (pass_index+1)-th output of Random(1).Rand()
+ * (mirrors `seed = Random(frame)` / `seed.Rand()`, render.cu:1050-1052,1099).
+ * A new renderer starts at pass 0; Init does not reset it (nor does the reference). */
+int tinsel_hip_set_pass_index(tinsel_hip* r, uint32_t pass_index);
+uint32_t tinsel_hip_get_pass_index(tinsel_hip* r);
+
+/* Counters since creation (or the last reset): rays = Trace()-equivalent casts
+ * (extension + shadow; reference render.cpp:17 call sites :253,:122,:175),
+ * samples = camera paths started, gpu_seconds = sum of HIP-event-timed spans. */
+void tinsel_hip_stats(tinsel_hip* r, unsigned long long* rays, unsigned long long* samples,
+                      double* gpu_seconds);
+void tinsel_hip_reset_stats(tinsel_hip* r);
+
+/* Per-kernel timing (HIP events on the launch stream) of the most recent
+ * tinsel_hip_render* call, for bench.py's roofline block.  Returns the number
+ * of kernel classes written (<= max_entries).  Blocks until the events resolve. */
+typedef struct tinsel_kernel_time {
+    char name[32];
+    uint32_t launches;
+    float total_ms;
+} tinsel_kernel_time;
+int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entries);
+int tinsel_hip_enable_kernel_timing(tinsel_hip* r, int enable);
+
+const char* tinsel_hip_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Scene packs: a relocatable single-blob serialisation of tinsel_scene_desc   */
+/* (+ the scene's camera/options) so that scenes travel to machines without    */
+/* the reference's loader.  See DESIGN.md "Scene pack".                         */
+
+#define TINSEL_PACK_MAGIC "TINPACK1"
+
+typedef struct tinsel_pack_header {
+    char magic[8];
+    uint32_t version;               /* 1 */
+    uint32_t num_primitives;
+    uint32_t num_bvh_nodes;
+    uint32_t num_meshes;
+    uint64_t total_bytes;
+    uint64_t off_primitives;        /* tinsel_primitive[]; mesh pointer fields hold BYTE OFFSETS into the blob */
+    uint64_t off_bvh_nodes;
+    uint64_t off_probe_data;        /* 0 when there is no probe */
+    uint64_t off_probe_pdf_x;
+    uint64_t off_probe_cdf_x;
+    uint64_t off_probe_pdf_y;
+    uint64_t off_probe_cdf_y;
+    int32_t probe_width;
+    int32_t probe_height;
+    tinsel_vec3 sky_horizon;
+    tinsel_vec3 sky_zenith;
+    tinsel_camera camera;
+    tinsel_options options;
+    uint8_t _reserved[48];
+} tinsel_pack_header;
+
+/* Resolves the offsets of a pack blob (in place: `blob` must stay alive and
+ * writable) into a tinsel_scene_desc whose pointers point into the blob. */
+int tinsel_pack_open(void* blob, size_t size, tinsel_scene_desc* out_scene,
+                     tinsel_camera* out_camera, tinsel_options* out_options);
+
+#ifdef __cplusplus
+}
+
+static_assert(sizeof(tinsel_vec3) == 12, "Vec3");
+static_assert(sizeof(tinsel_transform) == 32, "Transform");
+static_assert(sizeof(tinsel_bvh_node) == 32, "BVHNode");
+static_assert(sizeof(tinsel_camera) == 40, "Camera");
+static_assert(sizeof(tinsel_texture) == 24, "Texture");
+static_assert(sizeof(tinsel_material) == 128, "Material");
+static_assert(offsetof(tinsel_material, eta) == 36, "Material.eta");
+static_assert(offsetof(tinsel_material, transmission) == 80, "Material.transmission");
+static_assert(offsetof(tinsel_material, bump_map) == 88, "Material.bumpMap");
+static_assert(offsetof(tinsel_material, bump) == 112, "Material.bump");
+static_assert(sizeof(tinsel_mesh_geometry) == 64, "MeshGeometry");
+static_assert(offsetof(tinsel_mesh_geometry, num_vertices) == 40, "MeshGeometry.numVertices");
+static_assert(offsetof(tinsel_mesh_geometry, area) == 52, "MeshGeometry.area");
+static_assert(offsetof(tinsel_mesh_geometry, id) == 56, "MeshGeometry.id");
+static_assert(sizeof(tinsel_primitive) == 272, "Primitive");
+static_assert(offsetof(tinsel_primitive, type) == 64, "Primitive.type");
+static_assert(offsetof(tinsel_primitive, geo) == 72, "Primitive.geo");
+static_assert(offsetof(tinsel_primitive, material) == 136, "Primitive.material");
+static_assert(offsetof(tinsel_primitive, light_samples) == 264, "Primitive.lightSamples");
+static_assert(sizeof(tinsel_filter) == 16, "Filter");
+static_assert(sizeof(tinsel_options) == 48, "Options");
+static_assert(offsetof(tinsel_options, max_depth) == 40, "Options.maxDepth");
+static_assert(sizeof(tinsel_pack_header) == 256, "pack header");
+#endif
+
+#endif /* TINSEL_HIP_H */
