@@ -177,6 +177,11 @@ void tinsel_hip_destroy(tinsel_hip* r);
  * W*H float4 accumulation buffer. */
 int tinsel_hip_init(tinsel_hip* r, int width, int height);
 
+/* Same, but the accumulator is caller-owned DEVICE memory of W*H*4 floats (e.g. a
+ * torch tensor, so the host language can hand it to RCCL); it is zeroed here and
+ * must outlive the renderer or the next init. */
+int tinsel_hip_init_external(tinsel_hip* r, int width, int height, float* device_accum);
+
 /* Replaces GpuRenderer::Render (render.cu:1077-1103) with `passes` == 1: adds one
  * sample per pixel per pass to the device accumulator, then copies the running sum
  * (rgb*w, w) to `out_rgba` (W*H*4 floats, host memory).  `out_rgba` may be NULL
@@ -229,6 +234,19 @@ typedef struct tinsel_kernel_time {
 } tinsel_kernel_time;
 int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entries);
 int tinsel_hip_enable_kernel_timing(tinsel_hip* r, int enable);
+
+/* Extended counters since the last reset: [0]=rays [1]=samples [2]=internal BVH node visits
+ * [3]=triangle tests [4]=primitive tests [5]=shadow rays [6..7] reserved.  [2..4] only advance
+ * while detail counting is on (it costs a few percent); they feed B_ray of DESIGN.md. */
+int tinsel_hip_stats_detail(tinsel_hip* r, unsigned long long* out8);
+int tinsel_hip_set_detail_counters(tinsel_hip* r, int enable);
+
+/* Upper bound on path slots resident per batch (default 4 Mi, or env TINSEL_HIP_BATCH_PATHS). */
+int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths);
+
+/* Introspection: LDS traversal-stack entries per lane chosen for this scene, NEE rays per bounce. */
+int tinsel_hip_stack_entries(tinsel_hip* r);
+int tinsel_hip_nee_per_path(tinsel_hip* r);
 
 const char* tinsel_hip_last_error(void);
 

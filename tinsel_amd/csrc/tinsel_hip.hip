@@ -1,0 +1,1128 @@
+// tinsel_hip.hip -- host side of the C-ABI (include/tinsel_hip.h): scene flattening/upload,
+// camera set-up, batch scheduling of the streaming pipeline, statistics and timing.
+//
+// Replaces the reference's GpuRenderer (src/render.cu:978-1110).  Built only with
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (tinsel_amd/build.py)
+
+#include "../../include/tinsel_hip.h"
+
+#include "tn_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace tn;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(const std::string& msg)
+{
+    g_error = msg;
+    fprintf(stderr, "tinsel_hip: %s\n", msg.c_str());
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
+    } while (0)
+
+#define HIP_TRY_NULL(expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) {                                                                             \
+            fail(std::string(#expr) + ": " + hipGetErrorString(_e));                                        \
+            return nullptr;                                                                                 \
+        }                                                                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// BVH re-layout: reference 32-B nodes -> one Node64 per internal node (tn_scene.h)
+
+struct ConvertedBvh
+{
+    std::vector<Node64> nodes;
+    uint32_t root = 0;
+    int maxLeafDepth = 0;
+};
+
+inline bool ref_is_leaf(const tinsel_bvh_node& n) { return (n.right_index_leaf >> 31) != 0; }
+inline uint32_t ref_right(const tinsel_bvh_node& n) { return n.right_index_leaf & 0x7fffffffu; }
+
+bool convert_bvh(const tinsel_bvh_node* ref, int numNodes, ConvertedBvh& out)
+{
+    out.nodes.clear();
+    out.maxLeafDepth = 0;
+    if (numNodes <= 0 || !ref)
+        return false;
+
+    if (ref_is_leaf(ref[0]))
+    {
+        out.root = kLeafBit | ref[0].left_index;
+        return true;
+    }
+
+    // DFS pre-order numbering of internal nodes (keeps the builder's locality: a node's left
+    // subtree follows it immediately)
+    std::vector<uint32_t> internalIndex((size_t)numNodes, kNoNode);
+    struct Item { uint32_t node; int depth; };
+    std::vector<Item> stack;
+    std::vector<uint32_t> order;
+    stack.push_back({ 0u, 0 });
+    while (!stack.empty())
+    {
+        Item it = stack.back();
+        stack.pop_back();
+        const tinsel_bvh_node& n = ref[it.node];
+        if (ref_is_leaf(n))
+        {
+            if (it.depth > out.maxLeafDepth)
+                out.maxLeafDepth = it.depth;
+            continue;
+        }
+        if (n.left_index >= (uint32_t)numNodes || ref_right(n) >= (uint32_t)numNodes)
+            return false;
+        internalIndex[it.node] = (uint32_t)order.size();
+        order.push_back(it.node);
+        stack.push_back({ ref_right(n), it.depth + 1 });
+        stack.push_back({ n.left_index, it.depth + 1 });
+    }
+
+    out.nodes.resize(order.size());
+    for (size_t k = 0; k < order.size(); ++k)
+    {
+        const tinsel_bvh_node& n = ref[order[k]];
+        const tinsel_bvh_node& l = ref[n.left_index];
+        const tinsel_bvh_node& r = ref[ref_right(n)];
+        Node64& o = out.nodes[k];
+        memset(&o, 0, sizeof(o));
+        o.lminx = l.lower.x; o.lminy = l.lower.y; o.lminz = l.lower.z;
+        o.lmaxx = l.upper.x; o.lmaxy = l.upper.y; o.lmaxz = l.upper.z;
+        o.rminx = r.lower.x; o.rminy = r.lower.y; o.rminz = r.lower.z;
+        o.rmaxx = r.upper.x; o.rmaxy = r.upper.y; o.rmaxz = r.upper.z;
+        o.left = ref_is_leaf(l) ? (kLeafBit | l.left_index) : internalIndex[n.left_index];
+        o.right = ref_is_leaf(r) ? (kLeafBit | r.left_index) : internalIndex[ref_right(n)];
+    }
+    out.root = 0;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// material digestion: every material-only sub-expression, in the reference's own precision
+
+void make_material(const tinsel_primitive& p, Mat128& m)
+{
+    const tinsel_material& a = p.material;
+    memset(&m, 0, sizeof(m));
+    m.emission[0] = a.emission.x; m.emission[1] = a.emission.y; m.emission[2] = a.emission.z;
+    m.color[0] = a.color.x; m.color[1] = a.color.y; m.color[2] = a.color.z;
+    m.absorption[0] = a.absorption.x; m.absorption[1] = a.absorption.y; m.absorption[2] = a.absorption.z;
+
+    // Material::GetIndexOfRefraction (scene.h:72-78): sqrtf(0.08*specular) with a double product
+    if (a.eta == 0.0f)
+        m.ior = 2.0f/(1.0f - sqrtf((float)(0.08*(double)a.specular))) - 1.0f;
+    else
+        m.ior = a.eta;
+
+    m.metallic = a.metallic;
+    m.subsurface = a.subsurface;
+    m.roughness = a.roughness;
+    m.transmission = a.transmission;
+    m.clearcoat = a.clearcoat;
+
+    // disney.h:306-310
+    const float c[3] = { a.color.x, a.color.y, a.color.z };
+    const float Cdlum = (float)(.3*(double)c[0] + .6*(double)c[1] + .1*(double)c[2]);
+    float Ctint[3] = { 1.0f, 1.0f, 1.0f };
+    if (Cdlum > 0.0f)
+    {
+        const float rcp = (float)(1.0/(double)Cdlum);      // Cdlin/Cdlum == Cdlin*(1.0/Cdlum), maths.h:242
+        for (int k = 0; k < 3; ++k)
+            Ctint[k] = c[k]*rcp;
+    }
+    const float spec08 = (float)((double)a.specular*.08);   // `mat.specular*.08` is a double, narrowed by operator*(Real, Vec3)
+    for (int k = 0; k < 3; ++k)
+    {
+        const float tint = 1.0f + (Ctint[k] - 1.0f)*a.specular_tint;   // Lerp(Vec3(1), Ctint, specularTint)
+        const float s = tint*spec08;
+        m.cspec0[k] = s + (c[k] - s)*a.metallic;                       // Lerp(., Cdlin, metallic)
+        m.sqrtColor[k] = sqrtf(c[k]);                                  // disney.h:352
+    }
+
+    // Lerp(.1,.001, clearcoatGloss) evaluated in double (disney.h:387)
+    m.clearcoatAlpha = (float)(.1 + (.001 - .1)*(double)a.clearcoat_gloss);
+
+    // PrimitiveArea (intersection.h:833-853)
+    if (p.type == TINSEL_GEOM_SPHERE)
+        m.area = 4.0f*kPi*p.geo.sphere.radius*p.geo.sphere.radius;
+    else if (p.type == TINSEL_GEOM_MESH)
+        m.area = p.geo.mesh.area*p.end_transform.s;
+    else
+        m.area = 0.0f;
+
+    m.lightSamples = p.light_samples;
+}
+
+Xform to_xform(const tinsel_transform& t)
+{
+    Xform x;
+    x.p = V3(t.p.x, t.p.y, t.p.z);
+    x.r = { t.r.x, t.r.y, t.r.z, t.r.w };
+    x.s = t.s;
+    return x;
+}
+
+// ---------------------------------------------------------------------------
+
+struct DeviceArena
+{
+    std::vector<void*> allocs;
+
+    template <class T>
+    T* upload(const T* host, size_t count)
+    {
+        if (count == 0)
+            return nullptr;
+        void* d = nullptr;
+        if (hipMalloc(&d, sizeof(T)*count) != hipSuccess)
+            return nullptr;
+        allocs.push_back(d);
+        if (hipMemcpy(d, host, sizeof(T)*count, hipMemcpyHostToDevice) != hipSuccess)
+            return nullptr;
+        return (T*)d;
+    }
+
+    void release()
+    {
+        for (void* p : allocs)
+            (void)hipFree(p);
+        allocs.clear();
+    }
+};
+
+const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals" };
+enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_COUNT };
+
+struct TimedSpan { int kernel; hipEvent_t start, stop; };
+
+} // namespace
+
+struct tinsel_hip
+{
+    int device = 0;
+    int numCUs = 256;
+
+    DeviceArena sceneMem;
+    DevScene scene;
+    int stackNeed = 16;
+    int neePerPath = 0;
+
+    int width = 0, height = 0;
+    float4* accum = nullptr;
+    bool accumOwned = true;
+
+    // path batch buffers
+    size_t batchSlots = 0;
+    int batchNee = -1;
+    int batchDepth = -1;
+    std::vector<void*> batchAllocs;
+    PathState ps;
+    QueueCtl ctl;
+    uint32_t* ctlBase = nullptr;
+    size_t ctlWords = 0;
+    uint32_t* queues[2] = { nullptr, nullptr };
+    uint32_t* queueNee = nullptr;
+    uint32_t* passSeedsDev = nullptr;
+    size_t passSeedsCap = 0;
+    unsigned long long* statsDev = nullptr;
+
+    size_t maxBatchSlots = 4u << 20;
+    int pipeline = TINSEL_PIPELINE_WAVEFRONT;
+    bool countDetail = false;
+
+    uint32_t passIndex = 0;
+    int shardRank = 0, shardWorld = 1, shardTile = 32;
+
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> eventPool;
+    double gpuSeconds = 0.0;
+};
+
+namespace {
+
+void free_batch(tinsel_hip* r)
+{
+    for (void* p : r->batchAllocs)
+        (void)hipFree(p);
+    r->batchAllocs.clear();
+    r->batchSlots = 0;
+    r->batchNee = -1;
+    r->batchDepth = -1;
+}
+
+template <class T>
+int batch_alloc(tinsel_hip* r, T** out, size_t count)
+{
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(T)*(count ? count : 1)));
+    r->batchAllocs.push_back(d);
+    *out = (T*)d;
+    return 0;
+}
+
+int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
+{
+    const int K = r->neePerPath;
+    if (r->batchSlots >= slots && r->batchNee == K && r->batchDepth >= maxDepth)
+        return 0;
+    free_batch(r);
+
+    PathState& ps = r->ps;
+    if (batch_alloc(r, &ps.rayO, slots) || batch_alloc(r, &ps.rayD, slots) || batch_alloc(r, &ps.thr, slots) ||
+        batch_alloc(r, &ps.rad, slots) || batch_alloc(r, &ps.absorb, slots) || batch_alloc(r, &ps.rngRaster, slots) ||
+        batch_alloc(r, &ps.hit, slots) || batch_alloc(r, &ps.hitPrim, slots) ||
+        batch_alloc(r, &ps.nee, slots*(size_t)K*4) || batch_alloc(r, &ps.neeThr, slots) ||
+        batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots) || batch_alloc(r, &r->queueNee, slots))
+        return -1;
+    ps.neePerPath = K;
+
+    const size_t D = (size_t)maxDepth + 1;
+    r->ctlWords = D*5;
+    if (batch_alloc(r, &r->ctlBase, r->ctlWords))
+        return -1;
+    r->ctl.activeCount = r->ctlBase;
+    r->ctl.neeCount = r->ctlBase + D;
+    r->ctl.cursorExtend = r->ctlBase + 2*D;
+    r->ctl.cursorShade = r->ctlBase + 3*D;
+    r->ctl.cursorShadow = r->ctlBase + 4*D;
+    r->ctl.stats = r->statsDev;
+
+    r->batchSlots = slots;
+    r->batchNee = K;
+    r->batchDepth = maxDepth;
+    return 0;
+}
+
+// CameraSampler constructor (util.h:45-71) + Mat44(Transform) (maths.h:841-849), host side, once per call
+void make_camera(const tinsel_camera& c, int width, int height, CameraParams& out)
+{
+    // Mat33(Quat): columns are q*e_k (maths.h:654-663); Mat44(Transform): cols*s, translation p*s with s == 1
+    Q4 q = { c.rotation.x, c.rotation.y, c.rotation.z, c.rotation.w };
+    const float s = 1.0f;
+    V3 c0 = qrotate(q, V3(1.0f, 0.0f, 0.0f))*s;
+    V3 c1 = qrotate(q, V3(0.0f, 1.0f, 0.0f))*s;
+    V3 c2 = qrotate(q, V3(0.0f, 0.0f, 1.0f))*s;
+    V3 c3 = V3(c.position.x, c.position.y, c.position.z)*s;
+
+    // column-major 4x4s
+    float c2w[16] = { c0.x, c0.y, c0.z, 0.0f, c1.x, c1.y, c1.z, 0.0f, c2.x, c2.y, c2.z, 0.0f, c3.x, c3.y, c3.z, 1.0f };
+
+    // rasterToScreen given row-wise in the reference constructor (maths.h:801-829)
+    float r2s[16] = { 2.0f/width, 0.0f, 0.0f, 0.0f,
+                      0.0f, -2.0f/height, 0.0f, 0.0f,
+                      0.0f, 0.0f, 1.0f, 0.0f,
+                      -1.0f, 1.0f, 1.0f, 1.0f };
+
+    float f = tanf(c.fov*0.5f);
+    float aspect = float(width)/height;
+
+    float s2c[16] = { f*aspect, 0.0f, 0.0f, 0.0f,
+                      0.0f, f, 0.0f, 0.0f,
+                      0.0f, 0.0f, -1.0f, 0.0f,
+                      0.0f, 0.0f, 0.0f, 1.0f };
+
+    // MatrixMultiply<4,4,4> (maths.h:83-99): result[i+j*4] = sum_k a[i+k*4]*b[k+j*4], k ascending from t = 0
+    auto mul = [](float* result, const float* a, const float* b) {
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+            {
+                float t = 0.0f;
+                for (int k = 0; k < 4; ++k)
+                    t += a[i + k*4]*b[k + j*4];
+                result[i + j*4] = t;
+            }
+    };
+
+    float tmp[16];
+    mul(tmp, c2w, s2c);             // cameraToWorld*screenToCamera
+    mul(out.r2w, tmp, r2s);         // ... *rasterToScreen
+    out.ox = c2w[12]; out.oy = c2w[13]; out.oz = c2w[14];
+    out.shutterStart = c.shutter_start;
+    out.shutterEnd = c.shutter_end;
+}
+
+hipEvent_t get_event(tinsel_hip* r)
+{
+    if (!r->eventPool.empty())
+    {
+        hipEvent_t e = r->eventPool.back();
+        r->eventPool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ScopedTimer
+{
+    tinsel_hip* r;
+    hipStream_t stream;
+    TimedSpan span;
+    bool on;
+    ScopedTimer(tinsel_hip* r_, int kernel, hipStream_t s) : r(r_), stream(s), on(r_->timing)
+    {
+        if (on)
+        {
+            span.kernel = kernel;
+            span.start = get_event(r);
+            span.stop = get_event(r);
+            (void)hipEventRecord(span.start, stream);
+        }
+    }
+    ~ScopedTimer()
+    {
+        if (on)
+        {
+            (void)hipEventRecord(span.stop, stream);
+            r->spans.push_back(span);
+        }
+    }
+};
+
+int pick_stack(int need)
+{
+    const int sizes[] = { 8, 12, 16, 24, 32, 48, 64, 96, 128, 156 };
+    for (int s : sizes)
+        if (need <= s)
+            return s;
+    return -1;
+}
+
+size_t stack_bytes(const tinsel_hip* r) { return (size_t)r->stackNeed*kBlock*sizeof(uint32_t); }
+
+void launch_extend(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
+{
+    if (r->countDetail)
+        hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce);
+    else
+        hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce);
+}
+
+void launch_shadow(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
+{
+    if (r->countDetail)
+        hipLaunchKernelGGL((k_shadow<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce);
+    else
+        hipLaunchKernelGGL((k_shadow<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce);
+}
+
+void launch_mega(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
+{
+    if (r->countDetail)
+        hipLaunchKernelGGL((k_mega<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev);
+    else
+        hipLaunchKernelGGL((k_mega<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev);
+}
+
+void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
+{
+    hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum);
+}
+
+int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp)
+{
+    const size_t npix = (size_t)fp.width*fp.height;
+    const size_t slots = npix*(size_t)fp.numPasses;
+    const int gridFlat = (int)((slots + kBlock - 1)/kBlock);
+    const int gridPersist = (int)std::min<size_t>((size_t)gridFlat, (size_t)r->numCUs*8);
+    HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
+
+    if (r->pipeline == TINSEL_PIPELINE_MEGAKERNEL)
+    {
+        ScopedTimer t(r, KN_MEGA, st);
+        launch_mega(r, st, gridFlat, cam, fp);
+    }
+    else
+    {
+        {
+            ScopedTimer t(r, KN_GENERATE, st);
+            hipLaunchKernelGGL(k_generate, dim3(gridFlat), dim3(kBlock), 0, st, r->ps, r->ctl, r->queues[0], cam, fp, r->passSeedsDev);
+        }
+        for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
+        {
+            uint32_t* qin = r->queues[bounce & 1];
+            uint32_t* qout = r->queues[(bounce + 1) & 1];
+            {
+                ScopedTimer t(r, KN_EXTEND, st);
+                launch_extend(r, st, gridPersist, qin, bounce);
+            }
+            {
+                ScopedTimer t(r, KN_SHADE, st);
+                hipLaunchKernelGGL(k_shade, dim3(gridPersist), dim3(kBlock), 0, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, fp.maxDepth);
+            }
+            if (r->neePerPath > 0)
+            {
+                ScopedTimer t(r, KN_SHADOW, st);
+                launch_shadow(r, st, gridPersist, r->queueNee, bounce);
+            }
+        }
+    }
+
+    {
+        ScopedTimer t(r, KN_ACCUMULATE, st);
+        const int gridPix = (int)((npix + kBlock - 1)/kBlock);
+        hipLaunchKernelGGL(k_accumulate, dim3(gridPix), dim3(kBlock), 0, st, r->ps, fp, r->accum);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, int passes, hipStream_t st)
+{
+    if (!r || !camera || !options)
+        return fail("render: null argument");
+    if (!r->accum || options->width != r->width || options->height != r->height)
+        return fail("render: options.width/height do not match the last tinsel_hip_init");
+    if (passes < 1)
+        return fail("render: passes must be >= 1");
+    HIP_TRY(hipSetDevice(r->device));
+
+    // return finished timing events to the pool
+    for (TimedSpan& s : r->spans)
+    {
+        r->eventPool.push_back(s.start);
+        r->eventPool.push_back(s.stop);
+    }
+    r->spans.clear();
+
+    CameraParams cam;
+    make_camera(*camera, options->width, options->height, cam);
+
+    FrameParams fp;
+    fp.width = options->width;
+    fp.height = options->height;
+    fp.maxDepth = options->max_depth;
+    fp.shardRank = r->shardRank;
+    fp.shardWorld = r->shardWorld;
+    fp.shardTile = r->shardTile;
+    fp.filterType = options->filter.type;
+    fp.filterWidth = options->filter.width;
+    fp.filterFalloff = options->filter.falloff;
+    fp.filterOffset = options->filter.offset;
+    fp.clampLen = options->clamp;
+    fp.passBase = 0;
+    fp.numPasses = 1;
+
+    const size_t npix = (size_t)fp.width*fp.height;
+    const int gridPix = (int)((npix + kBlock - 1)/kBlock);
+
+    if (options->mode == TINSEL_MODE_NORMALS)
+    {
+        ScopedTimer t(r, KN_NORMALS, st);
+        launch_normals(r, st, gridPix, cam, fp);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if (options->mode != TINSEL_MODE_PATHTRACE)
+        return 0;       // eComplexity is a no-op in the reference too (render.cpp:516-519)
+    if (fp.maxDepth < 1)
+        return 0;
+
+    // pass seeds for this call: passSeed[s] = (s+1)-th output of Random(1).Rand()
+    std::vector<uint32_t> seeds((size_t)passes);
+    {
+        Rng sr = Rng::seeded(1u);
+        for (uint32_t i = 0; i < r->passIndex; ++i)
+            (void)sr.rand();
+        for (int i = 0; i < passes; ++i)
+            seeds[(size_t)i] = sr.rand();
+    }
+    if (r->passSeedsCap < (size_t)passes)
+    {
+        if (r->passSeedsDev)
+            (void)hipFree(r->passSeedsDev);
+        HIP_TRY(hipMalloc((void**)&r->passSeedsDev, sizeof(uint32_t)*(size_t)passes));
+        r->passSeedsCap = (size_t)passes;
+    }
+    HIP_TRY(hipMemcpyAsync(r->passSeedsDev, seeds.data(), sizeof(uint32_t)*(size_t)passes, hipMemcpyHostToDevice, st));
+    // the host vector dies at return: make the copy complete first (pageable memcpy is staged synchronously
+    // by the runtime, but do not rely on it)
+    HIP_TRY(hipStreamSynchronize(st));
+
+    int perBatch = (int)std::max<size_t>(1, r->maxBatchSlots/npix);
+    if (perBatch > passes)
+        perBatch = passes;
+    if (ensure_batch(r, npix*(size_t)perBatch, fp.maxDepth))
+        return -1;
+
+    for (int done = 0; done < passes; done += perBatch)
+    {
+        fp.passBase = done;
+        fp.numPasses = std::min(perBatch, passes - done);
+        if (render_batch(r, st, cam, fp))
+            return -1;
+    }
+    r->passIndex += (uint32_t)passes;
+    return 0;
+}
+
+} // namespace
+
+// ===========================================================================
+// C-ABI
+
+extern "C" {
+
+const char* tinsel_hip_last_error(void) { return g_error.c_str(); }
+
+tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
+{
+    if (!desc || !desc->primitives || desc->num_primitives <= 0 || !desc->bvh_nodes || desc->num_bvh_nodes <= 0)
+    {
+        fail("create: empty scene (Scene::Build must have run)");
+        return nullptr;
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+        fail("create: no HIP device visible -- this library has no CPU fallback");
+        return nullptr;
+    }
+    if (device_index < 0 || device_index >= ndev)
+    {
+        fail("create: bad device index");
+        return nullptr;
+    }
+    HIP_TRY_NULL(hipSetDevice(device_index));
+
+    tinsel_hip* r = new tinsel_hip();
+    r->device = device_index;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_index) == hipSuccess)
+        r->numCUs = prop.multiProcessorCount;
+
+    if (const char* e = getenv("TINSEL_HIP_BATCH_PATHS"))
+    {
+        long long v = atoll(e);
+        if (v >= 65536)
+            r->maxBatchSlots = (size_t)v;
+    }
+
+    DevScene& sc = r->scene;
+    memset(&sc, 0, sizeof(sc));
+
+    const int P = desc->num_primitives;
+    std::vector<Prim64> prims((size_t)P);
+    std::vector<Mat128> mats((size_t)P);
+    std::vector<Moving64> moving;
+    std::vector<DevMesh> meshes;
+    std::vector<int32_t> lights;
+    std::map<uint64_t, uint32_t> meshIndex;     // MeshGeometry::id (util.h:20) -> DevScene::meshes index
+    int maxMeshNeed = 0;
+    int totalLightSamples = 0;
+
+    bool ok = true;
+
+    for (int i = 0; i < P && ok; ++i)
+    {
+        const tinsel_primitive& p = desc->primitives[i];
+        Prim64& o = prims[(size_t)i];
+        memset(&o, 0, sizeof(o));
+
+        make_material(p, mats[(size_t)i]);
+        if (p.light_samples > 0)
+        {
+            if (p.type == TINSEL_GEOM_PLANE)
+            {
+                fail("create: a plane cannot be a light (PrimitiveSample asserts, intersection.h:871-875)");
+                ok = false;
+                break;
+            }
+            lights.push_back(i);
+            totalLightSamples += p.light_samples;
+        }
+
+        const bool isStatic = memcmp(&p.start_transform, &p.end_transform, sizeof(tinsel_transform)) == 0;
+        const Xform xs = to_xform(p.start_transform), xe = to_xform(p.end_transform);
+        if (isStatic)
+        {
+            // InterpolateTransform(a, a, t) is t-independent: evaluate it once, with the same function
+            const Xform x = interpolate_xform(xs, xe, 0.0f);
+            o.px = x.p.x; o.py = x.p.y; o.pz = x.p.z; o.s = x.s;
+            o.rx = x.r.x; o.ry = x.r.y; o.rz = x.r.z; o.rw = x.r.w;
+        }
+        else
+        {
+            o.flags |= kPrimMoving;
+            o.moving = (uint32_t)moving.size();
+            Moving64 mv;
+            mv.spx = xs.p.x; mv.spy = xs.p.y; mv.spz = xs.p.z; mv.ss = xs.s;
+            mv.srx = xs.r.x; mv.sry = xs.r.y; mv.srz = xs.r.z; mv.srw = xs.r.w;
+            mv.epx = xe.p.x; mv.epy = xe.p.y; mv.epz = xe.p.z; mv.es = xe.s;
+            mv.erx = xe.r.x; mv.ery = xe.r.y; mv.erz = xe.r.z; mv.erw = xe.r.w;
+            moving.push_back(mv);
+        }
+
+        if (p.type == TINSEL_GEOM_SPHERE)
+        {
+            o.type = kPrimSphere;
+            o.g0 = p.geo.sphere.radius;
+        }
+        else if (p.type == TINSEL_GEOM_PLANE)
+        {
+            o.type = kPrimPlane;
+            o.g0 = p.geo.plane.plane[0]; o.g1 = p.geo.plane.plane[1]; o.g2 = p.geo.plane.plane[2]; o.g3 = p.geo.plane.plane[3];
+        }
+        else if (p.type == TINSEL_GEOM_MESH)
+        {
+            o.type = kPrimMesh;
+            const tinsel_mesh_geometry& g = p.geo.mesh;
+            // Key on MeshGeometry::id and rewrite EVERY instance (the reference forgets both: render.cu:1000-1011)
+            auto it = meshIndex.find(g.id);
+            if (it != meshIndex.end())
+            {
+                o.mesh = it->second;
+            }
+            else
+            {
+                const int numTris = g.num_indices/3;
+                if (numTris <= 0 || !g.positions || !g.normals || !g.indices || !g.nodes || !g.cdf)
+                {
+                    fail("create: mesh primitive with missing arrays");
+                    ok = false;
+                    break;
+                }
+                ConvertedBvh cb;
+                if (!convert_bvh(g.nodes, g.num_nodes, cb))
+                {
+                    fail("create: malformed mesh BVH");
+                    ok = false;
+                    break;
+                }
+                std::vector<Tri48> tris((size_t)numTris);
+                for (int t = 0; t < numTris; ++t)
+                {
+                    const int i0 = g.indices[t*3 + 0], i1 = g.indices[t*3 + 1], i2 = g.indices[t*3 + 2];
+                    if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= g.num_vertices || i1 >= g.num_vertices || i2 >= g.num_vertices)
+                    {
+                        fail("create: mesh index out of range");
+                        ok = false;
+                        break;
+                    }
+                    Tri48& T = tris[(size_t)t];
+                    T.ax = g.positions[i0].x; T.ay = g.positions[i0].y; T.az = g.positions[i0].z; T.i0 = i0;
+                    T.bx = g.positions[i1].x; T.by = g.positions[i1].y; T.bz = g.positions[i1].z; T.i1 = i1;
+                    T.cx = g.positions[i2].x; T.cy = g.positions[i2].y; T.cz = g.positions[i2].z; T.i2 = i2;
+                }
+                if (!ok)
+                    break;
+
+                DevMesh dm;
+                memset(&dm, 0, sizeof(dm));
+                dm.nodes = r->sceneMem.upload(cb.nodes.data(), cb.nodes.size());
+                dm.tris = r->sceneMem.upload(tris.data(), tris.size());
+                dm.normals = r->sceneMem.upload(&g.normals[0].x, (size_t)g.num_vertices*3);
+                dm.cdf = r->sceneMem.upload(g.cdf, (size_t)numTris);
+                dm.root = cb.root;
+                dm.numTris = numTris;
+                dm.stackNeed = cb.maxLeafDepth + 1;
+                if ((!cb.nodes.empty() && !dm.nodes) || !dm.tris || !dm.normals || !dm.cdf)
+                {
+                    fail("create: device allocation failed (mesh)");
+                    ok = false;
+                    break;
+                }
+                if (dm.stackNeed > maxMeshNeed)
+                    maxMeshNeed = dm.stackNeed;
+                o.mesh = (uint32_t)meshes.size();
+                meshIndex[g.id] = o.mesh;
+                meshes.push_back(dm);
+            }
+        }
+        else
+        {
+            fail("create: unknown primitive type");
+            ok = false;
+        }
+    }
+
+    ConvertedBvh sceneBvh;
+    if (ok && !convert_bvh(desc->bvh_nodes, desc->num_bvh_nodes, sceneBvh))
+    {
+        fail("create: malformed scene BVH");
+        ok = false;
+    }
+
+    if (ok)
+    {
+        const int need = sceneBvh.maxLeafDepth + 1 + maxMeshNeed;
+        r->stackNeed = pick_stack(need);
+        if (r->stackNeed < 0)
+        {
+            fail("create: BVH too deep for the 156-entry LDS traversal stack");
+            ok = false;
+        }
+    }
+
+    if (ok)
+    {
+        sc.nodes = r->sceneMem.upload(sceneBvh.nodes.data(), sceneBvh.nodes.size());
+        sc.root = sceneBvh.root;
+        sc.prims = r->sceneMem.upload(prims.data(), prims.size());
+        sc.mats = r->sceneMem.upload(mats.data(), mats.size());
+        sc.moving = r->sceneMem.upload(moving.data(), moving.size());
+        sc.meshes = r->sceneMem.upload(meshes.data(), meshes.size());
+        sc.lights = r->sceneMem.upload(lights.data(), lights.size());
+        sc.numPrims = P;
+        sc.numLights = (int)lights.size();
+        sc.horizon[0] = desc->sky_horizon.x; sc.horizon[1] = desc->sky_horizon.y; sc.horizon[2] = desc->sky_horizon.z;
+        sc.zenith[0] = desc->sky_zenith.x; sc.zenith[1] = desc->sky_zenith.y; sc.zenith[2] = desc->sky_zenith.z;
+
+        if ((!sceneBvh.nodes.empty() && !sc.nodes) || !sc.prims || !sc.mats || (!moving.empty() && !sc.moving) ||
+            (!meshes.empty() && !sc.meshes) || (!lights.empty() && !sc.lights))
+        {
+            fail("create: device allocation failed (scene)");
+            ok = false;
+        }
+    }
+
+    if (ok && desc->probe_valid)
+    {
+        const size_t n = (size_t)desc->probe_width*desc->probe_height;
+        if (!desc->probe_data || !desc->probe_pdf_x || !desc->probe_cdf_x || !desc->probe_pdf_y || !desc->probe_cdf_y || n == 0)
+        {
+            fail("create: probe marked valid but arrays missing");
+            ok = false;
+        }
+        else
+        {
+            sc.probe.data = (const float4*)r->sceneMem.upload((const float*)desc->probe_data, n*4);
+            sc.probe.pdfX = r->sceneMem.upload(desc->probe_pdf_x, n);
+            sc.probe.cdfX = r->sceneMem.upload(desc->probe_cdf_x, n);
+            sc.probe.pdfY = r->sceneMem.upload(desc->probe_pdf_y, (size_t)desc->probe_height);
+            sc.probe.cdfY = r->sceneMem.upload(desc->probe_cdf_y, (size_t)desc->probe_height);
+            sc.probe.width = desc->probe_width;
+            sc.probe.height = desc->probe_height;
+            sc.probe.valid = 1;
+            if (!sc.probe.data || !sc.probe.pdfX || !sc.probe.cdfX || !sc.probe.pdfY || !sc.probe.cdfY)
+            {
+                fail("create: device allocation failed (probe)");
+                ok = false;
+            }
+        }
+    }
+
+    if (ok)
+    {
+        r->neePerPath = totalLightSamples + (sc.probe.valid ? 1 : 0);
+        sc.totalLightSamples = r->neePerPath;
+        if (hipMalloc((void**)&r->statsDev, sizeof(unsigned long long)*8) != hipSuccess ||
+            hipMemset(r->statsDev, 0, sizeof(unsigned long long)*8) != hipSuccess)
+        {
+            fail("create: device allocation failed (stats)");
+            ok = false;
+        }
+    }
+
+    if (!ok)
+    {
+        r->sceneMem.release();
+        delete r;
+        return nullptr;
+    }
+    return r;
+}
+
+void tinsel_hip_destroy(tinsel_hip* r)
+{
+    if (!r)
+        return;
+    (void)hipSetDevice(r->device);
+    (void)hipDeviceSynchronize();
+    free_batch(r);
+    r->sceneMem.release();
+    if (r->accum && r->accumOwned) (void)hipFree(r->accum);
+    if (r->passSeedsDev) (void)hipFree(r->passSeedsDev);
+    if (r->statsDev) (void)hipFree(r->statsDev);
+    for (TimedSpan& s : r->spans)
+    {
+        (void)hipEventDestroy(s.start);
+        (void)hipEventDestroy(s.stop);
+    }
+    for (hipEvent_t e : r->eventPool)
+        (void)hipEventDestroy(e);
+    delete r;
+}
+
+int tinsel_hip_init(tinsel_hip* r, int width, int height)
+{
+    if (!r || width <= 0 || height <= 0)
+        return fail("init: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (r->accum && r->accumOwned)
+        (void)hipFree(r->accum);
+    r->accum = nullptr;
+    r->accumOwned = true;
+    HIP_TRY(hipMalloc((void**)&r->accum, sizeof(float4)*(size_t)width*height));
+    HIP_TRY(hipMemset(r->accum, 0, sizeof(float4)*(size_t)width*height));
+    r->width = width;
+    r->height = height;
+    return 0;
+}
+
+int tinsel_hip_init_external(tinsel_hip* r, int width, int height, float* device_accum)
+{
+    if (!r || width <= 0 || height <= 0 || !device_accum)
+        return fail("init_external: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (r->accum && r->accumOwned)
+        (void)hipFree(r->accum);
+    r->accum = (float4*)device_accum;
+    r->accumOwned = false;
+    HIP_TRY(hipMemset(r->accum, 0, sizeof(float4)*(size_t)width*height));
+    r->width = width;
+    r->height = height;
+    return 0;
+}
+
+int tinsel_hip_render_async(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, int passes, void* stream)
+{
+    return render_impl(r, camera, options, passes, (hipStream_t)stream);
+}
+
+int tinsel_hip_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, float* out_rgba, int passes)
+{
+    if (render_impl(r, camera, options, passes, nullptr))
+        return -1;
+    if (out_rgba)
+        return tinsel_hip_read_accum(r, out_rgba);
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+float* tinsel_hip_accum_device_ptr(tinsel_hip* r) { return r ? (float*)r->accum : nullptr; }
+
+int tinsel_hip_read_accum(tinsel_hip* r, float* out_rgba)
+{
+    if (!r || !r->accum || !out_rgba)
+        return fail("read_accum: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_rgba, r->accum, sizeof(float4)*(size_t)r->width*r->height, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tinsel_hip_set_shard(tinsel_hip* r, int rank, int world, int tile)
+{
+    if (!r || world < 1 || rank < 0 || rank >= world || tile < 1)
+        return fail("set_shard: bad arguments");
+    r->shardRank = rank;
+    r->shardWorld = world;
+    r->shardTile = tile;
+    return 0;
+}
+
+int tinsel_hip_set_pipeline(tinsel_hip* r, int pipeline)
+{
+    if (!r || (pipeline != TINSEL_PIPELINE_WAVEFRONT && pipeline != TINSEL_PIPELINE_MEGAKERNEL))
+        return fail("set_pipeline: bad arguments");
+    r->pipeline = pipeline;
+    return 0;
+}
+
+int tinsel_hip_set_pass_index(tinsel_hip* r, uint32_t pass_index)
+{
+    if (!r)
+        return fail("set_pass_index: null");
+    r->passIndex = pass_index;
+    return 0;
+}
+
+uint32_t tinsel_hip_get_pass_index(tinsel_hip* r) { return r ? r->passIndex : 0; }
+
+void tinsel_hip_stats(tinsel_hip* r, unsigned long long* rays, unsigned long long* samples, double* gpu_seconds)
+{
+    unsigned long long s[8] = { 0 };
+    if (r && r->statsDev)
+    {
+        (void)hipSetDevice(r->device);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(s, r->statsDev, sizeof(s), hipMemcpyDeviceToHost);
+    }
+    if (rays) *rays = s[0];
+    if (samples) *samples = s[1];
+    if (gpu_seconds) *gpu_seconds = r ? r->gpuSeconds : 0.0;
+}
+
+/* extended counters: [0]=rays [1]=samples [2]=internal node visits [3]=triangle tests
+ * [4]=primitive tests [5]=shadow rays ; [2..4] only count while detail counting is on */
+int tinsel_hip_stats_detail(tinsel_hip* r, unsigned long long* out8)
+{
+    if (!r || !out8)
+        return fail("stats_detail: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out8, r->statsDev, sizeof(unsigned long long)*8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tinsel_hip_set_detail_counters(tinsel_hip* r, int enable)
+{
+    if (!r)
+        return fail("set_detail_counters: null");
+    r->countDetail = enable != 0;
+    return 0;
+}
+
+void tinsel_hip_reset_stats(tinsel_hip* r)
+{
+    if (!r)
+        return;
+    (void)hipSetDevice(r->device);
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(r->statsDev, 0, sizeof(unsigned long long)*8);
+    r->gpuSeconds = 0.0;
+}
+
+int tinsel_hip_enable_kernel_timing(tinsel_hip* r, int enable)
+{
+    if (!r)
+        return fail("enable_kernel_timing: null");
+    r->timing = enable != 0;
+    return 0;
+}
+
+int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entries)
+{
+    if (!r || !out)
+        return fail("kernel_times: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    float total[KN_COUNT] = { 0 };
+    uint32_t launches[KN_COUNT] = { 0 };
+    for (const TimedSpan& s : r->spans)
+    {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess)
+        {
+            total[s.kernel] += ms;
+            launches[s.kernel]++;
+        }
+    }
+    int n = 0;
+    double sum = 0.0;
+    for (int k = 0; k < KN_COUNT && n < max_entries; ++k)
+    {
+        if (!launches[k])
+            continue;
+        memset(&out[n], 0, sizeof(out[n]));
+        strncpy(out[n].name, kKernelNames[k], sizeof(out[n].name) - 1);
+        out[n].launches = launches[k];
+        out[n].total_ms = total[k];
+        sum += total[k];
+        ++n;
+    }
+    r->gpuSeconds += sum*1e-3;
+    return n;
+}
+
+int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths)
+{
+    if (!r || max_paths < 1024)
+        return fail("set_batch_paths: bad arguments");
+    r->maxBatchSlots = (size_t)max_paths;
+    return 0;
+}
+
+int tinsel_hip_stack_entries(tinsel_hip* r) { return r ? r->stackNeed : 0; }
+int tinsel_hip_nee_per_path(tinsel_hip* r) { return r ? r->neePerPath : 0; }
+
+// ---------------------------------------------------------------------------
+// scene packs
+
+int tinsel_pack_open(void* blob, size_t size, tinsel_scene_desc* out_scene, tinsel_camera* out_camera, tinsel_options* out_options)
+{
+    if (!blob || size < sizeof(tinsel_pack_header) || !out_scene)
+        return fail("pack_open: bad arguments");
+    unsigned char* base = (unsigned char*)blob;
+    tinsel_pack_header hdr;
+    memcpy(&hdr, base, sizeof(hdr));
+    if (memcmp(hdr.magic, TINSEL_PACK_MAGIC, 8) != 0 || hdr.version != 1)
+        return fail("pack_open: not a TINPACK1 blob");
+    if (hdr.total_bytes > size)
+        return fail("pack_open: truncated blob");
+
+    auto in_range = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(hdr) && off + bytes <= hdr.total_bytes; };
+
+    if (!in_range(hdr.off_primitives, (uint64_t)hdr.num_primitives*sizeof(tinsel_primitive)) ||
+        !in_range(hdr.off_bvh_nodes, (uint64_t)hdr.num_bvh_nodes*sizeof(tinsel_bvh_node)))
+        return fail("pack_open: section out of range");
+
+    tinsel_primitive* prims = (tinsel_primitive*)(base + hdr.off_primitives);
+    for (uint32_t i = 0; i < hdr.num_primitives; ++i)
+    {
+        tinsel_primitive& p = prims[i];
+        if (p.type != TINSEL_GEOM_MESH)
+            continue;
+        tinsel_mesh_geometry& g = p.geo.mesh;
+        // offsets -> pointers, exactly once (a resolved pointer is far above total_bytes)
+        const uint64_t offs[5] = { (uint64_t)(uintptr_t)g.positions, (uint64_t)(uintptr_t)g.normals, (uint64_t)(uintptr_t)g.indices,
+                                   (uint64_t)(uintptr_t)g.nodes, (uint64_t)(uintptr_t)g.cdf };
+        const uint64_t sizes[5] = { (uint64_t)g.num_vertices*12, (uint64_t)g.num_vertices*12, (uint64_t)g.num_indices*4,
+                                    (uint64_t)g.num_nodes*32, (uint64_t)(g.num_indices/3)*4 };
+        for (int k = 0; k < 5; ++k)
+            if (!in_range(offs[k], sizes[k]))
+                return fail("pack_open: mesh section out of range (or pack already opened)");
+        g.positions = (const tinsel_vec3*)(base + offs[0]);
+        g.normals = (const tinsel_vec3*)(base + offs[1]);
+        g.indices = (const int32_t*)(base + offs[2]);
+        g.nodes = (const tinsel_bvh_node*)(base + offs[3]);
+        g.cdf = (const float*)(base + offs[4]);
+    }
+
+    memset(out_scene, 0, sizeof(*out_scene));
+    out_scene->primitives = prims;
+    out_scene->num_primitives = (int32_t)hdr.num_primitives;
+    out_scene->bvh_nodes = (const tinsel_bvh_node*)(base + hdr.off_bvh_nodes);
+    out_scene->num_bvh_nodes = (int32_t)hdr.num_bvh_nodes;
+    out_scene->sky_horizon = hdr.sky_horizon;
+    out_scene->sky_zenith = hdr.sky_zenith;
+    if (hdr.off_probe_data)
+    {
+        const uint64_t n = (uint64_t)hdr.probe_width*hdr.probe_height;
+        if (!in_range(hdr.off_probe_data, n*16) || !in_range(hdr.off_probe_pdf_x, n*4) || !in_range(hdr.off_probe_cdf_x, n*4) ||
+            !in_range(hdr.off_probe_pdf_y, (uint64_t)hdr.probe_height*4) || !in_range(hdr.off_probe_cdf_y, (uint64_t)hdr.probe_height*4))
+            return fail("pack_open: probe section out of range");
+        out_scene->probe_valid = 1;
+        out_scene->probe_width = hdr.probe_width;
+        out_scene->probe_height = hdr.probe_height;
+        out_scene->probe_data = (const tinsel_vec4*)(base + hdr.off_probe_data);
+        out_scene->probe_pdf_x = (const float*)(base + hdr.off_probe_pdf_x);
+        out_scene->probe_cdf_x = (const float*)(base + hdr.off_probe_cdf_x);
+        out_scene->probe_pdf_y = (const float*)(base + hdr.off_probe_pdf_y);
+        out_scene->probe_cdf_y = (const float*)(base + hdr.off_probe_cdf_y);
+    }
+    if (out_camera)
+        *out_camera = hdr.camera;
+    if (out_options)
+        *out_options = hdr.options;
+    return 0;
+}
+
+} // extern "C"

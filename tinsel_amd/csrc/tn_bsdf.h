@@ -1,0 +1,260 @@
+// tn_bsdf.h -- the Disney uber-BSDF of the reference (src/disney.h), evaluated from the
+// pre-digested Mat128 record.  Material-only sub-expressions that the reference evaluates
+// in double on the host (Cdlum/Ctint/Cspec0 disney.h:306-310, the clearcoat alpha :387,
+// the IOR scene.h:72-78) are computed once in host_scene.cpp with the same expressions.
+#pragma once
+
+#include "tn_scene.h"
+
+namespace tn {
+
+enum BsdfType : int { kReflected = 0, kTransmitted = 1, kSpecular = 2 };   // disney.h:27-32
+
+struct Mat
+{
+    V3 emission, color, absorption, cspec0, sqrtColor;
+    float ior, metallic, subsurface, roughness, transmission, clearcoat, clearcoatAlpha, area;
+    int lightSamples;
+};
+
+TN_D Mat load_mat(const Mat128* mats, int idx)
+{
+    const float4* p = reinterpret_cast<const float4*>(mats + idx);
+    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5];
+    Mat m;
+    m.emission = V3(a.x, a.y, a.z); m.ior = a.w;
+    m.color = V3(b.x, b.y, b.z); m.metallic = b.w;
+    m.absorption = V3(c.x, c.y, c.z); m.subsurface = c.w;
+    m.cspec0 = V3(d.x, d.y, d.z); m.roughness = d.w;
+    m.sqrtColor = V3(e.x, e.y, e.z); m.transmission = e.w;
+    m.clearcoat = f.x; m.clearcoatAlpha = f.y; m.area = f.z; m.lightSamples = __float_as_int(f.w);
+    return m;
+}
+
+// Refract (disney.h:34-47)
+TN_D bool refract(V3 wi, V3 n, float eta, V3& wt)
+{
+    float cosThetaI = dot(n, wi);
+    float sin2ThetaI = maxT(0.0f, 1.0f - cosThetaI*cosThetaI);
+    float sin2ThetaT = eta*eta*sin2ThetaI;
+    if (sin2ThetaT >= 1)
+        return false;
+    float cosThetaT = sqrtf(1.0f - sin2ThetaT);
+    wt = eta*(-wi) + (eta*cosThetaI - cosThetaT)*n;
+    return true;
+}
+
+TN_D float schlick_fresnel(float u)        // disney.h:49-54
+{
+    float m = clampT(1 - u, 0.0f, 1.0f);
+    float m2 = m*m;
+    return m2*m2*m;
+}
+
+TN_D float gtr1(float NDotH, float a)      // disney.h:56-62
+{
+    if (a >= 1) return kInvPi;
+    float a2 = a*a;
+    float t = 1 + (a2 - 1)*NDotH*NDotH;
+    return (a2 - 1)/(kPi*logf(a2)*t);
+}
+
+TN_D float gtr2(float NDotH, float a)      // disney.h:64-69
+{
+    float a2 = a*a;
+    float t = 1.0f + (a2 - 1.0f)*NDotH*NDotH;
+    return a2/(kPi*t*t);
+}
+
+TN_D float smith_ggx(float NDotv, float alphaG)    // disney.h:71-76
+{
+    float a = alphaG*alphaG;
+    float b = NDotv*NDotv;
+    return 1/(NDotv + sqrtf(a + b - a*b));
+}
+
+TN_D float fresnel_dielectric(float VDotN, float etaI, float etaT)     // Fr, disney.h:79-96
+{
+    float SinThetaT2 = sqr(etaI/etaT)*(1.0f - VDotN*VDotN);
+    if (SinThetaT2 > 1.0f)
+        return 1.0f;
+    float LDotN = sqrtf(1.0f - SinThetaT2);
+    float eta = etaT/etaI;
+    float r1 = (VDotN - eta*LDotN)/(VDotN + eta*LDotN);
+    float r2 = (LDotN - eta*VDotN)/(LDotN + eta*VDotN);
+    return 0.5f*(sqr(r1) + sqr(r2));
+}
+
+// BSDFPdf (disney.h:125-166)
+TN_D float bsdf_pdf(const Mat& mat, float etaI, float etaO, V3 n, V3 V, V3 L)
+{
+    if (dot(L, n) <= 0.0f)
+    {
+        float bsdfPdf = 0.0f;
+        float brdfPdf = kInv2Pi*mat.subsurface*0.5f;
+        return lerpf(brdfPdf, bsdfPdf, mat.transmission);
+    }
+    else
+    {
+        float F = fresnel_dielectric(dot(n, V), etaI, etaO);
+        const float a = maxT(0.001f, mat.roughness);
+        const V3 half = safe_normalize(L + V, V3(0.0f));
+        const float cosThetaHalf = absf(dot(half, n));
+        const float pdfHalf = gtr2(cosThetaHalf, a)*cosThetaHalf;
+        float pdfSpec = 0.25f*pdfHalf/maxT(1.e-6f, dot(L, half));
+        float pdfDiff = absf(dot(L, n))*kInvPi*(1.0f - mat.subsurface);
+        float bsdfPdf = pdfSpec*F;
+        float brdfPdf = lerpf(pdfDiff, pdfSpec, 0.5f);
+        return lerpf(brdfPdf, bsdfPdf, mat.transmission);
+    }
+}
+
+// the GTR2 half-vector sampling shared by both specular branches (disney.h:184-204 == 265-285)
+TN_D V3 sample_ggx_reflection(const Mat& mat, V3 U, V3 Vt, V3 N, V3 view, float r1, float r2)
+{
+    const float a = maxT(0.001f, mat.roughness);
+    const float phiHalf = r1*k2Pi;
+    const float cosThetaHalf = sqrtf((1.0f - r2)/(1.0f + (sqr(a) - 1.0f)*r2));
+    const float sinThetaHalf = sqrtf(maxT(0.0f, 1.0f - sqr(cosThetaHalf)));
+    const float sinPhiHalf = sinf(phiHalf);
+    const float cosPhiHalf = cosf(phiHalf);
+
+    V3 half = U*(sinThetaHalf*cosPhiHalf) + Vt*(sinThetaHalf*sinPhiHalf) + N*cosThetaHalf;
+    if (dot(half, view) <= 0.0f)
+        half = half*(-1.0f);
+
+    return 2.0f*dot(view, half)*half - view;
+}
+
+// BSDFSample (disney.h:170-293)
+TN_D void bsdf_sample(const Mat& mat, float etaI, float etaO, V3 U, V3 Vt, V3 N, V3 view, V3& light, float& pdf, int& type, Rng& rng)
+{
+    if (rng.randf() < mat.transmission)
+    {
+        float F = fresnel_dielectric(dot(N, view), etaI, etaO);
+        if (rng.randf() < F)
+        {
+            float r1 = rng.randf();
+            float r2 = rng.randf();
+            type = kReflected;
+            light = sample_ggx_reflection(mat, U, Vt, N, view, r1, r2);
+        }
+        else
+        {
+            float eta = etaI/etaO;
+            if (refract(view, N, eta, light))
+            {
+                type = kSpecular;
+                pdf = (1.0f - F)*mat.transmission;
+                return;
+            }
+            else
+            {
+                pdf = 0.0f;
+                return;
+            }
+        }
+    }
+    else
+    {
+        float r1 = rng.randf();
+        float r2 = rng.randf();
+
+        if (rng.randf() < 0.5f)
+        {
+            if (rng.randf() < mat.subsurface)
+            {
+                const V3 d = uniform_sample_hemisphere(rng);
+                light = U*d.x + Vt*d.y - N*d.z;
+                type = kTransmitted;
+            }
+            else
+            {
+                const V3 d = cosine_sample_hemisphere(r1, r2);
+                light = U*d.x + Vt*d.y + N*d.z;
+                type = kReflected;
+            }
+        }
+        else
+        {
+            light = sample_ggx_reflection(mat, U, Vt, N, view, r1, r2);
+            type = kReflected;
+        }
+    }
+
+    pdf = bsdf_pdf(mat, etaI, etaO, N, view, light);
+}
+
+// BSDFEval (disney.h:296-405)
+TN_D V3 bsdf_eval(const Mat& mat, float etaI, float etaO, V3 N, V3 V, V3 L)
+{
+    float NDotL = dot(N, L);
+    float NDotV = dot(N, V);
+
+    V3 H = normalize(L + V);
+
+    float NDotH = dot(N, H);
+    float LDotH = dot(L, H);
+
+    V3 Cdlin = mat.color;
+    V3 Cspec0 = mat.cspec0;
+
+    V3 bsdf(0.0f);
+    V3 brdf(0.0f);
+
+    if (mat.transmission > 0.0f)
+    {
+        if (NDotL <= 0)
+        {
+            float F = fresnel_dielectric(NDotV, etaI, etaO);
+            bsdf = V3(mat.transmission*(1.0f - F)/absf(NDotL)*(1.0f - mat.metallic));
+        }
+        else
+        {
+            float a = maxT(0.001f, mat.roughness);
+            float Ds = gtr2(NDotH, a);
+            float FH = fresnel_dielectric(LDotH, etaI, etaO);
+            V3 Fs = lerp3(Cspec0, V3(1.0f), FH);
+            float roughg = a;
+            float Gs = smith_ggx(NDotV, roughg)*smith_ggx(NDotL, roughg);
+            bsdf = Gs*Fs*Ds;
+        }
+    }
+
+    if (mat.transmission < 1.0f)
+    {
+        if (NDotL <= 0)
+        {
+            if (mat.subsurface > 0.0f)
+            {
+                V3 s = mat.sqrtColor;
+                float FL = schlick_fresnel(absf(NDotL)), FV = schlick_fresnel(NDotV);
+                float Fd = (1.0f - 0.5f*FL)*(1.0f - 0.5f*FV);
+                brdf = kInvPi*s*mat.subsurface*Fd*(1.0f - mat.metallic);
+            }
+        }
+        else
+        {
+            float a = maxT(0.001f, mat.roughness);
+            float Ds = gtr2(NDotH, a);
+            float FH = schlick_fresnel(LDotH);
+            V3 Fs = lerp3(Cspec0, V3(1.0f), FH);
+            float roughg = a;
+            float Gs = smith_ggx(NDotV, roughg)*smith_ggx(NDotL, roughg);
+
+            float FL = schlick_fresnel(NDotL), FV = schlick_fresnel(NDotV);
+            float Fd90 = 0.5f + 2.0f*LDotH*LDotH*mat.roughness;
+            float Fd = lerpf(1.0f, Fd90, FL)*lerpf(1.0f, Fd90, FV);
+
+            float Dr = gtr1(NDotH, mat.clearcoatAlpha);
+            float Fc = lerpf(.04f, 1.0f, FH);
+            float Gr = smith_ggx(NDotL, .25f)*smith_ggx(NDotV, .25f);
+
+            brdf = kInvPi*Fd*Cdlin*(1.0f - mat.metallic)*(1.0f - mat.subsurface) + Gs*Fs*Ds + V3(mat.clearcoat*Gr*Fc*Dr);
+        }
+    }
+
+    return lerp3(brdf, bsdf, mat.transmission);
+}
+
+} // namespace tn

@@ -1,0 +1,326 @@
+// tn_integrator.h -- the path integrator of the CPU oracle (reference src/render.cpp:103-388)
+// cut into the pieces the streaming pipeline needs.  Every piece is a pure function of the
+// path registers, so the megakernel arm and the wavefront arm run the same arithmetic in the
+// same order; only WHERE the registers live between pieces differs (VGPRs vs HBM queues).
+//
+//   PathTrace loop body (render.cpp:250-385):
+//     on_hit_begin   :255-310   medium bookkeeping, Beer-Lambert, emission with BSDF-side MIS
+//     nee_*          :103-227   SampleLights split into  prepare (RNG + BSDF terms, before the
+//                               shadow trace)  and  resolve (after it)
+//     bsdf_step      :322-363   light-hit termination, BSDFSample/BSDFEval, throughput, next ray
+//     on_miss        :365-384   sky / probe with MIS
+#pragma once
+
+#include "tn_bsdf.h"
+#include "tn_isect.h"
+#include "tn_probe.h"
+
+namespace tn {
+
+constexpr float kRayEpsilon = 0.0001f;      // render.cpp:11
+constexpr float kBsdfSamples = 1.0f;        // render.cpp:9
+constexpr float kProbeSamples = 1.0f;       // render.cpp:10
+
+struct PathRegs
+{
+    V3 o, d;            // rayOrigin, rayDir
+    float time;         // rayTime
+    V3 thr;             // pathThroughput
+    V3 rad;             // totalRadiance
+    Rng rng;
+    float eta;          // rayEta
+    V3 absorption;      // rayAbsorption
+    float bsdfPdf;
+    int rayType;        // BSDFType of the last bounce
+};
+
+// render.cpp:233-248
+TN_D void path_begin(PathRegs& p, V3 o, V3 d, float time, Rng rng)
+{
+    p.o = o; p.d = d; p.time = time;
+    p.thr = V3(1.0f, 1.0f, 1.0f);
+    p.rad = V3(0.0f, 0.0f, 0.0f);
+    p.rng = rng;
+    p.eta = 1.0f;
+    p.absorption = V3(0.0f);
+    p.bsdfPdf = 1.0f;
+    p.rayType = kReflected;
+}
+
+struct HitCtx
+{
+    V3 p;               // hit position
+    V3 n;               // face-forwarded normal (surface == shading normal in the oracle, render.cpp:314)
+    V3 wo;              // -rayDir
+    float etaI, etaO;   // rayEta, outEta
+    V3 outAbsorption;
+};
+
+// render.cpp:255-310.  `bounce` is the loop index i.
+TN_D void on_hit_begin(PathRegs& p, const Mat& mat, float t, V3 n, int bounce, HitCtx& h)
+{
+    if (p.eta == 1.0f)
+    {
+        h.etaO = mat.ior;
+        h.outAbsorption = mat.absorption;
+    }
+    else
+    {
+        h.etaO = 1.0f;
+        h.outAbsorption = V3(0.0f);
+    }
+    h.etaI = p.eta;
+
+    // pathThroughput *= Exp(-rayAbsorption*t)   (render.cpp:272, maths.h:253)
+    V3 a = (-p.absorption)*t;
+    p.thr = p.thr*V3(expf(a.x), expf(a.y), expf(a.z));
+
+    h.p = p.o + p.d*t;
+    h.n = n;
+    h.wo = -p.d;
+
+    if (bounce == 0)
+    {
+        p.rad = p.rad + mat.emission;
+    }
+    else
+    {
+        float lightArea = mat.area;
+        if (lightArea > 0.0f)
+        {
+            float lightPdf = ((1.0f/lightArea)*t*t)/clampT(dot(-p.d, n), 1.e-3f, 1.0f);
+
+            int N = int(float(mat.lightSamples) + kBsdfSamples);
+            float cbsdf = kBsdfSamples/N;
+            float clight = float(mat.lightSamples)/N;
+            float weight = cbsdf*p.bsdfPdf/(cbsdf*p.bsdfPdf + clight*lightPdf);
+
+            if (p.rayType == kSpecular)
+                weight = 1.0f;
+
+            p.rad = p.rad + weight*p.thr*mat.emission;
+        }
+    }
+}
+
+// One NEE shadow ray: everything SampleLights knows BEFORE its Trace() call.
+struct NeeRec
+{
+    V3 o;               // shadow origin
+    V3 wi;
+    float dist;         // sqrtf(dSq) for area lights; < 0 marks a probe sample
+    float nl;           // |dot(lightNormal, wi)|
+    V3 f;               // BSDFEval toward wi   (probe: the finished contribution if unoccluded)
+    float bsdfPdf;
+    float absDot;       // |dot(wi, shadingNormal)|
+    int light;          // light primitive index
+};
+
+// PrimitiveSample (intersection.h:855-904) for light `prim`
+TN_D void primitive_sample(const DevScene& sc, int index, float time, V3& pos, V3& normal, Rng& rng)
+{
+    const Prim64 p = load_prim(sc.prims, index);
+    const Xform x = prim_pose(sc, p, time);
+
+    if (p.type == kPrimSphere)
+    {
+        float u1 = rng.randf();
+        float u2 = rng.randf();
+        pos = xform_point(x, uniform_sample_sphere(u1, u2)*p.g0);
+        normal = normalize(pos - x.p);
+    }
+    else if (p.type == kPrimMesh)
+    {
+        const DevMesh m = sc.meshes[p.mesh];
+        float r = rng.randf();
+
+        // LowerBound(cdf, cdf+numTris, r) (probe.h:162-183), clamped (intersection.h:880-881)
+        int lo = 0, hi = m.numTris;
+        while (lo < hi)
+        {
+            int mid = lo + (hi - lo)/2;
+            if (m.cdf[mid] < r)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        int tri = minI(lo, m.numTris - 1);
+
+        float u, v;
+        uniform_sample_triangle(rng, u, v);
+
+        const float4* tp = reinterpret_cast<const float4*>(m.tris + tri);
+        float4 ta = tp[0], tb = tp[1], tc = tp[2];
+        V3 a(ta.x, ta.y, ta.z), b(tb.x, tb.y, tb.z), c(tc.x, tc.y, tc.z);
+        int i0 = __float_as_int(ta.w), i1 = __float_as_int(tb.w), i2 = __float_as_int(tc.w);
+        const float* nr = m.normals;
+        V3 n1(nr[i0*3 + 0], nr[i0*3 + 1], nr[i0*3 + 2]);
+        V3 n2(nr[i1*3 + 0], nr[i1*3 + 1], nr[i1*3 + 2]);
+        V3 n3(nr[i2*3 + 0], nr[i2*3 + 1], nr[i2*3 + 2]);
+
+        pos = xform_point(x, u*a + v*b + (1.0f - u - v)*c);
+        normal = safe_normalize(xform_vector(x, u*n1 + v*n2 + (1.0f - u - v)*n3), V3(0.0f));
+    }
+    // planes are never lights (PrimitiveSample asserts, intersection.h:871-875)
+}
+
+// render.cpp:158-170 + the BSDF terms of :198-199 (pure functions, hoisted above the trace)
+TN_D void nee_prepare_light(const DevScene& sc, const Mat& surf, const HitCtx& h, float time, int light, Rng& rng, NeeRec& r)
+{
+    V3 lightPos, lightNormal;
+    primitive_sample(sc, light, time, lightPos, lightNormal, rng);
+
+    V3 wi = lightPos - h.p;
+    float dSq = length_sq(wi);
+    wi = divs(wi, sqrtf(dSq));                  // wi /= sqrtf(dSq)  (maths.h:251)
+
+    r.o = h.p + face_forward(h.n, wi)*kRayEpsilon;
+    r.wi = wi;
+    r.dist = sqrtf(dSq);
+    r.nl = absf(dot(lightNormal, wi));
+    r.bsdfPdf = bsdf_pdf(surf, h.etaI, h.etaO, h.n, h.wo, wi);
+    r.f = bsdf_eval(surf, h.etaI, h.etaO, h.n, h.wo, wi);
+    r.absDot = absf(dot(wi, h.n));
+    r.light = light;
+}
+
+// render.cpp:175-219: the part after Trace().  `hitPrim` < 0 means the shadow ray missed.
+TN_D V3 nee_resolve_light(const DevScene& sc, const NeeRec& r, int hitPrim, float t)
+{
+    V3 L(0.0f);
+    if (hitPrim < 0)
+        return L;
+
+    const float kTolerance = 1.e-2f;
+    if (fabsf(t - r.dist) <= kTolerance)
+    {
+        if (absf(r.nl) < 1.e-6f)
+            return L;
+
+        const Mat128* lm = sc.mats + r.light;
+        const float lightArea = lm->area;
+        const int lightSamples = lm->lightSamples;
+        float tSq = t*t;
+        float lightPdf = ((1.0f/lightArea)*tSq)/r.nl;
+
+        if (r.bsdfPdf > 0.0f)
+        {
+            int N = int(float(lightSamples) + kBsdfSamples);
+            float cbsdf = kBsdfSamples/N;
+            float clight = float(lightSamples)/N;
+            float weight = clight*lightPdf/(cbsdf*r.bsdfPdf + clight*lightPdf);
+
+            const Mat128* hm = sc.mats + hitPrim;
+            V3 em(hm->emission[0], hm->emission[1], hm->emission[2]);
+            L = weight*r.f*em*(r.absDot/maxT(1.e-3f, lightPdf));
+        }
+    }
+    return L;
+}
+
+// render.cpp:107-140: probe sample; the whole contribution is known before the trace
+TN_D void nee_prepare_probe(const DevScene& sc, const Mat& surf, const HitCtx& h, Rng& rng, NeeRec& r)
+{
+    V3 skyColor, wi;
+    float skyPdf;
+    probe_sample(sc.probe, wi, skyColor, skyPdf, rng);
+
+    r.o = h.p + face_forward(h.n, wi)*kRayEpsilon;
+    r.wi = wi;
+    r.dist = -1.0f;
+    r.nl = 0.0f;
+    r.light = -1;
+    r.absDot = 0.0f;
+
+    float bsdfPdf = bsdf_pdf(surf, h.etaI, h.etaO, h.n, h.wo, wi);
+    V3 f = bsdf_eval(surf, h.etaI, h.etaO, h.n, h.wo, wi);
+    r.bsdfPdf = bsdfPdf;
+    r.f = V3(0.0f);
+
+    if (bsdfPdf > 0.0f)
+    {
+        int N = int(kProbeSamples + kBsdfSamples);
+        float cbsdf = kBsdfSamples/N;
+        float csky = float(kProbeSamples)/N;
+        float weight = csky*skyPdf/(cbsdf*bsdfPdf + csky*skyPdf);
+        if (weight > 0.0f)
+            r.f = divs(weight*skyColor*f*absf(dot(wi, h.n)), skyPdf);
+    }
+}
+
+// Sums per-light contributions in the oracle's order.  `contrib(k)` returns the resolved
+// contribution of NEE ray k (k counts the probe ray first, then lights x samples).
+template <class Contrib>
+TN_D V3 nee_sum(const DevScene& sc, Contrib contrib)
+{
+    V3 sum(0.0f);
+    int k = 0;
+    if (sc.probe.valid)
+    {
+        sum = sum + contrib(k++);
+        sum = divs(sum, float(kProbeSamples));              // render.cpp:142-143
+    }
+    for (int li = 0; li < sc.numLights; ++li)
+    {
+        const int numSamples = sc.mats[sc.lights[li]].lightSamples;
+        V3 L(0.0f);
+        for (int s = 0; s < numSamples; ++s)
+            L = L + contrib(k++);
+        sum = sum + L*(1.0f/numSamples);                    // render.cpp:223
+    }
+    return sum;
+}
+
+enum StepResult : int { kContinue = 0, kTerminate = 1 };
+
+// render.cpp:322-363
+TN_D int bsdf_step(PathRegs& p, const Mat& mat, const HitCtx& h)
+{
+    if (mat.lightSamples)
+        return kTerminate;
+
+    V3 u, v;
+    basis_from_vector(h.n, u, v);
+
+    V3 bsdfDir;
+    int bsdfType = kReflected;
+    float pdf = 0.0f;
+    bsdf_sample(mat, h.etaI, h.etaO, u, v, h.n, h.wo, bsdfDir, pdf, bsdfType, p.rng);
+    p.bsdfPdf = pdf;
+
+    if (pdf <= 0.0f)
+        return kTerminate;
+
+    V3 f = bsdf_eval(mat, h.etaI, h.etaO, h.n, h.wo, bsdfDir);
+
+    if (dot(bsdfDir, h.n) <= 0.0f)
+    {
+        p.eta = h.etaO;
+        p.absorption = h.outAbsorption;
+    }
+
+    // pathThroughput *= f * Abs(Dot(n, bsdfDir))/bsdfPdf   (Vec3/Real == a*(1.0/s), maths.h:242)
+    p.thr = p.thr*divs(f*absf(dot(h.n, bsdfDir)), pdf);
+
+    p.rayType = bsdfType;
+    p.d = bsdfDir;
+    p.o = h.p + face_forward(h.n, bsdfDir)*kRayEpsilon;
+    return kContinue;
+}
+
+// render.cpp:365-383
+TN_D void on_miss(const DevScene& sc, PathRegs& p, int bounce)
+{
+    float weight = 1.0f;
+    if (sc.probe.valid && bounce > 0 && p.rayType != kSpecular)
+    {
+        float skyPdf = probe_pdf(sc.probe, p.d);
+        int N = int(kProbeSamples + kBsdfSamples);
+        float cbsdf = kBsdfSamples/N;
+        float csky = float(kProbeSamples)/N;
+        weight = cbsdf*p.bsdfPdf/(cbsdf*p.bsdfPdf + csky*skyPdf);
+    }
+    p.rad = p.rad + weight*sky_eval(sc, p.d)*p.thr;
+}
+
+} // namespace tn

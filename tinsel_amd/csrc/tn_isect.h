@@ -1,0 +1,349 @@
+// tn_isect.h -- ray/primitive tests and the two-level closest-hit traversal.
+//
+// Semantics follow the CPU oracle exactly (reference src/intersection.h, src/render.cpp:17-62):
+//   * scene level: DFS over the scene BVH, near child first, NO closest-t cull   (intersection.h:751-799)
+//   * mesh level : DFS with `tChild < tmax` cull, near child first               (intersection.h:678-749)
+//   * closest hit keeps the FIRST visited among equal t (`t < minT`, strict)     (render.cpp:45, intersection.h:650)
+// Only the memory layout differs (tn_scene.h): one 64-B record per internal visit, leaves in the ref.
+#pragma once
+
+#include "tn_scene.h"
+
+namespace tn {
+
+// Per-lane traversal stack living in LDS as stack[entry][lane] (conflict-free: consecutive
+// lanes hit consecutive banks).  `base` already points at this lane's column.
+template <int STRIDE>
+struct LdsStack
+{
+    uint32_t* base;
+    TN_D void set(int i, uint32_t v) { base[i*STRIDE] = v; }
+    TN_D uint32_t get(int i) const { return base[i*STRIDE]; }
+};
+
+struct TraceCounters
+{
+    uint32_t internal;      // Node64 records visited (= internal BVH nodes, both levels)
+    uint32_t tris;          // triangle tests
+    uint32_t prims;         // PrimitiveIntersect calls
+};
+
+TN_D float minf_ref(float a, float b) { return a < b ? a : b; }     // intersection.h:369
+TN_D float maxf_ref(float a, float b) { return a > b ? a : b; }     // intersection.h:370
+
+// IntersectRayAABBFast (intersection.h:373-397)
+TN_D bool ray_aabb(V3 pos, V3 rcp, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t)
+{
+    float l1 = (minx - pos.x)*rcp.x;
+    float l2 = (maxx - pos.x)*rcp.x;
+    float lmin = minf_ref(l1, l2);
+    float lmax = maxf_ref(l1, l2);
+
+    l1 = (miny - pos.y)*rcp.y;
+    l2 = (maxy - pos.y)*rcp.y;
+    lmin = maxf_ref(minf_ref(l1, l2), lmin);
+    lmax = minf_ref(maxf_ref(l1, l2), lmax);
+
+    l1 = (minz - pos.z)*rcp.z;
+    l2 = (maxz - pos.z)*rcp.z;
+    lmin = maxf_ref(minf_ref(l1, l2), lmin);
+    lmax = minf_ref(maxf_ref(l1, l2), lmax);
+
+    bool hit = ((lmax >= 0.f) & (lmax >= lmin));
+    if (hit)
+        t = lmin;
+    return hit;
+}
+
+TN_D Node64 load_node(const Node64* nodes, uint32_t idx)
+{
+    // four 16-B loads of one 64-B aligned record
+    const float4* p = reinterpret_cast<const float4*>(nodes + idx);
+    float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    Node64 n;
+    n.lminx = a.x; n.lminy = a.y; n.lminz = a.z; n.lmaxx = a.w;
+    n.lmaxy = b.x; n.lmaxz = b.y; n.rminx = b.z; n.rminy = b.w;
+    n.rminz = c.x; n.rmaxx = c.y; n.rmaxy = c.z; n.rmaxz = c.w;
+    n.left = __float_as_uint(d.x);
+    n.right = __float_as_uint(d.y);
+    return n;
+}
+
+// IntersectRaySphere + SolveQuadratic (intersection.h:30-83), a == 1
+TN_D bool ray_sphere(V3 center, float radius, V3 o, V3 d, float& outT, V3& outN)
+{
+    V3 q = o - center;
+    float a = 1.0f;
+    float b = 2.0f*dot(q, d);
+    float c = dot(q, q) - (radius*radius);
+
+    float disc = b*b - 4.0f*a*c;
+    if (disc < 0.0f)
+        return false;
+
+    float sgn = (b < 0.0f) ? -1.0f : 1.0f;                 // Sign (maths.h:43)
+    float tt = -0.5f*(b + sgn*sqrtf(disc));
+    float t0 = tt/a;
+    float t1 = c/tt;
+    if (t1 < t0) { float tmp = t0; t0 = t1; t1 = tmp; }    // Sort2 (intersection.h:9-13)
+
+    if (t0 < 0.0f && t1 < 0.0f)
+        return false;
+    if (t0 < 0.0f && t1 > 0.0f)
+        t0 = t1;
+
+    outN = normalize((o + d*t0) - center);
+    outT = t0;
+    return true;
+}
+
+// IntersectRayPlane (intersection.h:85-99); Dot(Vec4,Vec4) keeps the w term (maths.h:331)
+TN_D bool ray_plane(V3 p, V3 dir, float px, float py, float pz, float pw, float& t)
+{
+    float d = px*dir.x + py*dir.y + pz*dir.z + pw*0.0f;
+    if (d == 0.0f)
+        return false;
+    t = -(px*p.x + py*p.y + pz*p.z + pw*1.0f)/d;
+    return t > 0.0f;
+}
+
+// IntersectRayTriTwoSided (intersection.h:117-145)
+TN_D bool ray_tri(V3 p, V3 dir, V3 a, V3 b, V3 c, float& t, float& u, float& v, float& w, float& sign, V3& n)
+{
+    V3 ab = b - a;
+    V3 ac = c - a;
+    n = cross(ab, ac);
+
+    V3 nd = -dir;
+    float d = dot(nd, n);
+    float ood = 1.0f/d;
+    V3 ap = p - a;
+
+    t = dot(ap, n)*ood;
+    if (t < 0.0f)
+        return false;
+
+    V3 e = cross(nd, ap);
+    v = dot(ac, e)*ood;
+    if (v < 0.0f || v > 1.0f)
+        return false;
+    w = -dot(ab, e)*ood;
+    if (w < 0.0f || v + w > 1.0f)
+        return false;
+
+    u = 1.0f - v - w;
+    sign = d;
+    return true;
+}
+
+struct MeshHit
+{
+    float t, u, v, w;
+    int tri;
+    V3 n;
+};
+
+// IntersectRayMesh + MeshQuery (intersection.h:629-749).  `sp` = first free stack slot.
+template <class Stack, bool COUNT>
+TN_D bool ray_mesh(const DevMesh& m, Stack& st, int sp, V3 o, V3 d, MeshHit& hit, TraceCounters& ctr)
+{
+    float closestT = kFltMax;
+    float tmax = kFltMax;
+    V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+
+    const int base = sp;
+    st.set(sp++, m.root);
+
+    while (sp > base)
+    {
+        uint32_t ref = st.get(--sp);
+
+        if (ref & kLeafBit)
+        {
+            const int i = (int)(ref & ~kLeafBit);
+            const float4* tp = reinterpret_cast<const float4*>(m.tris + i);
+            float4 ta = tp[0], tb = tp[1], tc = tp[2];
+            if (COUNT) ctr.tris++;
+
+            float t, u, v, w, sign;
+            V3 n;
+            if (ray_tri(o, d, V3(ta.x, ta.y, ta.z), V3(tb.x, tb.y, tb.z), V3(tc.x, tc.y, tc.z), t, u, v, w, sign, n))
+            {
+                if (t > 0.0f && t < closestT)
+                {
+                    closestT = t;
+                    hit.t = t; hit.u = u; hit.v = v; hit.w = w;
+                    hit.tri = i;
+                    hit.n = n*sign;
+                }
+            }
+            tmax = closestT;    // "truncate ray" (intersection.h:701-702)
+        }
+        else
+        {
+            Node64 nd = load_node(m.nodes, ref);
+            if (COUNT) ctr.internal++;
+
+            float tL, tR;
+            bool hL = ray_aabb(o, rcp, nd.lminx, nd.lminy, nd.lminz, nd.lmaxx, nd.lmaxy, nd.lmaxz, tL) && tL < tmax;
+            bool hR = ray_aabb(o, rcp, nd.rminx, nd.rminy, nd.rminz, nd.rmaxx, nd.rmaxy, nd.rmaxz, tR) && tR < tmax;
+
+            uint32_t first = nd.left, second = nd.right;
+            if (hL && hR && (tL < tR))      // traverse closest first: push far, then near
+            {
+                first = nd.right;
+                second = nd.left;
+            }
+            if (hL)
+                st.set(sp++, first);
+            if (hR)
+                st.set(sp++, second);
+        }
+    }
+    return closestT < kFltMax;
+}
+
+TN_D Xform prim_pose(const DevScene& sc, const Prim64& p, float time)
+{
+    Xform x;
+    if (p.flags & kPrimMoving)
+    {
+        const float4* mp = reinterpret_cast<const float4*>(sc.moving + p.moving);
+        float4 a0 = mp[0], a1 = mp[1], b0 = mp[2], b1 = mp[3];
+        Xform s, e;
+        s.p = V3(a0.x, a0.y, a0.z); s.s = a0.w; s.r = { a1.x, a1.y, a1.z, a1.w };
+        e.p = V3(b0.x, b0.y, b0.z); e.s = b0.w; e.r = { b1.x, b1.y, b1.z, b1.w };
+        x = interpolate_xform(s, e, time);
+    }
+    else
+    {
+        x.p = V3(p.px, p.py, p.pz);
+        x.s = p.s;
+        x.r = { p.rx, p.ry, p.rz, p.rw };
+    }
+    return x;
+}
+
+TN_D Prim64 load_prim(const Prim64* prims, int idx)
+{
+    const float4* pp = reinterpret_cast<const float4*>(prims + idx);
+    float4 a = pp[0], b = pp[1], c = pp[2], d = pp[3];
+    Prim64 p;
+    p.px = a.x; p.py = a.y; p.pz = a.z; p.s = a.w;
+    p.rx = b.x; p.ry = b.y; p.rz = b.z; p.rw = b.w;
+    p.g0 = c.x; p.g1 = c.y; p.g2 = c.z; p.g3 = c.w;
+    p.type = __float_as_uint(d.x); p.flags = __float_as_uint(d.y);
+    p.mesh = __float_as_uint(d.z); p.moving = __float_as_uint(d.w);
+    return p;
+}
+
+// PrimitiveIntersect (intersection.h:951-1020)
+template <class Stack, bool COUNT>
+TN_D bool prim_intersect(const DevScene& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr)
+{
+    const Prim64 p = load_prim(sc.prims, index);
+    if (COUNT) ctr.prims++;
+
+    if (p.type == kPrimPlane)
+    {
+        // the reference interpolates the pose here too but the plane test never reads it
+        bool hit = ray_plane(o, d, p.g0, p.g1, p.g2, p.g3, outT);
+        if (hit)
+            outN = V3(p.g0, p.g1, p.g2);
+        return hit;
+    }
+
+    const Xform x = prim_pose(sc, p, time);
+
+    if (p.type == kPrimSphere)
+    {
+        return ray_sphere(x.p, p.g0*x.s, o, d, outT, outN);
+    }
+
+    // mesh: ray into mesh space
+    V3 lo = inv_xform_point(x, o);
+    V3 ld = inv_xform_vector(x, d);
+
+    const DevMesh m = sc.meshes[p.mesh];
+    MeshHit h;
+    if (!ray_mesh<Stack, COUNT>(m, st, sp, lo, ld, h, ctr))
+        return false;
+
+    // interpolate vertex normals (intersection.h:996-1012)
+    const float4* tp = reinterpret_cast<const float4*>(m.tris + h.tri);
+    const int i0 = __float_as_int(tp[0].w), i1 = __float_as_int(tp[1].w), i2 = __float_as_int(tp[2].w);
+    const float* nr = m.normals;
+    V3 n1(nr[i0*3 + 0], nr[i0*3 + 1], nr[i0*3 + 2]);
+    V3 n2(nr[i1*3 + 0], nr[i1*3 + 1], nr[i1*3 + 2]);
+    V3 n3(nr[i2*3 + 0], nr[i2*3 + 1], nr[i2*3 + 2]);
+
+    V3 smooth = h.u*n1 + h.v*n2 + h.w*n3;
+    if (dot(smooth, h.n) < 0.0f)
+        smooth = smooth*(-1.0f);
+
+    outT = h.t;
+    outN = safe_normalize(xform_vector(x, smooth), h.n);
+    return true;
+}
+
+// Trace (render.cpp:17-62) over QueryBVH (intersection.h:751-799).
+// Returns the primitive index or -1; outN is already FaceForward(n, -dir) (render.cpp:59).
+template <class Stack, bool COUNT>
+TN_D int trace(const DevScene& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr)
+{
+    float minT = kFltMax;
+    int closest = -1;
+    V3 cn;
+
+    V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+
+    int sp = 0;
+    st.set(sp++, sc.root);
+
+    while (sp)
+    {
+        uint32_t ref = st.get(--sp);
+
+        if (ref & kLeafBit)
+        {
+            float t;
+            V3 n;
+            const int index = (int)(ref & ~kLeafBit);
+            if (prim_intersect<Stack, COUNT>(sc, index, st, sp, o, d, time, t, n, ctr))
+            {
+                if (t < minT && t > 0.0f)
+                {
+                    minT = t;
+                    closest = index;
+                    cn = n;
+                }
+            }
+        }
+        else
+        {
+            Node64 nd = load_node(sc.nodes, ref);
+            if (COUNT) ctr.internal++;
+
+            float tL, tR;
+            bool hL = ray_aabb(o, rcp, nd.lminx, nd.lminy, nd.lminz, nd.lmaxx, nd.lmaxy, nd.lmaxz, tL);
+            bool hR = ray_aabb(o, rcp, nd.rminx, nd.rminy, nd.rminz, nd.rmaxx, nd.rmaxy, nd.rmaxz, tR);
+
+            uint32_t first = nd.left, second = nd.right;
+            if (hL && hR && (tL < tR))
+            {
+                first = nd.right;
+                second = nd.left;
+            }
+            if (hL)
+                st.set(sp++, first);
+            if (hR)
+                st.set(sp++, second);
+        }
+    }
+
+    outT = minT;
+    outN = face_forward(cn, -d);
+    return closest;
+}
+
+} // namespace tn

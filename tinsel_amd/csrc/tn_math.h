@@ -1,0 +1,235 @@
+// tn_math.h -- fp32 vector / quaternion / RNG primitives for the gfx950 path tracer.
+//
+// Every function states which reference expression it evaluates; the OPERATION ORDER is
+// part of the contract (the translation unit is compiled with -ffp-contract=off and without
+// fast-math, so each line is the same sequence of IEEE-754 binary32 roundings as the CPU
+// oracle's).  Where the reference silently widens to double (`a*(1.0/s)`, maths.h:242) the
+// double step is a single division whose double->float rounding is innocuous
+// (53 >= 2*24+2), so the correctly-rounded fp32 division used here is bit-identical.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TN_HD __host__ __device__ __forceinline__
+#define TN_D __device__ __forceinline__
+
+namespace tn {
+
+constexpr float kPi = 3.141592653589793f;          // maths.h:32
+constexpr float k2Pi = 3.141592653589793f*2.0f;    // maths.h:33
+constexpr float kInvPi = 1.0f/kPi;                 // maths.h:34
+constexpr float kInv2Pi = 1.0f/k2Pi;               // maths.h:35
+constexpr float kFltMax = 3.402823466e+38f;
+
+struct V3
+{
+    float x, y, z;
+    TN_HD V3() : x(0.0f), y(0.0f), z(0.0f) {}
+    TN_HD explicit V3(float s) : x(s), y(s), z(s) {}
+    TN_HD V3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+};
+
+struct Q4 { float x, y, z, w; };        // quaternion (maths.h:502-525), w = real part
+
+struct Xform { V3 p; Q4 r; float s; };  // Transform (maths.h:575-589)
+
+// maths.h:236-251
+TN_HD V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+TN_HD V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+TN_HD V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+TN_HD V3 operator*(V3 a, float s) { return V3(a.x*s, a.y*s, a.z*s); }
+TN_HD V3 operator*(float s, V3 a) { return V3(a.x*s, a.y*s, a.z*s); }
+TN_HD V3 operator*(V3 a, V3 b) { return V3(a.x*b.x, a.y*b.y, a.z*b.z); }
+// operator/(Vec3, Real s) == a*(1.0/s)  (maths.h:242)
+TN_HD V3 divs(V3 a, float s) { float r = 1.0f/s; return V3(a.x*r, a.y*r, a.z*r); }
+
+TN_HD float dot(V3 a, V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }                                   // maths.h:257
+TN_HD V3 cross(V3 a, V3 b) { return V3(a.y*b.z - b.y*a.z, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x); }   // maths.h:256
+TN_HD float length_sq(V3 a) { return dot(a, a); }
+TN_HD float length(V3 a) { return sqrtf(dot(a, a)); }                                                // maths.h:259
+TN_HD V3 normalize(V3 a) { return divs(a, length(a)); }                                              // maths.h:260
+
+// SafeNormalize (maths.h:261-273): a * (1.0/sqrt(m))
+TN_HD V3 safe_normalize(V3 a, V3 fallback)
+{
+    float m = length_sq(a);
+    if (m > 0.0f)
+    {
+        float r = 1.0f/sqrtf(m);
+        return V3(a.x*r, a.y*r, a.z*r);
+    }
+    return fallback;
+}
+
+// template Abs (maths.h:67-74): `x < 0.0 ? -x : x` (keeps -0.0, propagates NaN)
+TN_HD float absf(float x) { return (x < 0.0f) ? -x : x; }
+// Min/Max templates (maths.h:55-59)
+TN_HD float minT(float a, float b) { return (a < b) ? a : b; }
+TN_HD float maxT(float a, float b) { return (a < b) ? b : a; }
+TN_HD int minI(int a, int b) { return (a < b) ? a : b; }
+TN_HD int maxI(int a, int b) { return (a < b) ? b : a; }
+TN_HD float clampT(float x, float lo, float hi) { return minT(maxT(x, lo), hi); }                    // maths.h:61-65
+TN_HD float lerpf(float a, float b, float t) { return a + (b - a)*t; }                               // maths.h:76-80
+TN_HD V3 lerp3(V3 a, V3 b, float t) { return a + (b - a)*t; }
+TN_HD float sqr(float x) { return x*x; }
+
+// FaceForward (maths.h:1592-1598)
+TN_HD V3 face_forward(V3 n, V3 v) { return (dot(v, n) < 0.0f) ? -n : n; }
+
+// ---------------------------------------------------------------------------
+// quaternions / transforms
+
+// operator*(Quat, Quat)  (maths.h:531-537)
+TN_HD Q4 qmul(Q4 a, Q4 b)
+{
+    Q4 r;
+    r.x = a.w*b.x + b.w*a.x + a.y*b.z - b.y*a.z;
+    r.y = a.w*b.y + b.w*a.y + a.z*b.x - b.z*a.x;
+    r.z = a.w*b.z + b.w*a.z + a.x*b.y - b.x*a.y;
+    r.w = a.w*b.w - a.x*b.x - a.y*b.y - a.z*b.z;
+    return r;
+}
+
+TN_HD Q4 qconj(Q4 q) { Q4 r = { -q.x, -q.y, -q.z, q.w }; return r; }                                 // maths.h:555
+
+// Rotate(q, v) = (q*Quat(v,0)*Conjugate(q)).xyz  (maths.h:558-563)
+TN_HD V3 qrotate(Q4 q, V3 v)
+{
+    Q4 qv = { v.x, v.y, v.z, 0.0f };
+    Q4 t = qmul(qmul(q, qv), qconj(q));
+    return V3(t.x, t.y, t.z);
+}
+
+// Normalize(Quat)  (maths.h:547-553)
+TN_HD Q4 qnormalize(Q4 q)
+{
+    float len = sqrtf(q.x*q.x + q.y*q.y + q.z*q.z + q.w*q.w);
+    float r = 1.0f/len;
+    Q4 o = { q.x*r, q.y*r, q.z*r, q.w*r };
+    return o;
+}
+
+// InterpolateTransform(Transform, Transform, t)  (maths.h:1566-1569)
+TN_HD Xform interpolate_xform(const Xform& a, const Xform& b, float t)
+{
+    Xform o;
+    o.p = lerp3(a.p, b.p, t);
+    Q4 q = { a.r.x + (b.r.x - a.r.x)*t, a.r.y + (b.r.y - a.r.y)*t, a.r.z + (b.r.z - a.r.z)*t, a.r.w + (b.r.w - a.r.w)*t };
+    o.r = qnormalize(q);
+    o.s = lerpf(a.s, b.s, t);
+    return o;
+}
+
+TN_HD V3 xform_vector(const Xform& t, V3 v) { return qrotate(t.r, t.s*v); }                          // maths.h:601-604
+TN_HD V3 xform_point(const Xform& t, V3 v) { return t.p + qrotate(t.r, t.s*v); }                     // maths.h:606-609
+TN_HD V3 inv_xform_vector(const Xform& t, V3 v) { return (1.0f/t.s)*qrotate(qconj(t.r), v); }        // maths.h:611-614
+TN_HD V3 inv_xform_point(const Xform& t, V3 v) { return (1.0f/t.s)*qrotate(qconj(t.r), v - t.p); }   // maths.h:616-619
+
+// ---------------------------------------------------------------------------
+// Random (maths.h:1036-1091): two-word xorshift/multiply generator
+
+struct Rng
+{
+    uint32_t s1, s2;
+
+    // Random(int seed), with the addition done in uint32 (no signed overflow)
+    TN_HD static Rng seeded(uint32_t seed)
+    {
+        Rng r;
+        r.s1 = 315645664u + seed;
+        r.s2 = r.s1 ^ 0x13ab45feu;
+        return r;
+    }
+
+    TN_HD uint32_t rand()
+    {
+        s1 = (s2 ^ ((s1 << 5) | (s1 >> 27))) ^ (s1*s2);
+        s2 = s1 ^ ((s2 << 12) | (s2 >> 20));
+        return s1;
+    }
+
+    // Randf(): (float)value * (1.0f/(float)0xffffffff)   -- the constant is exactly 2^-32
+    TN_HD float randf() { return (float)rand()*(1.0f/4294967296.0f); }
+};
+
+// passSeed[s] = (s+1)-th output of Random(1).Rand()  (render.cu:1050-1052, 1099)
+inline uint32_t pass_seed(uint32_t passIndex)
+{
+    Rng r = Rng::seeded(1u);
+    uint32_t v = 0;
+    for (uint32_t i = 0; i <= passIndex; ++i)
+        v = r.rand();
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// sampling helpers
+
+// BasisFromVector (maths.h:1261-1275)
+TN_HD void basis_from_vector(V3 w, V3& u, V3& v)
+{
+    if (fabsf(w.x) > fabsf(w.y))
+    {
+        float invLen = 1.0f/sqrtf(w.x*w.x + w.z*w.z);
+        u = V3(-w.z*invLen, 0.0f, w.x*invLen);
+    }
+    else
+    {
+        float invLen = 1.0f/sqrtf(w.y*w.y + w.z*w.z);
+        u = V3(0.0f, w.z*invLen, -w.y*invLen);
+    }
+    v = cross(w, u);
+}
+
+// UniformSampleSphere (maths.h:1278-1287)
+TN_D V3 uniform_sample_sphere(float u1, float u2)
+{
+    float z = 1.f - 2.f*u1;
+    float r = sqrtf(maxT(0.f, 1.f - z*z));
+    float phi = 2.f*kPi*u2;
+    float x = r*cosf(phi);
+    float y = r*sinf(phi);
+    return V3(x, y, z);
+}
+
+// UniformSampleHemisphere(Random&) (maths.h:1291-1302)
+TN_D V3 uniform_sample_hemisphere(Rng& rng)
+{
+    float z = rng.randf();
+    float w = sqrtf(1.0f - z*z);
+    float phi = k2Pi*rng.randf();
+    float x = cosf(phi)*w;
+    float y = sinf(phi)*w;
+    return V3(x, y, z);
+}
+
+// CosineSampleHemisphere (maths.h:1319-1325) via UniformSampleDisc (maths.h:1304-1310)
+TN_D V3 cosine_sample_hemisphere(float u1, float u2)
+{
+    float r = sqrtf(u1);
+    float theta = k2Pi*u2;
+    float sx = r*cosf(theta);
+    float sy = r*sinf(theta);
+    float z = sqrtf(maxT(0.0f, 1.0f - sx*sx - sy*sy));
+    return V3(sx, sy, z);
+}
+
+// UniformSampleTriangle (maths.h:1312-1317)
+TN_D void uniform_sample_triangle(Rng& rng, float& u, float& v)
+{
+    float r = sqrtf(rng.randf());
+    u = 1.0f - r;
+    v = rng.randf()*r;
+}
+
+// ClampLength (maths.h:1577-1589)
+TN_HD V3 clamp_length(V3 v, float maxLength)
+{
+    float l = length(v);
+    if (l > maxLength)
+        return v*(maxLength/l);
+    return v;
+}
+
+} // namespace tn

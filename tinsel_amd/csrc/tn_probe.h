@@ -1,0 +1,111 @@
+// tn_probe.h -- lat-long environment probe: eval / pdf / importance sampling
+// (reference src/probe.h:105-236) and Sky::Eval (src/scene.h:168-178).
+#pragma once
+
+#include "tn_scene.h"
+
+namespace tn {
+
+struct V2 { float x, y; };
+
+// ProbeDirToUV (probe.h:105-113)
+TN_D V2 probe_dir_to_uv(V3 dir)
+{
+    float theta = acosf(clampT(dir.y, -1.0f, 1.0f));
+    float phi = (dir.x == 0.0f && dir.z == 0.0f) ? 0.0f : atan2f(dir.z, dir.x);
+    float u = (kPi + phi)*kInvPi*0.5f;
+    float v = theta*kInvPi;
+    V2 r = { u, v };
+    return r;
+}
+
+// ProbeUVToDir (probe.h:115-125)
+TN_D V3 probe_uv_to_dir(V2 uv)
+{
+    float theta = uv.y*kPi;
+    float phi = uv.x*2.0f*kPi;
+    float x = -sinf(theta)*cosf(phi);
+    float y = cosf(theta);
+    float z = -sinf(theta)*sinf(phi);
+    return V3(x, y, z);
+}
+
+TN_D int clampI(int x, int lo, int hi) { return minI(maxI(x, lo), hi); }
+
+// ProbeEval (probe.h:128-134)
+TN_D V3 probe_eval(const DevProbe& p, V2 uv)
+{
+    int px = clampI(int(uv.x*p.width), 0, p.width - 1);
+    int py = clampI(int(uv.y*p.height), 0, p.height - 1);
+    float4 c = p.data[py*p.width + px];
+    return V3(c.x, c.y, c.z);
+}
+
+// ProbePdf (probe.h:136-160)
+TN_D float probe_pdf(const DevProbe& p, V3 d)
+{
+    V2 uv = probe_dir_to_uv(d);
+    int col = clampI(int(uv.x*p.width), 0, p.width - 1);
+    int row = clampI(int(uv.y*p.height), 0, p.height - 1);
+
+    float pdf = p.pdfX[row*p.width + col]*p.pdfY[row];
+
+    float sinTheta = sinf(uv.y*kPi);
+    if (fabsf(sinTheta) < 0.0001f)
+        pdf = 0.0f;
+    else
+        pdf *= float(p.width)*float(p.height)/(2.0f*kPi*kPi*sinTheta);
+    return pdf;
+}
+
+// LowerBound(array, lower, upper, value) (probe.h:185-203)
+TN_D int lower_bound(const float* array, int lower, int upper, float value)
+{
+    while (lower < upper)
+    {
+        int mid = lower + (upper - lower)/2;
+        if (array[mid] < value)
+            lower = mid + 1;
+        else
+            upper = mid;
+    }
+    return lower;
+}
+
+// ProbeSample (probe.h:205-236)
+TN_D void probe_sample(const DevProbe& p, V3& dir, V3& color, float& pdf, Rng& rng)
+{
+    float r1 = rng.randf();
+    float r2 = rng.randf();
+
+    int row = lower_bound(p.cdfY, 0, p.height, r1);
+    int col = lower_bound(p.cdfX, row*p.width, (row + 1)*p.width, r2) - row*p.width;
+
+    float4 c = p.data[row*p.width + col];
+    color = V3(c.x, c.y, c.z);
+    pdf = p.pdfX[row*p.width + col]*p.pdfY[row];
+
+    float u = col/float(p.width);
+    float v = row/float(p.height);
+
+    float sinTheta = sinf(v*kPi);
+    if (sinTheta == 0.0f)
+        pdf = 0.0f;
+    else
+        pdf *= (p.width*p.height)/(2.0f*kPi*kPi*sinTheta);
+
+    V2 uv = { u, v };
+    dir = probe_uv_to_dir(uv);
+}
+
+// Sky::Eval (scene.h:168-178)
+TN_D V3 sky_eval(const DevScene& sc, V3 dir)
+{
+    if (sc.probe.valid)
+        return probe_eval(sc.probe, probe_dir_to_uv(dir));
+    V3 h(sc.horizon[0], sc.horizon[1], sc.horizon[2]);
+    V3 z(sc.zenith[0], sc.zenith[1], sc.zenith[2]);
+    return lerp3(h, z, sqrtf(absf(dir.y)));
+}
+
+} // namespace tn

@@ -1,0 +1,134 @@
+// tn_scene.h -- the scene as it lives in HBM (and, when it fits, in LDS).
+//
+// The reference keeps 32-B BVHNode records (bvh.h:9-20) and fetches THREE of them per
+// internal visit (the node, then both children: intersection.h:766-776), 272-B Primitives
+// (scene.h:138-159) and index+vertex gathers per triangle test (intersection.h:638-644).
+// Here the same trees, boxes and visit order are re-laid for 64-B / 128-B aligned loads:
+//
+//   Node64   one record per INTERNAL node holding BOTH children's boxes and child refs:
+//            one 64-B load (4 x dwordx4) per internal visit; node pairs are 128-B aligned.
+//            A child ref is (leaf<<31 | index): leaves carry their item id in the ref,
+//            so leaf nodes are never fetched at all.
+//   Tri48    the three vertex positions pre-gathered per triangle (+ the three vertex
+//            indices in the .w lanes for the normal fetch after the closest hit).
+//   Prim64   what PrimitiveIntersect needs (pose, geometry, kind): 64 B.
+//   Mat128   what shading needs, with every material-only sub-expression of
+//            disney.h / scene.h pre-evaluated on the host in the reference's own
+//            precision (see host_scene.cpp), 128 B.
+#pragma once
+
+#include "tn_math.h"
+
+namespace tn {
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kNoNode = 0xffffffffu;
+
+struct alignas(64) Node64
+{
+    // children L and R of one internal node; boxes exactly as in the reference nodes
+    float lminx, lminy, lminz, lmaxx;
+    float lmaxy, lmaxz, rminx, rminy;
+    float rminz, rmaxx, rmaxy, rmaxz;
+    uint32_t left, right;       // child refs
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(Node64) == 64, "Node64");
+
+struct alignas(16) Tri48
+{
+    float ax, ay, az; int32_t i0;
+    float bx, by, bz; int32_t i1;
+    float cx, cy, cz; int32_t i2;
+};
+static_assert(sizeof(Tri48) == 48, "Tri48");
+
+enum : uint32_t
+{
+    kPrimSphere = 0,
+    kPrimPlane = 1,
+    kPrimMesh = 2,
+};
+
+enum : uint32_t
+{
+    kPrimMoving = 1u,           // startTransform != endTransform: interpolate per ray
+};
+
+struct alignas(64) Prim64
+{
+    // pose at ray time for static primitives == InterpolateTransform(start, end, t) for any t
+    float px, py, pz, s;
+    float rx, ry, rz, rw;
+    float g0, g1, g2, g3;       // sphere: radius,-,-,- ; plane: the four coefficients
+    uint32_t type;
+    uint32_t flags;
+    uint32_t mesh;              // index into DevScene::meshes (kPrimMesh)
+    uint32_t moving;            // index into DevScene::moving (kPrimMoving)
+};
+static_assert(sizeof(Prim64) == 64, "Prim64");
+
+struct alignas(64) Moving64
+{
+    float spx, spy, spz, ss; float srx, sry, srz, srw;      // startTransform
+    float epx, epy, epz, es; float erx, ery, erz, erw;      // endTransform
+};
+static_assert(sizeof(Moving64) == 64, "Moving64");
+
+struct alignas(128) Mat128
+{
+    float emission[3]; float ior;           // Material::GetIndexOfRefraction() (scene.h:72-78)
+    float color[3];    float metallic;
+    float absorption[3]; float subsurface;
+    float cspec0[3];   float roughness;     // Cspec0 of BSDFEval (disney.h:306-310)
+    float sqrtColor[3]; float transmission; // sqrtf(color) of the sub-surface lobe (disney.h:352)
+    float clearcoat;
+    float clearcoatAlpha;                   // Lerp(.1,.001,clearcoatGloss) (disney.h:387)
+    float area;                             // PrimitiveArea (intersection.h:833-853)
+    int32_t lightSamples;
+    float pad[8];
+};
+static_assert(sizeof(Mat128) == 128, "Mat128");
+
+struct DevMesh
+{
+    const Node64* nodes;
+    const Tri48* tris;
+    const float* normals;       // 3 floats per vertex
+    const float* cdf;           // per-triangle area CDF (mesh.cpp:340-368)
+    uint32_t root;              // child ref of the root (leaf ref when the mesh has one triangle)
+    int32_t numTris;
+    int32_t stackNeed;          // worst-case traversal stack entries for this tree
+    int32_t pad;
+};
+
+struct DevProbe
+{
+    const float4* data;
+    const float* pdfX;
+    const float* cdfX;
+    const float* pdfY;
+    const float* cdfY;
+    int32_t width, height;
+    int32_t valid;
+    int32_t pad;
+};
+
+struct DevScene
+{
+    const Node64* nodes;        // scene-level BVH
+    const Prim64* prims;
+    const Mat128* mats;         // one per primitive, same index
+    const Moving64* moving;
+    const DevMesh* meshes;
+    const int32_t* lights;      // primitive indices with lightSamples > 0, in primitive order
+    uint32_t root;
+    int32_t numPrims;
+    int32_t numLights;
+    int32_t totalLightSamples;  // sum of lightSamples over lights (+1 when a probe is valid = NEE rays per bounce)
+    float horizon[3];
+    float zenith[3];
+    DevProbe probe;
+};
+
+} // namespace tn

@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's renderer interface over the C-ABI.
+
+Reference interface (src/render.h:66-79):
+
+    struct Renderer { virtual void Init(int w, int h); virtual void Render(const Camera&, const Options&, Color* out); };
+    Renderer* CreateGpuRenderer(const Scene* s);
+
+Here: `create_gpu_renderer(scene) -> HipRenderer` with `.init(w, h)` and
+`.render(camera, options, output=None, passes=1)`; same argument meaning, same
+framebuffer semantics (output == running sum of (rgb*w, w) since init), same
+"Init before Render, options.width/height must match Init" contract.  Errors
+raise `TinselHipError` carrying tinsel_hip_last_error().
+
+The compute lives entirely in libtinsel_hip.so (hand-written HIP for gfx950).
+There is no CPU fallback: without the library or without a GPU these calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtinsel_hip.so")
+
+_lib = None
+
+
+class TinselHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libtinsel_hip.so (once).  torch, when importable, is imported first so that both
+    share one HIP runtime (same SONAME libamdhip64.so.7) and torch device pointers are valid here."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TinselHipError(
+            "%s is missing: build it with `python -m tinsel_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing, not a requirement of the ABI
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.tinsel_hip_create.restype = vp
+    L.tinsel_hip_create.argtypes = [C.POINTER(abi.SceneDesc), ci]
+    L.tinsel_hip_destroy.restype = None
+    L.tinsel_hip_destroy.argtypes = [vp]
+    L.tinsel_hip_init.argtypes = [vp, ci, ci]
+    L.tinsel_hip_init_external.argtypes = [vp, ci, ci, vp]
+    L.tinsel_hip_render.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.Options), vp, ci]
+    L.tinsel_hip_render_async.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.Options), ci, vp]
+    L.tinsel_hip_accum_device_ptr.restype = vp
+    L.tinsel_hip_accum_device_ptr.argtypes = [vp]
+    L.tinsel_hip_read_accum.argtypes = [vp, vp]
+    L.tinsel_hip_set_shard.argtypes = [vp, ci, ci, ci]
+    L.tinsel_hip_set_pipeline.argtypes = [vp, ci]
+    L.tinsel_hip_set_pass_index.argtypes = [vp, C.c_uint32]
+    L.tinsel_hip_get_pass_index.restype = C.c_uint32
+    L.tinsel_hip_get_pass_index.argtypes = [vp]
+    L.tinsel_hip_stats.restype = None
+    L.tinsel_hip_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_double)]
+    L.tinsel_hip_reset_stats.restype = None
+    L.tinsel_hip_reset_stats.argtypes = [vp]
+    L.tinsel_hip_stats_detail.argtypes = [vp, vp]
+    L.tinsel_hip_set_detail_counters.argtypes = [vp, ci]
+    L.tinsel_hip_kernel_times.argtypes = [vp, C.POINTER(abi.KernelTime), ci]
+    L.tinsel_hip_enable_kernel_timing.argtypes = [vp, ci]
+    L.tinsel_hip_set_batch_paths.argtypes = [vp, C.c_ulonglong]
+    L.tinsel_hip_stack_entries.argtypes = [vp]
+    L.tinsel_hip_nee_per_path.argtypes = [vp]
+    L.tinsel_hip_last_error.restype = C.c_char_p
+    L.tinsel_pack_open.argtypes = [vp, C.c_size_t, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.Options)]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "tinsel_hip_create", "tinsel_hip_destroy", "tinsel_hip_init", "tinsel_hip_init_external", "tinsel_hip_render",
+    "tinsel_hip_render_async", "tinsel_hip_accum_device_ptr", "tinsel_hip_read_accum", "tinsel_hip_set_shard",
+    "tinsel_hip_set_pipeline", "tinsel_hip_set_pass_index", "tinsel_hip_get_pass_index", "tinsel_hip_stats",
+    "tinsel_hip_reset_stats", "tinsel_hip_stats_detail", "tinsel_hip_set_detail_counters", "tinsel_hip_kernel_times",
+    "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
+    "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open",
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().tinsel_hip_last_error()
+        raise TinselHipError("%s failed: %s" % (what, msg.decode() if msg else "?"))
+
+
+class Scene:
+    """A scene as the C-ABI sees it: a `SceneDesc` plus the camera/options the scene file carried.
+
+    Scenes come from scene packs (DESIGN.md "Scene pack"): one relocatable blob written by the
+    reference's own loader + Scene::Build (tests/golden/make_golden.py).
+    """
+
+    def __init__(self, blob: bytes):
+        L = load_library()
+        self._buf = C.create_string_buffer(blob, len(blob))     # owned, writable: pack_open relocates in place
+        self.desc = abi.SceneDesc()
+        self.camera = abi.Camera()
+        self.options = abi.Options()
+        _check(L.tinsel_pack_open(self._buf, len(blob), C.byref(self.desc), C.byref(self.camera), C.byref(self.options)),
+               "tinsel_pack_open")
+
+    @classmethod
+    def load_pack(cls, path):
+        with open(path, "rb") as fh:
+            return cls(fh.read())
+
+    @property
+    def num_primitives(self):
+        return self.desc.num_primitives
+
+
+class HipRenderer:
+    """`Renderer` (render.h:66-73) implemented by the gfx950 streaming path tracer."""
+
+    def __init__(self, scene: Scene, device: int = 0):
+        L = load_library()
+        self._L = L
+        self._h = L.tinsel_hip_create(C.byref(scene.desc), device)
+        if not self._h:
+            msg = L.tinsel_hip_last_error()
+            raise TinselHipError("tinsel_hip_create failed: %s" % (msg.decode() if msg else "?"))
+        self.device = device
+        self.width = self.height = 0
+        self._accum_tensor = None
+
+    # -- Renderer interface ------------------------------------------------
+    def init(self, width, height, accum_tensor=None):
+        """Renderer::Init: (re)allocate + zero the accumulator.  `accum_tensor`: optional torch
+        float32 device tensor [H,W,4] to use as the accumulator (for an RCCL reduce)."""
+        if accum_tensor is not None:
+            assert tuple(accum_tensor.shape) == (height, width, 4) and accum_tensor.is_contiguous()
+            self._accum_tensor = accum_tensor
+            _check(self._L.tinsel_hip_init_external(self._h, width, height, accum_tensor.data_ptr()), "tinsel_hip_init_external")
+        else:
+            self._accum_tensor = None
+            _check(self._L.tinsel_hip_init(self._h, width, height), "tinsel_hip_init")
+        self.width, self.height = width, height
+
+    def render(self, camera, options, output=None, passes=1, readback=True):
+        """Renderer::Render: add `passes` samples per pixel; returns the running sum [H,W,4] (rgb*w, w)."""
+        if output is None and readback:
+            output = np.empty((options.height, options.width, 4), np.float32)
+        ptr = output.ctypes.data_as(C.c_void_p) if (readback and output is not None) else None
+        _check(self._L.tinsel_hip_render(self._h, C.byref(camera), C.byref(options), ptr, passes), "tinsel_hip_render")
+        return output
+
+    Init = init
+    Render = render
+
+    # -- beyond the reference interface -------------------------------------
+    def render_async(self, camera, options, passes=1, stream=None):
+        _check(self._L.tinsel_hip_render_async(self._h, C.byref(camera), C.byref(options), passes, stream), "tinsel_hip_render_async")
+
+    def read_accum(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        _check(self._L.tinsel_hip_read_accum(self._h, out.ctypes.data_as(C.c_void_p)), "tinsel_hip_read_accum")
+        return out
+
+    @property
+    def accum_tensor(self):
+        return self._accum_tensor
+
+    def accum_device_ptr(self):
+        return self._L.tinsel_hip_accum_device_ptr(self._h)
+
+    def set_shard(self, rank, world, tile=32):
+        _check(self._L.tinsel_hip_set_shard(self._h, rank, world, tile), "tinsel_hip_set_shard")
+
+    def set_pipeline(self, pipeline):
+        _check(self._L.tinsel_hip_set_pipeline(self._h, pipeline), "tinsel_hip_set_pipeline")
+
+    def set_pass_index(self, i):
+        _check(self._L.tinsel_hip_set_pass_index(self._h, i), "tinsel_hip_set_pass_index")
+
+    def set_batch_paths(self, n):
+        _check(self._L.tinsel_hip_set_batch_paths(self._h, n), "tinsel_hip_set_batch_paths")
+
+    def set_detail_counters(self, on):
+        _check(self._L.tinsel_hip_set_detail_counters(self._h, int(on)), "tinsel_hip_set_detail_counters")
+
+    def enable_kernel_timing(self, on):
+        _check(self._L.tinsel_hip_enable_kernel_timing(self._h, int(on)), "tinsel_hip_enable_kernel_timing")
+
+    def kernel_times(self):
+        arr = (abi.KernelTime * 16)()
+        n = self._L.tinsel_hip_kernel_times(self._h, arr, 16)
+        if n < 0:
+            _check(n, "tinsel_hip_kernel_times")
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n)}
+
+    def stats(self):
+        names = ["rays", "samples", "internal_visits", "tri_tests", "prim_tests", "shadow_rays", "_6", "_7"]
+        out = np.zeros(8, np.uint64)
+        _check(self._L.tinsel_hip_stats_detail(self._h, out.ctypes.data_as(C.c_void_p)), "tinsel_hip_stats_detail")
+        return dict(zip(names, (int(v) for v in out)))
+
+    def reset_stats(self):
+        self._L.tinsel_hip_reset_stats(self._h)
+
+    @property
+    def stack_entries(self):
+        return self._L.tinsel_hip_stack_entries(self._h)
+
+    @property
+    def nee_per_path(self):
+        return self._L.tinsel_hip_nee_per_path(self._h)
+
+    def close(self):
+        if self._h:
+            self._L.tinsel_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_gpu_renderer(scene: Scene, device: int = 0) -> HipRenderer:
+    """`Renderer* CreateGpuRenderer(const Scene*)` (render.h:79)."""
+    return HipRenderer(scene, device)
+
+
+def resolve(accum):
+    """Consumer-side normalisation of main.cpp:262-268: rgb / w (0 where w == 0)."""
+    w = accum[..., 3:4]
+    return np.where(w > 0, accum[..., :3] / np.where(w > 0, w, 1.0), 0.0)
