@@ -244,6 +244,10 @@ int tinsel_hip_set_detail_counters(tinsel_hip* r, int enable);
 /* Upper bound on path slots resident per batch (default 4 Mi, or env TINSEL_HIP_BATCH_PATHS). */
 int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths);
 
+/* Per-path radiance of the most recent batch (test hook): copies min(max_paths, paths in batch)
+ * float4 records {r,g,b,-} in slot order (slot = pass_in_batch*W*H + j*W + i) and returns the count. */
+long long tinsel_hip_read_batch_radiance(tinsel_hip* r, float* out_rgbx, unsigned long long max_paths);
+
 /* Introspection: LDS traversal-stack entries per lane chosen for this scene, NEE rays per bounce. */
 int tinsel_hip_stack_entries(tinsel_hip* r);
 int tinsel_hip_nee_per_path(tinsel_hip* r);

@@ -247,6 +247,7 @@ struct tinsel_hip
     size_t passSeedsCap = 0;
     unsigned long long* statsDev = nullptr;
 
+    size_t lastBatchSlots = 0;
     size_t maxBatchSlots = 4u << 20;
     int pipeline = TINSEL_PIPELINE_WAVEFRONT;
     bool countDetail = false;
@@ -449,6 +450,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     const int gridFlat = (int)((slots + kBlock - 1)/kBlock);
     const int gridPersist = (int)std::min<size_t>((size_t)gridFlat, (size_t)r->numCUs*8);
     HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
+    r->lastBatchSlots = slots;
 
     if (r->pipeline == TINSEL_PIPELINE_MEGAKERNEL)
     {
@@ -1048,6 +1050,18 @@ int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths)
         return fail("set_batch_paths: bad arguments");
     r->maxBatchSlots = (size_t)max_paths;
     return 0;
+}
+
+long long tinsel_hip_read_batch_radiance(tinsel_hip* r, float* out_rgbx, unsigned long long max_paths)
+{
+    if (!r || !out_rgbx)
+        return fail("read_batch_radiance: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = std::min<size_t>((size_t)max_paths, r->lastBatchSlots);
+    if (n)
+        HIP_TRY(hipMemcpy(out_rgbx, r->ps.rad, sizeof(float4)*n, hipMemcpyDeviceToHost));
+    return (long long)n;
 }
 
 int tinsel_hip_stack_entries(tinsel_hip* r) { return r ? r->stackNeed : 0; }

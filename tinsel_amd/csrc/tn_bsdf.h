@@ -56,7 +56,7 @@ TN_D float gtr1(float NDotH, float a)      // disney.h:56-62
     if (a >= 1) return kInvPi;
     float a2 = a*a;
     float t = 1 + (a2 - 1)*NDotH*NDotH;
-    return (a2 - 1)/(kPi*logf(a2)*t);
+    return (a2 - 1)/(kPi*m_logf(a2)*t);
 }
 
 TN_D float gtr2(float NDotH, float a)      // disney.h:64-69
@@ -116,8 +116,8 @@ TN_D V3 sample_ggx_reflection(const Mat& mat, V3 U, V3 Vt, V3 N, V3 view, float 
     const float phiHalf = r1*k2Pi;
     const float cosThetaHalf = sqrtf((1.0f - r2)/(1.0f + (sqr(a) - 1.0f)*r2));
     const float sinThetaHalf = sqrtf(maxT(0.0f, 1.0f - sqr(cosThetaHalf)));
-    const float sinPhiHalf = sinf(phiHalf);
-    const float cosPhiHalf = cosf(phiHalf);
+    const float sinPhiHalf = m_sinf(phiHalf);
+    const float cosPhiHalf = m_cosf(phiHalf);
 
     V3 half = U*(sinThetaHalf*cosPhiHalf) + Vt*(sinThetaHalf*sinPhiHalf) + N*cosThetaHalf;
     if (dot(half, view) <= 0.0f)

@@ -73,7 +73,7 @@ TN_D void on_hit_begin(PathRegs& p, const Mat& mat, float t, V3 n, int bounce, H
 
     // pathThroughput *= Exp(-rayAbsorption*t)   (render.cpp:272, maths.h:253)
     V3 a = (-p.absorption)*t;
-    p.thr = p.thr*V3(expf(a.x), expf(a.y), expf(a.z));
+    p.thr = p.thr*V3(m_expf(a.x), m_expf(a.y), m_expf(a.z));
 
     h.p = p.o + p.d*t;
     h.n = n;

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kBlock) void k_mega(DevScene sc, PathState ps, Queu
 
 TN_D float filter_gauss(float x, float falloff, float offset)      // Filter::Gaussian (render.h:29-32)
 {
-    return maxT(0.0f, float(expf(-falloff*x*x)) - offset);
+    return maxT(0.0f, float(m_expf(-falloff*x*x)) - offset);
 }
 
 __global__ __launch_bounds__(kBlock) void k_accumulate(PathState ps, FrameParams fp, float4* __restrict__ accum)

@@ -78,6 +78,30 @@ TN_HD float sqr(float x) { return x*x; }
 TN_HD V3 face_forward(V3 n, V3 v) { return (dot(v, n) < 0.0f) ? -n : n; }
 
 // ---------------------------------------------------------------------------
+// transcendental functions.  The CPU oracle calls glibc's sinf/cosf/expf/logf/acosf/atan2f,
+// which evaluate in double and are correctly rounded in all but a fraction of a percent of
+// cases.  TN_LIBM_DOUBLE (default) does the same on the device: the ocml double routine,
+// rounded once to fp32.  With TN_LIBM_DOUBLE=0 the 1-2 ulp ocml fp32 routines are used.
+#ifndef TN_LIBM_DOUBLE
+#define TN_LIBM_DOUBLE 1
+#endif
+#if TN_LIBM_DOUBLE
+TN_D float m_sinf(float x) { return (float)::sin((double)x); }
+TN_D float m_cosf(float x) { return (float)::cos((double)x); }
+TN_D float m_expf(float x) { return (float)::exp((double)x); }
+TN_D float m_logf(float x) { return (float)::log((double)x); }
+TN_D float m_acosf(float x) { return (float)::acos((double)x); }
+TN_D float m_atan2f(float y, float x) { return (float)::atan2((double)y, (double)x); }
+#else
+TN_D float m_sinf(float x) { return ::sinf(x); }
+TN_D float m_cosf(float x) { return ::cosf(x); }
+TN_D float m_expf(float x) { return ::expf(x); }
+TN_D float m_logf(float x) { return ::logf(x); }
+TN_D float m_acosf(float x) { return ::acosf(x); }
+TN_D float m_atan2f(float y, float x) { return ::atan2f(y, x); }
+#endif
+
+// ---------------------------------------------------------------------------
 // quaternions / transforms
 
 // operator*(Quat, Quat)  (maths.h:531-537)
@@ -188,8 +212,8 @@ TN_D V3 uniform_sample_sphere(float u1, float u2)
     float z = 1.f - 2.f*u1;
     float r = sqrtf(maxT(0.f, 1.f - z*z));
     float phi = 2.f*kPi*u2;
-    float x = r*cosf(phi);
-    float y = r*sinf(phi);
+    float x = r*m_cosf(phi);
+    float y = r*m_sinf(phi);
     return V3(x, y, z);
 }
 
@@ -199,8 +223,8 @@ TN_D V3 uniform_sample_hemisphere(Rng& rng)
     float z = rng.randf();
     float w = sqrtf(1.0f - z*z);
     float phi = k2Pi*rng.randf();
-    float x = cosf(phi)*w;
-    float y = sinf(phi)*w;
+    float x = m_cosf(phi)*w;
+    float y = m_sinf(phi)*w;
     return V3(x, y, z);
 }
 
@@ -209,8 +233,8 @@ TN_D V3 cosine_sample_hemisphere(float u1, float u2)
 {
     float r = sqrtf(u1);
     float theta = k2Pi*u2;
-    float sx = r*cosf(theta);
-    float sy = r*sinf(theta);
+    float sx = r*m_cosf(theta);
+    float sy = r*m_sinf(theta);
     float z = sqrtf(maxT(0.0f, 1.0f - sx*sx - sy*sy));
     return V3(sx, sy, z);
 }

@@ -11,8 +11,8 @@ struct V2 { float x, y; };
 // ProbeDirToUV (probe.h:105-113)
 TN_D V2 probe_dir_to_uv(V3 dir)
 {
-    float theta = acosf(clampT(dir.y, -1.0f, 1.0f));
-    float phi = (dir.x == 0.0f && dir.z == 0.0f) ? 0.0f : atan2f(dir.z, dir.x);
+    float theta = m_acosf(clampT(dir.y, -1.0f, 1.0f));
+    float phi = (dir.x == 0.0f && dir.z == 0.0f) ? 0.0f : m_atan2f(dir.z, dir.x);
     float u = (kPi + phi)*kInvPi*0.5f;
     float v = theta*kInvPi;
     V2 r = { u, v };
@@ -24,9 +24,9 @@ TN_D V3 probe_uv_to_dir(V2 uv)
 {
     float theta = uv.y*kPi;
     float phi = uv.x*2.0f*kPi;
-    float x = -sinf(theta)*cosf(phi);
-    float y = cosf(theta);
-    float z = -sinf(theta)*sinf(phi);
+    float x = -m_sinf(theta)*m_cosf(phi);
+    float y = m_cosf(theta);
+    float z = -m_sinf(theta)*m_sinf(phi);
     return V3(x, y, z);
 }
 
@@ -50,7 +50,7 @@ TN_D float probe_pdf(const DevProbe& p, V3 d)
 
     float pdf = p.pdfX[row*p.width + col]*p.pdfY[row];
 
-    float sinTheta = sinf(uv.y*kPi);
+    float sinTheta = m_sinf(uv.y*kPi);
     if (fabsf(sinTheta) < 0.0001f)
         pdf = 0.0f;
     else
@@ -88,7 +88,7 @@ TN_D void probe_sample(const DevProbe& p, V3& dir, V3& color, float& pdf, Rng& r
     float u = col/float(p.width);
     float v = row/float(p.height);
 
-    float sinTheta = sinf(v*kPi);
+    float sinTheta = m_sinf(v*kPi);
     if (sinTheta == 0.0f)
         pdf = 0.0f;
     else

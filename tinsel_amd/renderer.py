@@ -72,6 +72,8 @@ def load_library():
     L.tinsel_hip_kernel_times.argtypes = [vp, C.POINTER(abi.KernelTime), ci]
     L.tinsel_hip_enable_kernel_timing.argtypes = [vp, ci]
     L.tinsel_hip_set_batch_paths.argtypes = [vp, C.c_ulonglong]
+    L.tinsel_hip_read_batch_radiance.restype = C.c_longlong
+    L.tinsel_hip_read_batch_radiance.argtypes = [vp, vp, C.c_ulonglong]
     L.tinsel_hip_stack_entries.argtypes = [vp]
     L.tinsel_hip_nee_per_path.argtypes = [vp]
     L.tinsel_hip_last_error.restype = C.c_char_p
@@ -86,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_set_pipeline", "tinsel_hip_set_pass_index", "tinsel_hip_get_pass_index", "tinsel_hip_stats",
     "tinsel_hip_reset_stats", "tinsel_hip_stats_detail", "tinsel_hip_set_detail_counters", "tinsel_hip_kernel_times",
     "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
-    "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open",
+    "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance",
 ]
 
 
@@ -206,6 +208,15 @@ class HipRenderer:
         out = np.zeros(8, np.uint64)
         _check(self._L.tinsel_hip_stats_detail(self._h, out.ctypes.data_as(C.c_void_p)), "tinsel_hip_stats_detail")
         return dict(zip(names, (int(v) for v in out)))
+
+    def batch_radiance(self, passes, height, width):
+        """Per-path radiance [passes,H,W,3] of the most recent batch (test hook)."""
+        n = passes*height*width
+        out = np.empty((n, 4), np.float32)
+        got = self._L.tinsel_hip_read_batch_radiance(self._h, out.ctypes.data_as(C.c_void_p), n)
+        if got != n:
+            raise TinselHipError("batch holds %d paths, wanted %d" % (got, n))
+        return out[:, :3].reshape(passes, height, width, 3).copy()
 
     def reset_stats(self):
         self._L.tinsel_hip_reset_stats(self._h)
