@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--maxdepth", type=int, default=0, help="0 = the scene's own / BASELINE value")
-    ap.add_argument("--pipeline", choices=["wavefront", "mega"], default="wavefront")
+    ap.add_argument("--pipeline", choices=["wavefront", "mega", "split"], default="wavefront")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-core-seconds of oracle work")
     ap.add_argument("--tile", type=int, default=32)
@@ -108,7 +108,7 @@ def main():
     opt.mode = abi.MODE_PATHTRACE
 
     r = tinsel_amd.create_gpu_renderer(scene, local)
-    r.set_pipeline(abi.PIPELINE_WAVEFRONT if args.pipeline == "wavefront" else abi.PIPELINE_MEGAKERNEL)
+    r.set_pipeline({"wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
     if world > 1:
         r.set_shard(rank, world, args.tile)
         r.set_batch_paths((4 << 20)*world)       # keep the same number of LIVE paths per batch as N = 1
@@ -190,7 +190,7 @@ def main():
     # ---- roofline of the dominant kernel ------------------------------------------------------------
     dom = max(ktimes.items(), key=lambda kv: kv[1][1]) if ktimes else (None, (0, 0.0))
     dom_name, (dom_launches, dom_ms) = dom
-    rays_by_kernel = {"k_extend": st["rays"] - st["shadow_rays"], "k_shadow": st["shadow_rays"], "k_mega": st["rays"]}
+    rays_by_kernel = {"k_extend": st["rays"] - st["shadow_rays"], "k_shadow": st["shadow_rays"], "k_mega": st["rays"], "k_bounce": st["rays"]}
     if dom_name in rays_by_kernel:
         dom_bytes = rays_by_kernel[dom_name]*B_ray
     elif dom_name == "k_accumulate":

@@ -160,9 +160,11 @@ typedef struct tinsel_scene_desc {
 
 typedef struct tinsel_hip tinsel_hip;       /* opaque */
 
-/* Pipeline selection (tinsel_hip_set_pipeline).  WAVEFRONT is the product path;
- * MEGAKERNEL is kept as an A/B arm with identical per-path arithmetic. */
-enum { TINSEL_PIPELINE_WAVEFRONT = 0, TINSEL_PIPELINE_MEGAKERNEL = 1 };
+/* Pipeline selection (tinsel_hip_set_pipeline).  WAVEFRONT is the product path: one streaming
+ * kernel per bounce over HBM ray queues with wave64 compaction.  MEGAKERNEL (one lane per whole
+ * path) and WAVEFRONT_SPLIT (extend / shade / shadow kernels per bounce) are A/B arms with
+ * identical per-path arithmetic. */
+enum { TINSEL_PIPELINE_WAVEFRONT = 0, TINSEL_PIPELINE_MEGAKERNEL = 1, TINSEL_PIPELINE_WAVEFRONT_SPLIT = 2 };
 
 /* Replaces GpuRenderer::GpuRenderer (render.cu:989-1053): deep-copies the scene
  * to device `device_index` (dedupes meshes by MeshGeometry::id, re-lays BVHs out

@@ -54,7 +54,8 @@ def _render(scene, cam, opt, passes, pipeline, batch=None, want_radiance=False):
 L2_FIXTURES = [s for s in SCENES if not s.startswith("features")]
 
 
-@pytest.mark.parametrize("pipeline", [abi.PIPELINE_WAVEFRONT, abi.PIPELINE_MEGAKERNEL], ids=["wavefront", "mega"])
+@pytest.mark.parametrize("pipeline", [abi.PIPELINE_WAVEFRONT, abi.PIPELINE_MEGAKERNEL, abi.PIPELINE_WAVEFRONT_SPLIT],
+                         ids=["wavefront", "mega", "split"])
 @pytest.mark.parametrize("name", SCENES)
 def test_accum_matches_golden(name, pipeline):
     scene, cam, opt, g = _load(name)
@@ -91,12 +92,15 @@ def test_normals_mode(name):
     assert bad.mean() <= 2e-3, "%d of %d pixels differ" % (bad.sum(), bad.size)
 
 
-def test_wavefront_equals_megakernel_bitwise():
-    """Both arms run the same arithmetic per path; the gather accumulate is order-deterministic."""
-    scene, cam, opt, g = _load("features")
+@pytest.mark.parametrize("name", ["features", "features_probe", "glass"])
+def test_pipelines_agree_bitwise(name):
+    """All arms run the same arithmetic per path; the gather accumulate is order-deterministic."""
+    scene, cam, opt, g = _load(name)
     a, _ = _render(scene, cam, opt, 2, abi.PIPELINE_WAVEFRONT)
     b, _ = _render(scene, cam, opt, 2, abi.PIPELINE_MEGAKERNEL)
+    c, _ = _render(scene, cam, opt, 2, abi.PIPELINE_WAVEFRONT_SPLIT)
     assert np.array_equal(a, b)
+    assert np.array_equal(a, c)
 
 
 def test_batching_is_invisible():

@@ -211,8 +211,8 @@ struct DeviceArena
     }
 };
 
-const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals" };
-enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_COUNT };
+const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals", "k_bounce" };
+enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_COUNT };
 
 struct TimedSpan { int kernel; hipEvent_t start, stop; };
 
@@ -412,7 +412,7 @@ int pick_stack(int need)
     return -1;
 }
 
-size_t stack_bytes(const tinsel_hip* r) { return (size_t)r->stackNeed*kBlock*sizeof(uint32_t); }
+size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + kScanWords)*sizeof(uint32_t); }
 
 void launch_extend(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
 {
@@ -438,6 +438,25 @@ void launch_mega(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& ca
         hipLaunchKernelGGL((k_mega<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev);
 }
 
+void launch_bounce(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, const CameraParams& cam, const FrameParams& fp)
+{
+    const size_t lds = stack_bytes(r);
+    if (bounce == 0)
+    {
+        if (r->countDetail)
+            hipLaunchKernelGGL((k_bounce<true, true>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
+        else
+            hipLaunchKernelGGL((k_bounce<false, true>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
+    }
+    else
+    {
+        if (r->countDetail)
+            hipLaunchKernelGGL((k_bounce<true, false>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
+        else
+            hipLaunchKernelGGL((k_bounce<false, false>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
+    }
+}
+
 void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
 {
     hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum);
@@ -457,11 +476,19 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         ScopedTimer t(r, KN_MEGA, st);
         launch_mega(r, st, gridFlat, cam, fp);
     }
+    else if (r->pipeline == TINSEL_PIPELINE_WAVEFRONT)
+    {
+        for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
+        {
+            ScopedTimer t(r, KN_BOUNCE, st);
+            launch_bounce(r, st, gridPersist, r->queues[bounce & 1], r->queues[(bounce + 1) & 1], bounce, cam, fp);
+        }
+    }
     else
     {
         {
             ScopedTimer t(r, KN_GENERATE, st);
-            hipLaunchKernelGGL(k_generate, dim3(gridFlat), dim3(kBlock), 0, st, r->ps, r->ctl, r->queues[0], cam, fp, r->passSeedsDev);
+            hipLaunchKernelGGL(k_generate, dim3(gridPersist), dim3(kBlock), 0, st, r->ps, r->ctl, r->queues[0], cam, fp, r->passSeedsDev);
         }
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
@@ -832,8 +859,8 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
     {
         r->neePerPath = totalLightSamples + (sc.probe.valid ? 1 : 0);
         sc.totalLightSamples = r->neePerPath;
-        if (hipMalloc((void**)&r->statsDev, sizeof(unsigned long long)*8) != hipSuccess ||
-            hipMemset(r->statsDev, 0, sizeof(unsigned long long)*8) != hipSuccess)
+        if (hipMalloc((void**)&r->statsDev, sizeof(unsigned long long)*kStatShards*kStatWords) != hipSuccess ||
+            hipMemset(r->statsDev, 0, sizeof(unsigned long long)*kStatShards*kStatWords) != hipSuccess)
         {
             fail("create: device allocation failed (stats)");
             ok = false;
@@ -942,7 +969,7 @@ int tinsel_hip_set_shard(tinsel_hip* r, int rank, int world, int tile)
 
 int tinsel_hip_set_pipeline(tinsel_hip* r, int pipeline)
 {
-    if (!r || (pipeline != TINSEL_PIPELINE_WAVEFRONT && pipeline != TINSEL_PIPELINE_MEGAKERNEL))
+    if (!r || pipeline < TINSEL_PIPELINE_WAVEFRONT || pipeline > TINSEL_PIPELINE_WAVEFRONT_SPLIT)
         return fail("set_pipeline: bad arguments");
     r->pipeline = pipeline;
     return 0;
@@ -958,15 +985,25 @@ int tinsel_hip_set_pass_index(tinsel_hip* r, uint32_t pass_index)
 
 uint32_t tinsel_hip_get_pass_index(tinsel_hip* r) { return r ? r->passIndex : 0; }
 
+static int read_stats(tinsel_hip* r, unsigned long long* out8)
+{
+    std::vector<unsigned long long> shards((size_t)kStatShards*kStatWords);
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(shards.data(), r->statsDev, sizeof(unsigned long long)*shards.size(), hipMemcpyDeviceToHost));
+    for (int w = 0; w < kStatWords; ++w)
+        out8[w] = 0;
+    for (int b = 0; b < kStatShards; ++b)
+        for (int w = 0; w < kStatWords; ++w)
+            out8[w] += shards[(size_t)b*kStatWords + w];
+    return 0;
+}
+
 void tinsel_hip_stats(tinsel_hip* r, unsigned long long* rays, unsigned long long* samples, double* gpu_seconds)
 {
     unsigned long long s[8] = { 0 };
     if (r && r->statsDev)
-    {
-        (void)hipSetDevice(r->device);
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(s, r->statsDev, sizeof(s), hipMemcpyDeviceToHost);
-    }
+        (void)read_stats(r, s);
     if (rays) *rays = s[0];
     if (samples) *samples = s[1];
     if (gpu_seconds) *gpu_seconds = r ? r->gpuSeconds : 0.0;
@@ -978,10 +1015,7 @@ int tinsel_hip_stats_detail(tinsel_hip* r, unsigned long long* out8)
 {
     if (!r || !out8)
         return fail("stats_detail: bad arguments");
-    HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out8, r->statsDev, sizeof(unsigned long long)*8, hipMemcpyDeviceToHost));
-    return 0;
+    return read_stats(r, out8);
 }
 
 int tinsel_hip_set_detail_counters(tinsel_hip* r, int enable)
@@ -998,7 +1032,7 @@ void tinsel_hip_reset_stats(tinsel_hip* r)
         return;
     (void)hipSetDevice(r->device);
     (void)hipDeviceSynchronize();
-    (void)hipMemset(r->statsDev, 0, sizeof(unsigned long long)*8);
+    (void)hipMemset(r->statsDev, 0, sizeof(unsigned long long)*kStatShards*kStatWords);
     r->gpuSeconds = 0.0;
 }
 

@@ -2,23 +2,33 @@
 //
 // Streaming (wavefront) pipeline, one batch of B = pixels x passes path slots:
 //
-//   k_generate                      camera rays + path state  -> HBM, bounce-0 queue
 //   for bounce in 0..maxDepth-1:
-//     k_extend   (queue[bounce])    closest-hit traversal           reads ray, writes hit
-//     k_shade    (queue[bounce])    emission/MIS, NEE sample records, BSDF sample -> next ray;
-//                                   wave64 ballot compaction into queue[bounce+1] and the NEE queue
-//     k_shadow   (neeQueue[bounce]) NEE visibility rays, resolves direct light into the path radiance
+//     k_bounce<FIRST = bounce==0>   one iteration of the oracle's path loop for every path in
+//                                   queue[bounce] (bounce 0: camera rays generated in-kernel);
+//                                   survivors' 96-B state -> HBM, wave64 ballot compaction into
+//                                   queue[bounce+1]
 //   k_accumulate                    filter-footprint GATHER into the float4 accumulator (no atomics,
 //                                   bit-reproducible, same summation order as render.cpp:401-445)
 //
-// All trace kernels are persistent: a fixed grid whose waves pull 64-entry chunks from the
-// queue with one atomic per wave; traversal stacks live in LDS as stack[entry][lane].
+// A/B arms sharing the same per-path arithmetic: the SPLIT pipeline (k_generate, then k_extend /
+// k_shade / k_shadow per bounce with hit and NEE records parked in HBM) and k_mega (one lane per
+// whole path).  All trace kernels are streaming: a fixed grid whose blocks own contiguous queue ranges and
+// append survivors with one atomic per 2048 entries; traversal stacks live in LDS as stack[entry][lane].
 #pragma once
 
 #include "tn_integrator.h"
 
 namespace tn {
 
+// Minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__
+// argument).  Measured on cornell 1024^2 (profiles/r01_b): the fused kernels are fastest at 2
+// (256 VGPRs, no AGPR spill copies, ~200 B scratch), the trace-only kernels at 4 (128 VGPRs).
+#ifndef TN_WAVES_FUSED
+#define TN_WAVES_FUSED 2
+#endif
+#ifndef TN_WAVES_TRACE
+#define TN_WAVES_TRACE 4
+#endif
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
@@ -72,43 +82,72 @@ struct FrameParams
 
 // ---------------------------------------------------------------------------
 // wave-level helpers
+//
+// Single-address atomics retire at ~88 M/s on this chip (MI355X_MICROARCH.md, "dequeue" row): one
+// atomic per 64 rays caps a kernel at ~5.6 Grays/s per counter, one per 128 still costs ~0.4 ms per
+// 4 Mi rays (profiles/r01_a, r01_b).  So the queue is cut STATICALLY into contiguous per-block
+// ranges (blocks are handed to CUs dynamically by the dispatcher, which is all the load balancing
+// a 2048-block grid needs) and a block appends its survivors with ONE atomic per queue per
+// kMaxItems x 256 entries, after a wave64-ballot + LDS scan.
+
+constexpr int kMaxItems = 8;
+constexpr int kStatShards = 2048;       // stats[kStatShards][8]
+constexpr int kStatWords = 8;
+constexpr int kScanWords = 8;           // LDS words behind the traversal stacks used by block_append
 
 TN_D int lane_id() { return (int)__lane_id(); }
 
-// Order-preserving-within-wave compaction: one atomic per wave.  Must be called by all lanes.
-TN_D uint32_t wave_enqueue(bool pred, uint32_t* counter)
+// rounds of kBlock entries this block must make over a queue of `count` entries
+TN_D uint32_t block_rounds(uint32_t count)
 {
-    const unsigned long long mask = __ballot(pred);
-    uint32_t base = 0;
-    if (mask)
+    return (count + gridDim.x*kBlock - 1u)/(gridDim.x*kBlock);
+}
+
+// Appends this block's survivors of up to kMaxItems rounds.  bits: thread-private mask, bit i =
+// the entry this thread handled in round i survives; slot(i) returns the value to append for it.
+// One atomic per block.  MUST be reached by every thread of the block (it synchronises).
+template <class SlotFn>
+TN_D void block_append(uint32_t bits, uint32_t* counter, uint32_t* __restrict__ queue, uint32_t* s_scan, SlotFn slot)
+{
+    const int lane = lane_id();
+    const int wave = (int)threadIdx.x/kWave;
+    unsigned long long masks[kMaxItems];
+    uint32_t waveTotal = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxItems; ++i)
     {
-        const int leader = __ffsll((long long)mask) - 1;
-        const int lane = lane_id();
-        if (lane == leader)
-            base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
-        const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        return base + prefix;
+        masks[i] = __ballot((bits >> i) & 1u);
+        waveTotal += (uint32_t)__popcll(masks[i]);
     }
-    return 0;
+    if (lane == 0)
+        s_scan[wave] = waveTotal;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const uint32_t total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+        s_scan[4] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_scan[4];
+    for (int w = 0; w < wave; ++w)
+        base += s_scan[w];
+#pragma unroll
+    for (int i = 0; i < kMaxItems; ++i)
+    {
+        if ((bits >> i) & 1u)
+            queue[base + (uint32_t)__popcll(masks[i] & ((1ull << lane) - 1ull))] = slot(i);
+        base += (uint32_t)__popcll(masks[i]);
+    }
+    __syncthreads();        // s_scan is reused by the next call
 }
 
-// One wave grabs the next 64 queue entries.
-TN_D uint32_t wave_fetch(uint32_t* cursor)
+// statistics: wave reduction, then one atomic per wave into this block's shard (distinct addresses)
+TN_D void wave_add_stat(unsigned long long* stats, int word, uint32_t v)
 {
-    uint32_t base = 0;
-    if (lane_id() == 0)
-        base = atomicAdd(cursor, (uint32_t)kWave);
-    return __shfl(base, 0);
-}
-
-TN_D void wave_add_stat(unsigned long long* dst, uint32_t v)
-{
-    // wave reduction, one atomic per wave
     for (int off = 32; off > 0; off >>= 1)
         v += __shfl_down(v, off);
     if (lane_id() == 0 && v)
-        atomicAdd(dst, (unsigned long long)v);
+        atomicAdd(stats + (size_t)(blockIdx.x % kStatShards)*kStatWords + word, (unsigned long long)v);
 }
 
 TN_D bool pixel_owned(const FrameParams& fp, int i, int j)
@@ -147,74 +186,252 @@ TN_D void camera_sample(const CameraParams& cam, const FrameParams& fp, int i, i
 }
 
 // ---------------------------------------------------------------------------
-// k_generate
+// path-state load/store
 
-__global__ __launch_bounds__(kBlock) void k_generate(PathState ps, QueueCtl q, uint32_t* queue0, CameraParams cam, FrameParams fp,
-                                                     const uint32_t* __restrict__ passSeeds)
+TN_D void load_path(const PathState& ps, uint32_t slot, PathRegs& p, float& rasterX, float& rasterY)
+{
+    const float4 ro = ps.rayO[slot], rd = ps.rayD[slot], th = ps.thr[slot], ra = ps.rad[slot];
+    const float4 ab = ps.absorb[slot], rr = ps.rngRaster[slot];
+    p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
+    p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
+    p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
+    p.rad = V3(ra.x, ra.y, ra.z); p.rayType = __float_as_int(ra.w);
+    p.absorption = V3(ab.x, ab.y, ab.z);
+    p.rng.s1 = __float_as_uint(rr.x); p.rng.s2 = __float_as_uint(rr.y);
+    rasterX = rr.z; rasterY = rr.w;
+}
+
+TN_D void store_path(const PathState& ps, uint32_t slot, const PathRegs& p, float rasterX, float rasterY)
+{
+    ps.rayO[slot] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
+    ps.rayD[slot] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
+    ps.thr[slot] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
+    ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
+    ps.absorb[slot] = make_float4(p.absorption.x, p.absorption.y, p.absorption.z, 0.0f);
+    ps.rngRaster[slot] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), rasterX, rasterY);
+}
+
+// Slot -> (pass, pixel); generates the camera sample.  Returns false for pixels of other shards.
+TN_D bool begin_path(const CameraParams& cam, const FrameParams& fp, const uint32_t* __restrict__ passSeeds, uint32_t slot,
+                     PathRegs& p, float& rx, float& ry)
 {
     const int npix = fp.width*fp.height;
-    const int total = npix*fp.numPasses;
-    const int slot = blockIdx.x*kBlock + threadIdx.x;
-    bool live = false;
+    const int s = (int)slot/npix;
+    const int pix = (int)slot - s*npix;
+    const int j = pix/fp.width;
+    const int i = pix - j*fp.width;
+    if (!pixel_owned(fp, i, j))
+        return false;
+    Rng rng;
+    float time;
+    V3 o, d;
+    camera_sample(cam, fp, i, j, passSeeds[fp.passBase + s], rng, rx, ry, time, o, d);
+    path_begin(p, o, d, time, rng);
+    return true;
+}
 
-    if (slot < total)
+// ---------------------------------------------------------------------------
+// k_bounce: the streaming pipeline's per-bounce kernel (the product path).
+//
+// One launch per bounce.  Each lane takes ONE live path from queue[bounce] (bounce 0: straight
+// from the camera), runs one iteration of the oracle's loop (render.cpp:250-385: closest hit,
+// emission/MIS, every NEE shadow ray, BSDF sample) and either retires the path or writes its
+// 96-B state back and appends it to queue[bounce+1].  Lanes are therefore always full at the
+// start of a bounce, and a path costs one state read + one state write per bounce.
+
+template <bool COUNT, bool FIRST>
+__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueIn,
+                                                   uint32_t* __restrict__ queueOut, int bounce, int stackEntries, CameraParams cam,
+                                                   FrameParams fp, const uint32_t* __restrict__ passSeeds)
+{
+    extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
+    LdsStack<kBlock> st = { s_stack + threadIdx.x };
+
+    uint32_t* s_scan = s_stack + stackEntries*kBlock;
+
+    const uint32_t count = FIRST ? (uint32_t)(fp.width*fp.height*fp.numPasses) : q.activeCount[bounce];
+    const uint32_t rounds = block_rounds(count);
+    const uint32_t first = blockIdx.x*rounds*kBlock;       // this block's contiguous range
+    uint32_t rays = 0, shadowRays = 0, samples = 0;
+    TraceCounters ctr = { 0, 0, 0 };
+
+    for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
     {
-        const int s = slot/npix;
-        const int pix = slot - s*npix;
-        const int j = pix/fp.width;
-        const int i = pix - j*fp.width;
+        const uint32_t base = first + r0*kBlock;
+        const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
 
-        if (pixel_owned(fp, i, j))
+        uint32_t keep = 0;
+        for (uint32_t g = 0; g < groups; ++g)
         {
-            Rng rng;
-            float rx, ry, time;
-            V3 o, d;
-            camera_sample(cam, fp, i, j, passSeeds[fp.passBase + s], rng, rx, ry, time, o, d);
+            const uint32_t idx = base + g*kBlock + threadIdx.x;
+            if (idx >= count)
+                continue;
+            const uint32_t slot = FIRST ? idx : queueIn[idx];
 
-            ps.rayO[slot] = make_float4(o.x, o.y, o.z, time);
-            ps.rayD[slot] = make_float4(d.x, d.y, d.z, 1.0f);
-            ps.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float((int)kReflected));
-            ps.absorb[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            ps.rngRaster[slot] = make_float4(__uint_as_float(rng.s1), __uint_as_float(rng.s2), rx, ry);
-            live = true;
+            PathRegs p;
+            float rx, ry;
+            if (FIRST)
+            {
+                if (!begin_path(cam, fp, passSeeds, slot, p, rx, ry))
+                {
+                    ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    ps.rngRaster[slot] = make_float4(0.0f, 0.0f, -1e30f, -1e30f);
+                    continue;
+                }
+                samples++;
+            }
+            else
+            {
+                load_path(ps, slot, p, rx, ry);
+            }
+
+            float t;
+            V3 n;
+            const int prim = trace<LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n, ctr);
+            rays++;
+
+            bool alive = false;
+            if (prim < 0)
+            {
+                on_miss(sc, p, bounce);
+            }
+            else
+            {
+                const Mat mat = load_mat(sc.mats, prim);
+                HitCtx h;
+                on_hit_begin(p, mat, t, n, bounce, h);
+
+                if (sc.totalLightSamples > 0)
+                {
+                    const V3 thrAtNee = p.thr;
+                    int li = 0, sInLight = 0;
+                    V3 sum = nee_sum(sc, [&](int k) -> V3 {
+                        NeeRec r;
+                        if (sc.probe.valid && k == 0)
+                        {
+                            nee_prepare_probe(sc, mat, h, p.rng, r);
+                        }
+                        else
+                        {
+                            // NEE rays arrive in order: walk (light, sample) along with k
+                            while (sInLight >= sc.mats[sc.lights[li]].lightSamples) { ++li; sInLight = 0; }
+                            nee_prepare_light(sc, mat, h, p.time, sc.lights[li], p.rng, r);
+                            ++sInLight;
+                        }
+                        float ts;
+                        V3 nn;
+                        const int hp = trace<LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, p.time, ts, nn, ctr);
+                        rays++;
+                        shadowRays++;
+                        if (r.dist < 0.0f)
+                            return (hp < 0) ? r.f : V3(0.0f);
+                        return nee_resolve_light(sc, r, hp, ts);
+                    });
+                    p.rad = p.rad + thrAtNee*sum;
+                }
+
+                // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
+                if (bounce + 1 < fp.maxDepth)
+                    alive = (bsdf_step(p, mat, h) == kContinue);
+            }
+
+            if (alive)
+            {
+                store_path(ps, slot, p, rx, ry);
+                keep |= 1u << g;
+            }
+            else
+            {
+                ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
+                if (FIRST)
+                    ps.rngRaster[slot] = make_float4(0.0f, 0.0f, rx, ry);
+            }
         }
-        else
-        {
-            ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            ps.rngRaster[slot] = make_float4(0.0f, 0.0f, -1e30f, -1e30f);
-        }
+
+        block_append(keep, q.activeCount + bounce + 1, queueOut, s_scan, [&](int i) -> uint32_t {
+            const uint32_t idx = base + (uint32_t)i*kBlock + threadIdx.x;
+            return FIRST ? idx : queueIn[idx];
+        });
     }
 
-    const uint32_t at = wave_enqueue(live, q.activeCount + 0);
-    if (live)
-        queue0[at] = (uint32_t)slot;
+    wave_add_stat(q.stats, 0, rays);
+    wave_add_stat(q.stats, 1, samples);
+    wave_add_stat(q.stats, 5, shadowRays);
+    if (COUNT)
+    {
+        wave_add_stat(q.stats, 2, ctr.internal);
+        wave_add_stat(q.stats, 3, ctr.tris);
+        wave_add_stat(q.stats, 4, ctr.prims);
+    }
+}
 
-    uint32_t one = live ? 1u : 0u;
-    wave_add_stat(q.stats + 1, one);
+// ===========================================================================
+// The SPLIT variant of the pipeline (TINSEL_PIPELINE_WAVEFRONT_SPLIT): the same bounce cut into
+// three kernels with hit / NEE records parked in HBM in between.  Kept as an A/B arm: it trades
+// ~3x the state traffic for smaller kernels (k_extend/k_shadow 132-136 VGPRs vs k_bounce's).
+
+// ---------------------------------------------------------------------------
+// k_generate
+
+__global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q, uint32_t* queue0, CameraParams cam, FrameParams fp,
+                                                     const uint32_t* __restrict__ passSeeds)
+{
+    __shared__ uint32_t s_scan[kScanWords];
+    const uint32_t count = (uint32_t)(fp.width*fp.height*fp.numPasses);
+    const uint32_t rounds = block_rounds(count);
+    const uint32_t first = blockIdx.x*rounds*kBlock;
+    uint32_t samples = 0;
+
+    for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
+    {
+        const uint32_t base = first + r0*kBlock;
+        const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
+        uint32_t keep = 0;
+        for (uint32_t g = 0; g < groups; ++g)
+        {
+            const uint32_t slot = base + g*kBlock + threadIdx.x;
+            if (slot >= count)
+                continue;
+            PathRegs p;
+            float rx, ry;
+            if (begin_path(cam, fp, passSeeds, slot, p, rx, ry))
+            {
+                store_path(ps, slot, p, rx, ry);
+                keep |= 1u << g;
+                samples++;
+            }
+            else
+            {
+                ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                ps.rngRaster[slot] = make_float4(0.0f, 0.0f, -1e30f, -1e30f);
+            }
+        }
+        block_append(keep, q.activeCount + 0, queue0, s_scan, [&](int i) -> uint32_t { return base + (uint32_t)i*kBlock + threadIdx.x; });
+    }
+    wave_add_stat(q.stats, 1, samples);
 }
 
 // ---------------------------------------------------------------------------
 // k_extend: closest hit for every queued path
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce)
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
 
     const uint32_t count = q.activeCount[bounce];
+    const uint32_t rounds = block_rounds(count);
+    const uint32_t first = blockIdx.x*rounds*kBlock;
     uint32_t rays = 0;
     TraceCounters ctr = { 0, 0, 0 };
 
-    for (;;)
     {
-        const uint32_t base = wave_fetch(q.cursorExtend + bounce);
-        if (base >= count)
-            break;
-        const uint32_t idx = base + lane_id();
-        if (idx < count)
+        for (uint32_t g = 0; g < rounds; ++g)
         {
+            const uint32_t idx = first + g*kBlock + threadIdx.x;
+            if (idx >= count)
+                continue;
             const uint32_t slot = queue[idx];
             const float4 ro = ps.rayO[slot];
             const float4 rd = ps.rayD[slot];
@@ -229,12 +446,12 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathState ps, Qu
         }
     }
 
-    wave_add_stat(q.stats + 0, rays);
+    wave_add_stat(q.stats, 0, rays);
     if (COUNT)
     {
-        wave_add_stat(q.stats + 2, ctr.internal);
-        wave_add_stat(q.stats + 3, ctr.tris);
-        wave_add_stat(q.stats + 4, ctr.prims);
+        wave_add_stat(q.stats, 2, ctr.internal);
+        wave_add_stat(q.stats, 3, ctr.tris);
+        wave_add_stat(q.stats, 4, ctr.prims);
     }
 }
 
@@ -262,102 +479,89 @@ TN_D NeeRec load_nee(const PathState& ps, uint32_t slot, int k)
     return r;
 }
 
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ queueNext, uint32_t* __restrict__ queueNee, int bounce, int maxDepth)
 {
+    __shared__ uint32_t s_scan[kScanWords];
     const uint32_t count = q.activeCount[bounce];
+    const uint32_t rounds = block_rounds(count);
+    const uint32_t first = blockIdx.x*rounds*kBlock;
 
-    for (;;)
+    for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
     {
-        const uint32_t base = wave_fetch(q.cursorShade + bounce);
-        if (base >= count)
-            break;
-        const uint32_t idx = base + lane_id();
+        const uint32_t base = first + r0*kBlock;
+        const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
 
-        bool wantNee = false;
-        bool wantNext = false;
-        uint32_t slot = 0;
-
-        if (idx < count)
+        uint32_t keepNee = 0, keepNext = 0;
+        for (uint32_t g = 0; g < groups; ++g)
         {
-            slot = queue[idx];
+            const uint32_t idx = base + g*kBlock + threadIdx.x;
+            if (idx >= count)
+                continue;
+            const uint32_t slot = queue[idx];
 
             PathRegs p;
-            {
-                const float4 ro = ps.rayO[slot], rd = ps.rayD[slot], th = ps.thr[slot], ra = ps.rad[slot];
-                const float4 ab = ps.absorb[slot], rr = ps.rngRaster[slot];
-                p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
-                p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
-                p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
-                p.rad = V3(ra.x, ra.y, ra.z); p.rayType = __float_as_int(ra.w);
-                p.absorption = V3(ab.x, ab.y, ab.z);
-                p.rng.s1 = __float_as_uint(rr.x); p.rng.s2 = __float_as_uint(rr.y);
-            }
+            float rx, ry;
+            load_path(ps, slot, p, rx, ry);
 
             const int prim = ps.hitPrim[slot];
             if (prim < 0)
             {
                 on_miss(sc, p, bounce);
                 ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
+                continue;
+            }
+
+            const float4 hh = ps.hit[slot];
+            const Mat mat = load_mat(sc.mats, prim);
+
+            HitCtx h;
+            on_hit_begin(p, mat, hh.x, V3(hh.y, hh.z, hh.w), bounce, h);
+
+            // SampleLights, part 1 (render.cpp:107-170): consume the RNG, emit shadow-ray records
+            int k = 0;
+            if (sc.probe.valid)
+            {
+                NeeRec r;
+                nee_prepare_probe(sc, mat, h, p.rng, r);
+                store_nee(ps, slot, k++, r);
+            }
+            for (int li = 0; li < sc.numLights; ++li)
+            {
+                const int light = sc.lights[li];
+                const int ns = sc.mats[light].lightSamples;
+                for (int s = 0; s < ns; ++s)
+                {
+                    NeeRec r;
+                    nee_prepare_light(sc, mat, h, p.time, light, p.rng, r);
+                    store_nee(ps, slot, k++, r);
+                }
+            }
+            if (k > 0)
+            {
+                ps.neeThr[slot] = make_float4(p.thr.x, p.thr.y, p.thr.z, 0.0f);
+                keepNee |= 1u << g;
+            }
+
+            // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
+            int res = kTerminate;
+            if (bounce + 1 < maxDepth)
+                res = bsdf_step(p, mat, h);
+
+            if (res == kContinue)
+            {
+                store_path(ps, slot, p, rx, ry);
+                keepNext |= 1u << g;
             }
             else
             {
-                const float4 hh = ps.hit[slot];
-                const Mat mat = load_mat(sc.mats, prim);
-
-                HitCtx h;
-                on_hit_begin(p, mat, hh.x, V3(hh.y, hh.z, hh.w), bounce, h);
-
-                // SampleLights, part 1 (render.cpp:107-170): consume the RNG, emit shadow-ray records
-                int k = 0;
-                if (sc.probe.valid)
-                {
-                    NeeRec r;
-                    nee_prepare_probe(sc, mat, h, p.rng, r);
-                    store_nee(ps, slot, k++, r);
-                }
-                for (int li = 0; li < sc.numLights; ++li)
-                {
-                    const int light = sc.lights[li];
-                    const int ns = sc.mats[light].lightSamples;
-                    for (int s = 0; s < ns; ++s)
-                    {
-                        NeeRec r;
-                        nee_prepare_light(sc, mat, h, p.time, light, p.rng, r);
-                        store_nee(ps, slot, k++, r);
-                    }
-                }
-                if (k > 0)
-                {
-                    ps.neeThr[slot] = make_float4(p.thr.x, p.thr.y, p.thr.z, 0.0f);
-                    wantNee = true;
-                }
-
-                // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
-                int res = kTerminate;
-                if (bounce + 1 < maxDepth)
-                    res = bsdf_step(p, mat, h);
-                wantNext = (res == kContinue);
-
                 ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
-                if (wantNext)
-                {
-                    const float4 rr = ps.rngRaster[slot];
-                    ps.rayO[slot] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
-                    ps.rayD[slot] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
-                    ps.thr[slot] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
-                    ps.absorb[slot] = make_float4(p.absorption.x, p.absorption.y, p.absorption.z, 0.0f);
-                    ps.rngRaster[slot] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), rr.z, rr.w);
-                }
             }
         }
 
-        const uint32_t atNee = wave_enqueue(wantNee, q.neeCount + bounce);
-        if (wantNee)
-            queueNee[atNee] = slot;
-        const uint32_t atNext = wave_enqueue(wantNext, q.activeCount + bounce + 1);
-        if (wantNext)
-            queueNext[atNext] = slot;
+        auto slotOf = [&](int i) -> uint32_t { return queue[base + (uint32_t)i*kBlock + threadIdx.x]; };
+        block_append(keepNee, q.neeCount + bounce, queueNee, s_scan, slotOf);
+        block_append(keepNext, q.activeCount + bounce + 1, queueNext, s_scan, slotOf);
     }
 }
 
@@ -366,23 +570,23 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, PathState ps, Que
 // its K shadow rays in the oracle's order, then totalRadiance += pathThroughput*sum (render.cpp:314)
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce)
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
 
     const uint32_t count = q.neeCount[bounce];
+    const uint32_t rounds = block_rounds(count);
+    const uint32_t first = blockIdx.x*rounds*kBlock;
     uint32_t rays = 0;
     TraceCounters ctr = { 0, 0, 0 };
 
-    for (;;)
     {
-        const uint32_t base = wave_fetch(q.cursorShadow + bounce);
-        if (base >= count)
-            break;
-        const uint32_t idx = base + lane_id();
-        if (idx < count)
+        for (uint32_t g = 0; g < rounds; ++g)
         {
+            const uint32_t idx = first + g*kBlock + threadIdx.x;
+            if (idx >= count)
+                continue;
             const uint32_t slot = queueNee[idx];
             const float time = ps.rayO[slot].w;     // rayTime never changes along a path
 
@@ -404,13 +608,13 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, PathState ps, Qu
         }
     }
 
-    wave_add_stat(q.stats + 0, rays);
-    wave_add_stat(q.stats + 5, rays);
+    wave_add_stat(q.stats, 0, rays);
+    wave_add_stat(q.stats, 5, rays);
     if (COUNT)
     {
-        wave_add_stat(q.stats + 2, ctr.internal);
-        wave_add_stat(q.stats + 3, ctr.tris);
-        wave_add_stat(q.stats + 4, ctr.prims);
+        wave_add_stat(q.stats, 2, ctr.internal);
+        wave_add_stat(q.stats, 3, ctr.tris);
+        wave_add_stat(q.stats, 4, ctr.prims);
     }
 }
 
@@ -418,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, PathState ps, Qu
 // k_mega: the A/B arm -- one lane walks one whole path (render.cpp:230-388), same pieces.
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_mega(DevScene sc, PathState ps, QueueCtl q, CameraParams cam, FrameParams fp,
+__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene sc, PathState ps, QueueCtl q, CameraParams cam, FrameParams fp,
                                                  const uint32_t* __restrict__ passSeeds)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
@@ -518,14 +722,14 @@ __global__ __launch_bounds__(kBlock) void k_mega(DevScene sc, PathState ps, Queu
         }
     }
 
-    wave_add_stat(q.stats + 0, rays);
-    wave_add_stat(q.stats + 1, samples);
-    wave_add_stat(q.stats + 5, shadowRays);
+    wave_add_stat(q.stats, 0, rays);
+    wave_add_stat(q.stats, 1, samples);
+    wave_add_stat(q.stats, 5, shadowRays);
     if (COUNT)
     {
-        wave_add_stat(q.stats + 2, ctr.internal);
-        wave_add_stat(q.stats + 3, ctr.tris);
-        wave_add_stat(q.stats + 4, ctr.prims);
+        wave_add_stat(q.stats, 2, ctr.internal);
+        wave_add_stat(q.stats, 3, ctr.tris);
+        wave_add_stat(q.stats, 4, ctr.prims);
     }
 }
 
@@ -540,7 +744,7 @@ TN_D float filter_gauss(float x, float falloff, float offset)      // Filter::Ga
     return maxT(0.0f, float(m_expf(-falloff*x*x)) - offset);
 }
 
-__global__ __launch_bounds__(kBlock) void k_accumulate(PathState ps, FrameParams fp, float4* __restrict__ accum)
+__global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FrameParams fp, float4* __restrict__ accum)
 {
     const int npix = fp.width*fp.height;
     const int pix = blockIdx.x*kBlock + threadIdx.x;
@@ -600,7 +804,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PathState ps, FrameParams
 // ---------------------------------------------------------------------------
 // k_normals: eNormals mode of the CPU renderer (render.cpp:494-515): x=i, y=j, time 1, overwrite.
 
-__global__ __launch_bounds__(kBlock) void k_normals(DevScene sc, CameraParams cam, FrameParams fp, float4* __restrict__ accum)
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_normals(DevScene sc, CameraParams cam, FrameParams fp, float4* __restrict__ accum)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };

@@ -22,7 +22,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinsel_hip.so")
+LIB_PATH = os.environ.get("TINSEL_HIP_LIB", os.path.join(_HERE, "libtinsel_hip.so"))     # env: A/B builds only
 
 _lib = None
 
