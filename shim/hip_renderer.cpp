@@ -1,0 +1,83 @@
+// hip_renderer.cpp -- the reference-side binding: what a Tinsel maintainer adds to make
+//     Renderer* CreateGpuRenderer(const Scene* s)            (reference src/render.h:79)
+// return the MI355X back-end instead of the CUDA one (reference src/render.cu:978-1110).
+//
+// Compiled by g++ against the REFERENCE headers (-I$(REF)/src) and linked with
+// tinsel_amd/libtinsel_hip.so; it is the only translation unit that sees both worlds.
+// `Scene` holds std::vectors (scene.h:186-190), so it is walked HERE and handed down as the
+// flat tinsel_scene_desc; the POD records cross the C-ABI unchanged (same layouts, asserted below).
+
+#include "render.h"
+#include "scene.h"
+
+#include "../include/tinsel_hip.h"
+
+#include <cstdio>
+
+static_assert(sizeof(Primitive) == sizeof(tinsel_primitive), "Primitive layout");
+static_assert(sizeof(BVHNode) == sizeof(tinsel_bvh_node), "BVHNode layout");
+static_assert(sizeof(Camera) == sizeof(tinsel_camera), "Camera layout");
+static_assert(sizeof(Options) == sizeof(tinsel_options), "Options layout");
+static_assert(sizeof(Color) == 4*sizeof(float), "Color layout");
+
+struct HipRenderer : public Renderer
+{
+    tinsel_hip* handle;
+
+    HipRenderer(const Scene* s) : handle(NULL)
+    {
+        tinsel_scene_desc d = {};
+        d.primitives = (const tinsel_primitive*)&s->primitives[0];
+        d.num_primitives = (int32_t)s->primitives.size();
+        d.bvh_nodes = (const tinsel_bvh_node*)s->bvh.nodes;
+        d.num_bvh_nodes = s->bvh.numNodes;
+        d.sky_horizon = { s->sky.horizon.x, s->sky.horizon.y, s->sky.horizon.z };
+        d.sky_zenith = { s->sky.zenith.x, s->sky.zenith.y, s->sky.zenith.z };
+        const Probe& p = s->sky.probe;
+        if (p.valid)
+        {
+            d.probe_valid = 1;
+            d.probe_width = p.width;
+            d.probe_height = p.height;
+            d.probe_data = (const tinsel_vec4*)p.data;
+            d.probe_pdf_x = p.pdfValuesX;
+            d.probe_cdf_x = p.cdfValuesX;
+            d.probe_pdf_y = p.pdfValuesY;
+            d.probe_cdf_y = p.cdfValuesY;
+        }
+        handle = tinsel_hip_create(&d, 0);
+        if (!handle)
+            fprintf(stderr, "CreateGpuRenderer: %s\n", tinsel_hip_last_error());
+    }
+
+    virtual ~HipRenderer() { tinsel_hip_destroy(handle); }
+
+    // Renderer::Init (render.h:70): allocate + zero the accumulator (render.cu:1070-1075)
+    virtual void Init(int width, int height)
+    {
+        if (handle && tinsel_hip_init(handle, width, height))
+            fprintf(stderr, "HipRenderer::Init: %s\n", tinsel_hip_last_error());
+    }
+
+    // Renderer::Render (render.h:71): one more sample per pixel; `output` receives the running
+    // sum (rgb*w, w) like render.cu:1102.  On failure `output` is left untouched (the reference
+    // reports no errors either; the message is on stderr and in tinsel_hip_last_error()).
+    virtual void Render(const Camera& camera, const Options& options, Color* output)
+    {
+        if (handle && tinsel_hip_render(handle, (const tinsel_camera*)&camera, (const tinsel_options*)&options, (float*)output, 1))
+            fprintf(stderr, "HipRenderer::Render: %s\n", tinsel_hip_last_error());
+    }
+};
+
+Renderer* CreateGpuRenderer(const Scene* s)
+{
+    return new HipRenderer(s);
+}
+
+// beyond the reference interface: N passes per call without the per-pass full-frame D2H
+// (SURVEY.md 8b "API-compat mitigation"); used by the headless driver.
+extern "C" int HipRendererRenderPasses(Renderer* r, const Camera& camera, const Options& options, Color* output, int passes)
+{
+    HipRenderer* h = static_cast<HipRenderer*>(r);
+    return h->handle ? tinsel_hip_render(h->handle, (const tinsel_camera*)&camera, (const tinsel_options*)&options, (float*)output, passes) : -1;
+}

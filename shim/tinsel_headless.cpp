@@ -1,0 +1,131 @@
+// tinsel_headless.cpp -- a headless stand-in for the caller of the boundary (reference src/main.cpp,
+// which needs GLUT/OpenGL): the reference's OWN loader, Scene::Build and CLI conventions
+// (main.cpp:95-172, 174-220, 242-271) driving CreateGpuRenderer() through the reference's
+// Renderer interface, with the reference's CreateCpuRenderer() timed beside it.
+//
+//   tinsel_headless scene.tin [-spp=N] [-width=W] [-height=H] [-maxdepth=D] [-cpuspp=M] [-out=file.pfm]
+//
+// Prints per-back-end wall time and the image-level difference of the two estimates (different RNG
+// streams: statistical agreement only; the per-seed parity tests live in tests/).
+#include "render.h"
+#include "loader.h"
+#include "scene.h"
+#include "util.h"
+#include "pfm.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+extern "C" int HipRendererRenderPasses(Renderer* r, const Camera& camera, const Options& options, Color* output, int passes);
+
+int main(int argc, char* argv[])
+{
+    Scene scene;
+    Camera camera;
+    Options options;
+
+    // defaults of main.cpp:181-193
+    options.width = 512;
+    options.height = 256;
+    options.filter = Filter(eFilterGaussian, 0.75f, 1.0f);
+    options.mode = ePathTrace;
+    options.exposure = 1.0f;
+    options.limit = 1.5f;
+    options.clamp = FLT_MAX;
+    options.maxDepth = 4;
+    options.maxSamples = INT_MAX;
+    camera.position = Vec3(0.0f, 1.0f, 5.0f);
+    camera.rotation = Quat();
+    camera.fov = DegToRad(35.0f);
+
+    int spp = 64, cpuSpp = 0;
+    const char* out = NULL;
+    const char* file = NULL;
+
+    for (int i = 1; i < argc; ++i)      // "-key=value" overrides after the scene file (main.cpp:143-149)
+    {
+        if (strstr(argv[i], ".tin"))
+            file = argv[i];
+    }
+    if (!file || !LoadTin(file, &scene, &camera, &options))
+    {
+        printf("usage: tinsel_headless scene.tin [-spp=N] [-width=W] [-height=H] [-maxdepth=D] [-cpuspp=M] [-out=f.pfm]\n");
+        return 1;
+    }
+    for (int i = 1; i < argc; ++i)
+    {
+        sscanf(argv[i], "-spp=%d", &spp);
+        sscanf(argv[i], "-cpuspp=%d", &cpuSpp);
+        sscanf(argv[i], "-width=%d", &options.width);
+        sscanf(argv[i], "-height=%d", &options.height);
+        sscanf(argv[i], "-maxdepth=%d", &options.maxDepth);
+        if (strncmp(argv[i], "-out=", 5) == 0)
+            out = argv[i] + 5;
+    }
+
+    scene.Build();      // main.cpp:199
+
+    const size_t npix = (size_t)options.width*options.height;
+    std::vector<Color> gpuPixels(npix), cpuPixels(npix);
+
+    Renderer* gpu = CreateGpuRenderer(&scene);
+    gpu->Init(options.width, options.height);
+    auto t0 = std::chrono::steady_clock::now();
+    if (HipRendererRenderPasses(gpu, camera, options, &gpuPixels[0], spp))
+    {
+        delete gpu;
+        return 2;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    const double gpuSec = std::chrono::duration<double>(t1 - t0).count();
+    printf("gpu: %d spp %dx%d in %.4f s (%.2f Msamples/s)\n", spp, options.width, options.height, gpuSec, spp*npix/gpuSec/1e6);
+    delete gpu;
+
+    if (cpuSpp > 0)
+    {
+        Renderer* cpu = CreateCpuRenderer(&scene);
+        cpu->Init(options.width, options.height);
+        auto c0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < cpuSpp; ++i)        // main.cpp:246-250
+            cpu->Render(camera, options, &cpuPixels[0]);
+        auto c1 = std::chrono::steady_clock::now();
+        const double cpuSec = std::chrono::duration<double>(c1 - c0).count();
+        printf("cpu: %d spp in %.4f s (%.3f Msamples/s, 1 thread)\n", cpuSpp, cpuSec, cpuSpp*npix/cpuSec/1e6);
+        delete cpu;
+
+        double sum = 0.0, meanG = 0.0, meanC = 0.0;
+        for (size_t i = 0; i < npix; ++i)
+        {
+            const Color g = gpuPixels[i], c = cpuPixels[i];
+            const float gw = g.w > 0.0f ? 1.0f/g.w : 0.0f, cw = c.w > 0.0f ? 1.0f/c.w : 0.0f;     // main.cpp:268
+            const float dx = g.x*gw - c.x*cw, dy = g.y*gw - c.y*cw, dz = g.z*gw - c.z*cw;
+            sum += dx*dx + dy*dy + dz*dz;
+            meanG += (g.x + g.y + g.z)*gw/3.0;
+            meanC += (c.x + c.y + c.z)*cw/3.0;
+        }
+        printf("mean radiance gpu %.5f cpu %.5f ; per-pixel L2 between the two estimates %.4e (independent RNG streams)\n",
+               meanG/npix, meanC/npix, std::sqrt(sum/npix));
+    }
+
+    if (out)
+    {
+        PfmImage img;
+        img.width = options.width;
+        img.height = options.height;
+        img.depth = 1;
+        std::vector<float> rgb(npix*3);
+        for (size_t i = 0; i < npix; ++i)
+        {
+            const float s = gpuPixels[i].w > 0.0f ? options.exposure/gpuPixels[i].w : 0.0f;
+            rgb[i*3 + 0] = gpuPixels[i].x*s; rgb[i*3 + 1] = gpuPixels[i].y*s; rgb[i*3 + 2] = gpuPixels[i].z*s;
+        }
+        img.data = &rgb[0];
+        PfmSave(out, img);
+        printf("wrote %s\n", out);
+    }
+    return 0;
+}

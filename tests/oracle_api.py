@@ -232,6 +232,12 @@ class PortOracle(_OracleBase):
     def __init__(self):
         super().__init__(PORT_SO)
         L = self.lib
+        L.port_render_sharded.restype = C.c_double
+        L.port_render_sharded.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Options), C.c_uint32,
+                                          C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.port_render_normals.restype = None
+        L.port_render_normals.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Options), C.c_void_p]
         L.port_render_seeded_counts.restype = C.c_double
         L.port_render_seeded_counts.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Options), C.c_uint32,
                                                 C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -249,6 +255,28 @@ class PortOracle(_OracleBase):
                                                   _fp(accum), None, threads, _fp(counts))
         names = ["rays", "samples", "internal_visits", "tri_tests", "prim_tests", "shadow_rays", "node_fetches", "_"]
         return accum, dict(zip(names, (int(c) for c in counts))), secs
+
+
+def _port_extra():
+    def render_sharded(self, h, cam, opt, rank, world, tile=32, pass_begin=0, passes=1, threads=0):
+        if threads <= 0:
+            threads = os.cpu_count() or 1
+        accum = np.zeros((opt.height, opt.width, 4), np.float32)
+        counts = np.zeros(8, np.uint64)
+        self.lib.port_render_sharded(h, C.byref(cam), C.byref(opt), pass_begin, passes, 0, 0, 0, 0, _fp(accum), None,
+                                     threads, rank, world, tile, _fp(counts))
+        return accum, int(counts[1])
+
+    def render_normals(self, h, cam, opt):
+        out = np.zeros((opt.height, opt.width, 4), np.float32)
+        self.lib.port_render_normals(h, C.byref(cam), C.byref(opt), _fp(out))
+        return out
+
+    PortOracle.render_sharded = render_sharded
+    PortOracle.render_normals = render_normals
+
+
+_port_extra()
 
 
 def image_l2(a, b):

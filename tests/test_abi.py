@@ -1,0 +1,107 @@
+"""CPU tests of the drop-in boundary (run with -m "not gpu"): the C-ABI library loads, exports every
+symbol include/tinsel_hip.h declares, mirrors the reference PODs byte for byte, opens scene packs on
+the host, and FAILS LOUDLY (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import tinsel_amd
+from tinsel_amd import abi
+from tinsel_amd.renderer import EXPORTED_SYMBOLS, LIB_PATH
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "tinsel_hip.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tinsel_(?:hip|pack)_\w+)\s*\(", text)))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(LIB_PATH), "run `python -m tinsel_amd.build` (hipcc --offload-arch=gfx950)"
+    assert os.path.dirname(LIB_PATH) == os.path.join(ROOT, "tinsel_amd")
+
+
+def test_every_declared_symbol_is_exported():
+    L = tinsel_amd.load_library()
+    declared = _declared()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), "include/tinsel_hip.h declares %s but the library does not export it" % name
+    # and the python mirror binds exactly the declared set
+    assert sorted(EXPORTED_SYMBOLS) == declared
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(LIB_PATH, "rb").read()
+    assert b"gfx950" in blob, "no gfx950 code object embedded"
+
+
+def test_pod_mirrors_match_reference_layouts():
+    # sizes / offsets probed from the reference with g++
+    assert C.sizeof(abi.Vec3) == 12 and C.sizeof(abi.Vec4) == 16
+    assert C.sizeof(abi.Transform) == 32 and C.sizeof(abi.BVHNode) == 32
+    assert C.sizeof(abi.Material) == 128 and abi.Material.eta.offset == 36 and abi.Material.transmission.offset == 80
+    assert abi.Material.bump_map.offset == 88 and abi.Material.bump.offset == 112 and abi.Material.bump_tile.offset == 116
+    assert C.sizeof(abi.MeshGeometry) == 64 and abi.MeshGeometry.num_vertices.offset == 40 and abi.MeshGeometry.id.offset == 56
+    assert C.sizeof(abi.Primitive) == 272 and abi.Primitive.type.offset == 64 and abi.Primitive.geo.offset == 72
+    assert abi.Primitive.material.offset == 136 and abi.Primitive.light_samples.offset == 264
+    assert C.sizeof(abi.Camera) == 40 and C.sizeof(abi.Filter) == 16 and C.sizeof(abi.Options) == 48
+    assert abi.Options.filter.offset == 12 and abi.Options.exposure.offset == 28 and abi.Options.max_depth.offset == 40
+
+
+@pytest.mark.parametrize("name,nprims,nmesh", [("cornell", 8, 1), ("veach", 9, 1), ("glass", 9, 3), ("features_probe", 9, 2)])
+def test_pack_open_on_host(golden_dir, name, nprims, nmesh):
+    scene = tinsel_amd.Scene.load_pack(os.path.join(golden_dir, name + ".pack"))
+    d = scene.desc
+    assert d.num_primitives == nprims and d.num_bvh_nodes == 2*nprims - 1
+    prims = C.cast(d.primitives, C.POINTER(abi.Primitive))
+    ids = set()
+    for i in range(nprims):
+        p = prims[i]
+        assert p.type in (abi.GEOM_SPHERE, abi.GEOM_PLANE, abi.GEOM_MESH)
+        if p.type == abi.GEOM_MESH:
+            g = p.geo.mesh
+            ids.add(g.id)
+            assert g.num_indices % 3 == 0 and g.num_nodes == 2*(g.num_indices//3) - 1
+            # pointers were relocated into the blob and are readable
+            idx = np.ctypeslib.as_array(C.cast(g.indices, C.POINTER(C.c_int32)), (g.num_indices,))
+            assert idx.min() >= 0 and idx.max() < g.num_vertices
+            cdf = np.ctypeslib.as_array(C.cast(g.cdf, C.POINTER(C.c_float)), (g.num_indices//3,))
+            assert np.all(np.diff(cdf) >= 0) and abs(cdf[-1] - 1.0) < 1e-5
+    assert len(ids) == nmesh
+    assert bool(d.probe_valid) == name.endswith("probe")
+    assert scene.options.width > 0 and scene.options.max_depth > 0
+
+
+def test_pack_open_rejects_garbage():
+    with pytest.raises(tinsel_amd.TinselHipError):
+        tinsel_amd.Scene(b"\0" * 512)
+    good = open(os.path.join(ROOT, "tests", "golden", "cornell.pack"), "rb").read()
+    with pytest.raises(tinsel_amd.TinselHipError):
+        tinsel_amd.Scene(good[:300])
+
+
+def test_no_cpu_fallback(golden_dir):
+    """Without a visible GPU the constructor must raise; nothing renders on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    scene = tinsel_amd.Scene.load_pack(os.path.join(golden_dir, "cornell.pack"))
+    with pytest.raises(tinsel_amd.TinselHipError, match="no HIP device|no CPU fallback"):
+        tinsel_amd.create_gpu_renderer(scene)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tinsel_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_api" not in text and "libtinsel_oracle" not in text and "libtinsel_ref" not in text, f
+                assert not re.search(r'#include\s+"[^"]*oracle', text), f

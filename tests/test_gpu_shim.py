@@ -1,0 +1,25 @@
+"""Drop-in check on the GPU box: the reference's OWN loader / Scene::Build / Renderer interface driving
+CreateGpuRenderer() through shim/hip_renderer.cpp (binary built where the reference is mounted)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "shim", "_build", "tinsel_headless")
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="shim/_build/tinsel_headless not built (needs /root/reference)")
+def test_reference_main_loop_drives_the_hip_backend():
+    scene = os.path.join(ROOT, "tests", "golden", "scenes", "features.tin")
+    out = subprocess.run([EXE, scene, "-spp=256", "-cpuspp=64", "-width=96", "-height=64"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"mean radiance gpu ([\d.]+) cpu ([\d.]+) ; per-pixel L2 between the two estimates ([\d.e+-]+)", out.stdout)
+    assert m, out.stdout
+    gpu, cpu, l2 = float(m.group(1)), float(m.group(2)), float(m.group(3))
+    # two independent Monte-Carlo estimates of the same image (different RNG streams): means agree to ~1 %
+    assert abs(gpu/cpu - 1) < 0.03, out.stdout
+    assert l2 < 0.5
