@@ -201,9 +201,19 @@ def main():
     gpu_ms = sum(v[1] for v in ktimes.values())
     job_bytes = st["rays"]*B_ray + st["samples"]*B_fb
 
+    # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; see the file's own note), same workload
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.scene)
+    if os.path.exists(tpath) and (args.width, args.height) == (1024, 1024):
+        try:
+            traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": traffic,
         "kernel": dom_name, "launches": dom_launches, "avg_launch_ms": dom_ms/max(1, dom_launches),
         "B_ray": B_ray, "I": I_bar, "T": T_bar, "P": P_bar, "B_fb": B_fb,
         "job_algorithmic_GBs": job_bytes/(gpu_ms*1e-3)/1e9 if gpu_ms > 0 else 0.0,
