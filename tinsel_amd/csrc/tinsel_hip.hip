@@ -162,6 +162,8 @@ void make_material(const tinsel_primitive& p, Mat128& m)
 
     // Lerp(.1,.001, clearcoatGloss) evaluated in double (disney.h:387)
     m.clearcoatAlpha = (float)(.1 + (.001 - .1)*(double)a.clearcoat_gloss);
+    m.clearcoatA2 = m.clearcoatAlpha*m.clearcoatAlpha;     // GTR1: a2 = a*a; logf(a2) by the host libm = the oracle's own
+    m.clearcoatLogA2 = logf(m.clearcoatA2);
 
     // PrimitiveArea (intersection.h:833-853)
     if (p.type == TINSEL_GEOM_SPHERE)
@@ -184,6 +186,24 @@ Xform to_xform(const tinsel_transform& t)
 }
 
 // ---------------------------------------------------------------------------
+
+// Host-side image of DevScene::arena: 128-B aligned sections, uploaded as one allocation.
+struct ArenaBuilder
+{
+    std::vector<unsigned char> bytes;
+    template <class T>
+    size_t add(const T* data, size_t count)
+    {
+        const size_t off = (bytes.size() + 127) & ~size_t(127);
+        bytes.resize(off + sizeof(T)*count, 0);
+        if (count)
+            memcpy(&bytes[off], data, sizeof(T)*count);
+        return off;
+    }
+};
+
+constexpr size_t kSmallMeshBytes = 4096;        // meshes up to this size ride inside the arena
+constexpr size_t kArenaLdsLimit = 32768;        // arenas up to this size are staged into LDS by the kernels
 
 struct DeviceArena
 {
@@ -412,30 +432,30 @@ int pick_stack(int need)
     return -1;
 }
 
-size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + kScanWords)*sizeof(uint32_t); }
+size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes; }
 
 void launch_extend(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
 {
     if (r->countDetail)
-        hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce);
+        hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
     else
-        hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce);
+        hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
 }
 
 void launch_shadow(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
 {
     if (r->countDetail)
-        hipLaunchKernelGGL((k_shadow<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce);
+        hipLaunchKernelGGL((k_shadow<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
     else
-        hipLaunchKernelGGL((k_shadow<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce);
+        hipLaunchKernelGGL((k_shadow<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
 }
 
 void launch_mega(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
 {
     if (r->countDetail)
-        hipLaunchKernelGGL((k_mega<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev);
+        hipLaunchKernelGGL((k_mega<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev, r->stackNeed);
     else
-        hipLaunchKernelGGL((k_mega<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev);
+        hipLaunchKernelGGL((k_mega<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev, r->stackNeed);
 }
 
 void launch_bounce(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, const CameraParams& cam, const FrameParams& fp)
@@ -459,7 +479,7 @@ void launch_bounce(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin,
 
 void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
 {
-    hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum);
+    hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum, r->stackNeed);
 }
 
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp)
@@ -500,7 +520,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             }
             {
                 ScopedTimer t(r, KN_SHADE, st);
-                hipLaunchKernelGGL(k_shade, dim3(gridPersist), dim3(kBlock), 0, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, fp.maxDepth);
+                hipLaunchKernelGGL(k_shade, dim3(gridPersist), dim3(kBlock), r->scene.arenaLdsBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, fp.maxDepth);
             }
             if (r->neePerPath > 0)
             {
@@ -661,6 +681,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
     std::vector<DevMesh> meshes;
     std::vector<int32_t> lights;
     std::map<uint64_t, uint32_t> meshIndex;     // MeshGeometry::id (util.h:20) -> DevScene::meshes index
+    ArenaBuilder arena;
     int maxMeshNeed = 0;
     int totalLightSamples = 0;
 
@@ -762,18 +783,31 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
 
                 DevMesh dm;
                 memset(&dm, 0, sizeof(dm));
-                dm.nodes = r->sceneMem.upload(cb.nodes.data(), cb.nodes.size());
-                dm.tris = r->sceneMem.upload(tris.data(), tris.size());
-                dm.normals = r->sceneMem.upload(&g.normals[0].x, (size_t)g.num_vertices*3);
-                dm.cdf = r->sceneMem.upload(g.cdf, (size_t)numTris);
                 dm.root = cb.root;
                 dm.numTris = numTris;
                 dm.stackNeed = cb.maxLeafDepth + 1;
-                if ((!cb.nodes.empty() && !dm.nodes) || !dm.tris || !dm.normals || !dm.cdf)
+                const size_t meshBytes = cb.nodes.size()*sizeof(Node64) + tris.size()*sizeof(Tri48) + (size_t)g.num_vertices*12 + (size_t)numTris*4;
+                if (meshBytes <= kSmallMeshBytes)
                 {
-                    fail("create: device allocation failed (mesh)");
-                    ok = false;
-                    break;
+                    // offsets for now; turned into pointers once the arena has its device address
+                    dm.inArena = 1;
+                    dm.nodes = (const Node64*)arena.add(cb.nodes.data(), cb.nodes.size());
+                    dm.tris = (const Tri48*)arena.add(tris.data(), tris.size());
+                    dm.normals = (const float*)arena.add(&g.normals[0].x, (size_t)g.num_vertices*3);
+                    dm.cdf = (const float*)arena.add(g.cdf, (size_t)numTris);
+                }
+                else
+                {
+                    dm.nodes = r->sceneMem.upload(cb.nodes.data(), cb.nodes.size());
+                    dm.tris = r->sceneMem.upload(tris.data(), tris.size());
+                    dm.normals = r->sceneMem.upload(&g.normals[0].x, (size_t)g.num_vertices*3);
+                    dm.cdf = r->sceneMem.upload(g.cdf, (size_t)numTris);
+                    if ((!cb.nodes.empty() && !dm.nodes) || !dm.tris || !dm.normals || !dm.cdf)
+                    {
+                        fail("create: device allocation failed (mesh)");
+                        ok = false;
+                        break;
+                    }
                 }
                 if (dm.stackNeed > maxMeshNeed)
                     maxMeshNeed = dm.stackNeed;
@@ -809,24 +843,57 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
 
     if (ok)
     {
-        sc.nodes = r->sceneMem.upload(sceneBvh.nodes.data(), sceneBvh.nodes.size());
+        // one contiguous arena: scene BVH, Prim64, Mat128, moving poses, lights, mesh table (+ small meshes, added above)
+        const size_t offNodes = arena.add(sceneBvh.nodes.data(), sceneBvh.nodes.size());
+        const size_t offPrims = arena.add(prims.data(), prims.size());
+        const size_t offMats = arena.add(mats.data(), mats.size());
+        const size_t offMoving = arena.add(moving.data(), moving.size());
+        const size_t offLights = arena.add(lights.data(), lights.size());
+        const size_t offMeshes = arena.add(meshes.data(), meshes.size());
+        arena.bytes.resize((arena.bytes.size() + 127) & ~size_t(127), 0);
+
+        unsigned char* arenaDev = r->sceneMem.upload(arena.bytes.data(), arena.bytes.size());
+        if (arenaDev)
+        {
+            // small meshes: offsets -> device pointers, in the host image of the mesh table, then upload once more
+            DevMesh* hm = reinterpret_cast<DevMesh*>(&arena.bytes[offMeshes]);
+            for (size_t m = 0; m < meshes.size(); ++m)
+            {
+                if (hm[m].inArena)
+                {
+                    hm[m].nodes = reinterpret_cast<const Node64*>(arenaDev + (size_t)hm[m].nodes);
+                    hm[m].tris = reinterpret_cast<const Tri48*>(arenaDev + (size_t)hm[m].tris);
+                    hm[m].normals = reinterpret_cast<const float*>(arenaDev + (size_t)hm[m].normals);
+                    hm[m].cdf = reinterpret_cast<const float*>(arenaDev + (size_t)hm[m].cdf);
+                }
+            }
+            if (!meshes.empty() && hipMemcpy(arenaDev + offMeshes, hm, sizeof(DevMesh)*meshes.size(), hipMemcpyHostToDevice) != hipSuccess)
+                arenaDev = nullptr;
+        }
+        if (!arenaDev)
+        {
+            fail("create: device allocation failed (scene arena)");
+            ok = false;
+        }
+        else
+        {
+            sc.arena = arenaDev;
+            sc.arenaBytes = (uint32_t)arena.bytes.size();
+            sc.arenaLdsBytes = (arena.bytes.size() <= kArenaLdsLimit && !getenv("TINSEL_HIP_NO_LDS_SCENE")) ? sc.arenaBytes : 0u;
+            sc.nodes = reinterpret_cast<const Node64*>(arenaDev + offNodes);
+            sc.prims = reinterpret_cast<const Prim64*>(arenaDev + offPrims);
+            sc.mats = reinterpret_cast<const Mat128*>(arenaDev + offMats);
+            sc.moving = reinterpret_cast<const Moving64*>(arenaDev + offMoving);
+            sc.lights = reinterpret_cast<const int32_t*>(arenaDev + offLights);
+            sc.meshes = reinterpret_cast<const DevMesh*>(arenaDev + offMeshes);
+            sc.numMeshes = (int)meshes.size();
+        }
         sc.root = sceneBvh.root;
-        sc.prims = r->sceneMem.upload(prims.data(), prims.size());
-        sc.mats = r->sceneMem.upload(mats.data(), mats.size());
-        sc.moving = r->sceneMem.upload(moving.data(), moving.size());
-        sc.meshes = r->sceneMem.upload(meshes.data(), meshes.size());
-        sc.lights = r->sceneMem.upload(lights.data(), lights.size());
         sc.numPrims = P;
         sc.numLights = (int)lights.size();
         sc.horizon[0] = desc->sky_horizon.x; sc.horizon[1] = desc->sky_horizon.y; sc.horizon[2] = desc->sky_horizon.z;
         sc.zenith[0] = desc->sky_zenith.x; sc.zenith[1] = desc->sky_zenith.y; sc.zenith[2] = desc->sky_zenith.z;
 
-        if ((!sceneBvh.nodes.empty() && !sc.nodes) || !sc.prims || !sc.mats || (!moving.empty() && !sc.moving) ||
-            (!meshes.empty() && !sc.meshes) || (!lights.empty() && !sc.lights))
-        {
-            fail("create: device allocation failed (scene)");
-            ok = false;
-        }
     }
 
     if (ok && desc->probe_valid)

@@ -13,14 +13,14 @@ enum BsdfType : int { kReflected = 0, kTransmitted = 1, kSpecular = 2 };   // di
 struct Mat
 {
     V3 emission, color, absorption, cspec0, sqrtColor;
-    float ior, metallic, subsurface, roughness, transmission, clearcoat, clearcoatAlpha, area;
+    float ior, metallic, subsurface, roughness, transmission, clearcoat, clearcoatAlpha, clearcoatA2, clearcoatLogA2, area;
     int lightSamples;
 };
 
 TN_D Mat load_mat(const Mat128* mats, int idx)
 {
     const float4* p = reinterpret_cast<const float4*>(mats + idx);
-    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5];
+    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6];
     Mat m;
     m.emission = V3(a.x, a.y, a.z); m.ior = a.w;
     m.color = V3(b.x, b.y, b.z); m.metallic = b.w;
@@ -28,6 +28,7 @@ TN_D Mat load_mat(const Mat128* mats, int idx)
     m.cspec0 = V3(d.x, d.y, d.z); m.roughness = d.w;
     m.sqrtColor = V3(e.x, e.y, e.z); m.transmission = e.w;
     m.clearcoat = f.x; m.clearcoatAlpha = f.y; m.area = f.z; m.lightSamples = __float_as_int(f.w);
+    m.clearcoatA2 = g.x; m.clearcoatLogA2 = g.y;
     return m;
 }
 
@@ -51,12 +52,13 @@ TN_D float schlick_fresnel(float u)        // disney.h:49-54
     return m2*m2*m;
 }
 
-TN_D float gtr1(float NDotH, float a)      // disney.h:56-62
+// GTR1 (disney.h:56-62).  `a` is a material constant (the clearcoat alpha), so a*a and logf(a*a)
+// are evaluated once on the host -- by glibc's logf, i.e. exactly the oracle's value.
+TN_D float gtr1(float NDotH, float a, float a2, float logA2)
 {
     if (a >= 1) return kInvPi;
-    float a2 = a*a;
     float t = 1 + (a2 - 1)*NDotH*NDotH;
-    return (a2 - 1)/(kPi*m_logf(a2)*t);
+    return (a2 - 1)/(kPi*logA2*t);
 }
 
 TN_D float gtr2(float NDotH, float a)      // disney.h:64-69
@@ -116,8 +118,8 @@ TN_D V3 sample_ggx_reflection(const Mat& mat, V3 U, V3 Vt, V3 N, V3 view, float 
     const float phiHalf = r1*k2Pi;
     const float cosThetaHalf = sqrtf((1.0f - r2)/(1.0f + (sqr(a) - 1.0f)*r2));
     const float sinThetaHalf = sqrtf(maxT(0.0f, 1.0f - sqr(cosThetaHalf)));
-    const float sinPhiHalf = m_sinf(phiHalf);
-    const float cosPhiHalf = m_cosf(phiHalf);
+    float sinPhiHalf, cosPhiHalf;
+    m_sincosf(phiHalf, sinPhiHalf, cosPhiHalf);
 
     V3 half = U*(sinThetaHalf*cosPhiHalf) + Vt*(sinThetaHalf*sinPhiHalf) + N*cosThetaHalf;
     if (dot(half, view) <= 0.0f)
@@ -126,60 +128,66 @@ TN_D V3 sample_ggx_reflection(const Mat& mat, V3 U, V3 Vt, V3 N, V3 view, float 
     return 2.0f*dot(view, half)*half - view;
 }
 
-// BSDFSample (disney.h:170-293)
+// BSDFSample (disney.h:170-293).  Same random-number draws in the same order and the same
+// arithmetic; the three lobe samplers are each written ONCE after the lobe choice so that lanes
+// which picked the same lobe through different branches (GGX via the Fresnel branch or via the
+// 50/50 BRDF branch) execute it together.
 TN_D void bsdf_sample(const Mat& mat, float etaI, float etaO, V3 U, V3 Vt, V3 N, V3 view, V3& light, float& pdf, int& type, Rng& rng)
 {
+    enum { kLobeGgx, kLobeCosine, kLobeInside };
+    int lobe = kLobeGgx;
+    float r1, r2;
+
     if (rng.randf() < mat.transmission)
     {
         float F = fresnel_dielectric(dot(N, view), etaI, etaO);
         if (rng.randf() < F)
         {
-            float r1 = rng.randf();
-            float r2 = rng.randf();
-            type = kReflected;
-            light = sample_ggx_reflection(mat, U, Vt, N, view, r1, r2);
+            r1 = rng.randf();
+            r2 = rng.randf();
+            lobe = kLobeGgx;                    // disney.h:180-205
         }
         else
         {
             float eta = etaI/etaO;
-            if (refract(view, N, eta, light))
+            if (refract(view, N, eta, light))   // disney.h:209-219
             {
                 type = kSpecular;
                 pdf = (1.0f - F)*mat.transmission;
-                return;
             }
             else
             {
                 pdf = 0.0f;
-                return;
             }
+            return;
         }
     }
     else
     {
-        float r1 = rng.randf();
-        float r2 = rng.randf();
-
+        r1 = rng.randf();
+        r2 = rng.randf();
         if (rng.randf() < 0.5f)
-        {
-            if (rng.randf() < mat.subsurface)
-            {
-                const V3 d = uniform_sample_hemisphere(rng);
-                light = U*d.x + Vt*d.y - N*d.z;
-                type = kTransmitted;
-            }
-            else
-            {
-                const V3 d = cosine_sample_hemisphere(r1, r2);
-                light = U*d.x + Vt*d.y + N*d.z;
-                type = kReflected;
-            }
-        }
+            lobe = (rng.randf() < mat.subsurface) ? kLobeInside : kLobeCosine;      // disney.h:243-261
         else
-        {
-            light = sample_ggx_reflection(mat, U, Vt, N, view, r1, r2);
-            type = kReflected;
-        }
+            lobe = kLobeGgx;                                                         // disney.h:264-287
+    }
+
+    if (lobe == kLobeGgx)
+    {
+        light = sample_ggx_reflection(mat, U, Vt, N, view, r1, r2);
+        type = kReflected;
+    }
+    else if (lobe == kLobeCosine)
+    {
+        const V3 d = cosine_sample_hemisphere(r1, r2);
+        light = U*d.x + Vt*d.y + N*d.z;
+        type = kReflected;
+    }
+    else
+    {
+        const V3 d = uniform_sample_hemisphere(rng);
+        light = U*d.x + Vt*d.y - N*d.z;
+        type = kTransmitted;
     }
 
     pdf = bsdf_pdf(mat, etaI, etaO, N, view, light);
@@ -246,7 +254,7 @@ TN_D V3 bsdf_eval(const Mat& mat, float etaI, float etaO, V3 N, V3 V, V3 L)
             float Fd90 = 0.5f + 2.0f*LDotH*LDotH*mat.roughness;
             float Fd = lerpf(1.0f, Fd90, FL)*lerpf(1.0f, Fd90, FV);
 
-            float Dr = gtr1(NDotH, mat.clearcoatAlpha);
+            float Dr = gtr1(NDotH, mat.clearcoatAlpha, mat.clearcoatA2, mat.clearcoatLogA2);
             float Fc = lerpf(.04f, 1.0f, FH);
             float Gr = smith_ggx(NDotL, .25f)*smith_ggx(NDotV, .25f);
 

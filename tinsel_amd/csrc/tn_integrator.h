@@ -72,8 +72,12 @@ TN_D void on_hit_begin(PathRegs& p, const Mat& mat, float t, V3 n, int bounce, H
     h.etaI = p.eta;
 
     // pathThroughput *= Exp(-rayAbsorption*t)   (render.cpp:272, maths.h:253)
-    V3 a = (-p.absorption)*t;
-    p.thr = p.thr*V3(m_expf(a.x), m_expf(a.y), m_expf(a.z));
+    // exp(-0*t) == 1 exactly and thr*1 == thr, so the (common) non-absorbing medium skips the three exps
+    if (p.absorption.x != 0.0f || p.absorption.y != 0.0f || p.absorption.z != 0.0f)
+    {
+        V3 a = (-p.absorption)*t;
+        p.thr = p.thr*V3(m_expf(a.x), m_expf(a.y), m_expf(a.z));
+    }
 
     h.p = p.o + p.d*t;
     h.n = n;

@@ -150,6 +150,52 @@ TN_D void wave_add_stat(unsigned long long* stats, int word, uint32_t v)
         atomicAdd(stats + (size_t)(blockIdx.x % kStatShards)*kStatWords + word, (unsigned long long)v);
 }
 
+// Stages the scene arena into LDS (cooperative 16-B copies) and re-points the DevScene at the LDS
+// copy.  The pointers stay generic (flat loads resolve the LDS aperture at run time), so one kernel
+// body serves both the staged and the HBM-resident case; for the config scenes everything a
+// traversal touches except large meshes then has LDS latency instead of an L1/L2 round trip.
+// MUST be reached by every thread of the block.
+TN_D void stage_scene_lds(DevScene& sc, uint32_t* ldsWords)
+{
+    if (sc.arenaLdsBytes == 0)
+        return;
+    unsigned char* lds = reinterpret_cast<unsigned char*>(ldsWords);
+    const float4* src = reinterpret_cast<const float4*>(sc.arena);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    const uint32_t n16 = sc.arenaLdsBytes/16u;
+    for (uint32_t i = threadIdx.x; i < n16; i += kBlock)
+        dst[i] = src[i];
+    __syncthreads();
+
+    // Re-point everything at the LDS copy.  The new pointers are derived FROM the LDS base (base +
+    // byte offset inside the arena), never from the old global pointers: the back-end assumes
+    // kernel-argument pointers are global, and global + delta would be issued as a global load of an
+    // LDS aperture address.
+    const unsigned char* g0 = sc.arena;
+    auto rebase = [&](const void* p) -> const unsigned char* {
+        return lds + (reinterpret_cast<const unsigned char*>(p) - g0);
+    };
+    DevMesh* lm = reinterpret_cast<DevMesh*>(lds + (reinterpret_cast<const unsigned char*>(sc.meshes) - g0));
+    for (int i = threadIdx.x; i < sc.numMeshes; i += kBlock)
+    {
+        if (lm[i].inArena)
+        {
+            lm[i].nodes = reinterpret_cast<const Node64*>(rebase(lm[i].nodes));
+            lm[i].tris = reinterpret_cast<const Tri48*>(rebase(lm[i].tris));
+            lm[i].normals = reinterpret_cast<const float*>(rebase(lm[i].normals));
+            lm[i].cdf = reinterpret_cast<const float*>(rebase(lm[i].cdf));
+        }
+    }
+    __syncthreads();
+
+    sc.nodes = reinterpret_cast<const Node64*>(rebase(sc.nodes));
+    sc.prims = reinterpret_cast<const Prim64*>(rebase(sc.prims));
+    sc.mats = reinterpret_cast<const Mat128*>(rebase(sc.mats));
+    sc.moving = reinterpret_cast<const Moving64*>(rebase(sc.moving));
+    sc.meshes = reinterpret_cast<const DevMesh*>(rebase(sc.meshes));
+    sc.lights = reinterpret_cast<const int32_t*>(rebase(sc.lights));
+}
+
 TN_D bool pixel_owned(const FrameParams& fp, int i, int j)
 {
     if (fp.shardWorld <= 1)
@@ -248,6 +294,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene sc, 
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
 
     uint32_t* s_scan = s_stack + stackEntries*kBlock;
+    stage_scene_lds(sc, s_scan + kScanWords);
 
     const uint32_t count = FIRST ? (uint32_t)(fp.width*fp.height*fp.numPasses) : q.activeCount[bounce];
     const uint32_t rounds = block_rounds(count);
@@ -415,10 +462,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q
 // k_extend: closest hit for every queued path
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce)
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce, int stackEntries)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
+    stage_scene_lds(sc, s_stack + stackEntries*kBlock + kScanWords);
 
     const uint32_t count = q.activeCount[bounce];
     const uint32_t rounds = block_rounds(count);
@@ -483,6 +531,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene sc, P
                                                   uint32_t* __restrict__ queueNext, uint32_t* __restrict__ queueNee, int bounce, int maxDepth)
 {
     __shared__ uint32_t s_scan[kScanWords];
+    extern __shared__ uint32_t s_arena[];
+    stage_scene_lds(sc, s_arena);
     const uint32_t count = q.activeCount[bounce];
     const uint32_t rounds = block_rounds(count);
     const uint32_t first = blockIdx.x*rounds*kBlock;
@@ -570,10 +620,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene sc, P
 // its K shadow rays in the oracle's order, then totalRadiance += pathThroughput*sum (render.cpp:314)
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce)
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce, int stackEntries)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
+    stage_scene_lds(sc, s_stack + stackEntries*kBlock + kScanWords);
 
     const uint32_t count = q.neeCount[bounce];
     const uint32_t rounds = block_rounds(count);
@@ -623,10 +674,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene sc, 
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene sc, PathState ps, QueueCtl q, CameraParams cam, FrameParams fp,
-                                                 const uint32_t* __restrict__ passSeeds)
+                                                 const uint32_t* __restrict__ passSeeds, int stackEntries)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
+    stage_scene_lds(sc, s_stack + stackEntries*kBlock + kScanWords);
 
     const int npix = fp.width*fp.height;
     const int total = npix*fp.numPasses;
@@ -804,10 +856,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FramePar
 // ---------------------------------------------------------------------------
 // k_normals: eNormals mode of the CPU renderer (render.cpp:494-515): x=i, y=j, time 1, overwrite.
 
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_normals(DevScene sc, CameraParams cam, FrameParams fp, float4* __restrict__ accum)
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_normals(DevScene sc, CameraParams cam, FrameParams fp, float4* __restrict__ accum, int stackEntries)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
+    stage_scene_lds(sc, s_stack + stackEntries*kBlock + kScanWords);
 
     const int npix = fp.width*fp.height;
     const int pix = blockIdx.x*kBlock + threadIdx.x;

@@ -79,20 +79,78 @@ TN_HD V3 face_forward(V3 n, V3 v) { return (dot(v, n) < 0.0f) ? -n : n; }
 
 // ---------------------------------------------------------------------------
 // transcendental functions.  The CPU oracle calls glibc's sinf/cosf/expf/logf/acosf/atan2f,
-// which evaluate in double and are correctly rounded in all but a fraction of a percent of
-// cases.  TN_LIBM_DOUBLE (default) does the same on the device: the ocml double routine,
-// rounded once to fp32.  With TN_LIBM_DOUBLE=0 the 1-2 ulp ocml fp32 routines are used.
+// which evaluate in double and are correctly rounded in all but ~1 % of calls.  The device
+// does the same: a DOUBLE evaluation rounded once to fp32 (error ~1e-16 before the rounding, so
+// the fp32 result is the correctly rounded one except within ~1e-9 of a rounding boundary).
+//   * sin/cos: every call site passes an angle in [0, 2*pi] (phi = 2*pi*u, theta = pi*v), so a
+//     quadrant reduction + the fdlibm kernel polynomials on |r| <= pi/4 do both at once;
+//   * exp: Cody-Waite reduction + degree-12 polynomial on |r| <= ln2/2 (0 below -104, inf above 89).
+//   * log/acos/atan2 (GTR1 is precomputed per material; the others are probe-only): ocml double.
+// TN_LIBM_DOUBLE=0 switches everything to the 1-2 ulp ocml fp32 routines (A/B only).
 #ifndef TN_LIBM_DOUBLE
 #define TN_LIBM_DOUBLE 1
 #endif
 #if TN_LIBM_DOUBLE
-TN_D float m_sinf(float x) { return (float)::sin((double)x); }
-TN_D float m_cosf(float x) { return (float)::cos((double)x); }
-TN_D float m_expf(float x) { return (float)::exp((double)x); }
+TN_D void m_sincosf(float xf, float& s, float& c)
+{
+    // |x| <= 2*pi at every call site; the two-term Cody-Waite reduction below stays exact to
+    // ~1e-16 for |x| up to ~1e5, so there is deliberately no slow path (a NaN stays a NaN)
+    const double x = (double)xf;
+    const double kd = ::rint(x*0.63661977236758138);            // 2/pi
+    const int k = (int)kd;
+    double r = ::fma(-kd, 1.5707963267948966, x);               // pi/2 (hi)
+    r = ::fma(-kd, 6.123233995736766e-17, r);                   // pi/2 (lo)
+    const double z = r*r;
+    // fdlibm __kernel_sin / __kernel_cos
+    double ps = ::fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = ::fma(z, ps, 2.75573137070700676789e-06);
+    ps = ::fma(z, ps, -1.98412698298579493134e-04);
+    ps = ::fma(z, ps, 8.33333333332248946124e-03);
+    ps = ::fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = ::fma(z*r, ps, r);
+    double pc = ::fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = ::fma(z, pc, -2.75573143513906633035e-07);
+    pc = ::fma(z, pc, 2.48015872894767294178e-05);
+    pc = ::fma(z, pc, -1.38888888888741095749e-03);
+    pc = ::fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = ::fma(z*z, pc, ::fma(z, -0.5, 1.0));
+    const double sv = (k & 1) ? cr : sr;
+    const double cv = (k & 1) ? sr : cr;
+    s = (float)((k & 2) ? -sv : sv);
+    c = (float)(((k + 1) & 2) ? -cv : cv);
+}
+TN_D float m_sinf(float x) { float s, c; m_sincosf(x, s, c); return s; }
+TN_D float m_cosf(float x) { float s, c; m_sincosf(x, s, c); return c; }
+TN_D float m_expf(float xf)
+{
+    double x = (double)xf;
+    if (!(x > -104.0))
+        return (x != x) ? xf : 0.0f;                            // exp(-104) < half the smallest fp32 denormal
+    x = x > 89.0 ? 89.0 : x;                                    // exp(89) already rounds to +inf in fp32
+    const double kd = ::rint(x*1.4426950408889634);             // log2(e)
+    double r = ::fma(-kd, 6.93147180369123816490e-01, x);       // ln2 (hi)
+    r = ::fma(-kd, 1.90821492927058770002e-10, r);              // ln2 (lo)
+    double p = 2.08767569878680989792e-09;                      // 1/12!
+    p = ::fma(r, p, 2.50521083854417187751e-08);
+    p = ::fma(r, p, 2.75573192239858906526e-07);
+    p = ::fma(r, p, 2.75573192239858906526e-06);
+    p = ::fma(r, p, 2.48015873015873015873e-05);
+    p = ::fma(r, p, 1.98412698412698412698e-04);
+    p = ::fma(r, p, 1.38888888888888888889e-03);
+    p = ::fma(r, p, 8.33333333333333333333e-03);
+    p = ::fma(r, p, 4.16666666666666666667e-02);
+    p = ::fma(r, p, 1.66666666666666666667e-01);
+    p = ::fma(r, p, 0.5);
+    p = ::fma(r, p, 1.0);
+    p = ::fma(r, p, 1.0);
+    const long long bits = ((long long)(int)kd + 1023ll) << 52; // 2^k
+    return (float)(p*__longlong_as_double(bits));
+}
 TN_D float m_logf(float x) { return (float)::log((double)x); }
 TN_D float m_acosf(float x) { return (float)::acos((double)x); }
 TN_D float m_atan2f(float y, float x) { return (float)::atan2((double)y, (double)x); }
 #else
+TN_D void m_sincosf(float x, float& s, float& c) { s = ::sinf(x); c = ::cosf(x); }
 TN_D float m_sinf(float x) { return ::sinf(x); }
 TN_D float m_cosf(float x) { return ::cosf(x); }
 TN_D float m_expf(float x) { return ::expf(x); }
@@ -212,8 +270,10 @@ TN_D V3 uniform_sample_sphere(float u1, float u2)
     float z = 1.f - 2.f*u1;
     float r = sqrtf(maxT(0.f, 1.f - z*z));
     float phi = 2.f*kPi*u2;
-    float x = r*m_cosf(phi);
-    float y = r*m_sinf(phi);
+    float sn, cs;
+    m_sincosf(phi, sn, cs);
+    float x = r*cs;
+    float y = r*sn;
     return V3(x, y, z);
 }
 
@@ -223,8 +283,10 @@ TN_D V3 uniform_sample_hemisphere(Rng& rng)
     float z = rng.randf();
     float w = sqrtf(1.0f - z*z);
     float phi = k2Pi*rng.randf();
-    float x = m_cosf(phi)*w;
-    float y = m_sinf(phi)*w;
+    float sn, cs;
+    m_sincosf(phi, sn, cs);
+    float x = cs*w;
+    float y = sn*w;
     return V3(x, y, z);
 }
 
@@ -233,8 +295,10 @@ TN_D V3 cosine_sample_hemisphere(float u1, float u2)
 {
     float r = sqrtf(u1);
     float theta = k2Pi*u2;
-    float sx = r*m_cosf(theta);
-    float sy = r*m_sinf(theta);
+    float sn, cs;
+    m_sincosf(theta, sn, cs);
+    float sx = r*cs;
+    float sy = r*sn;
     float z = sqrtf(maxT(0.0f, 1.0f - sx*sx - sy*sy));
     return V3(sx, sy, z);
 }

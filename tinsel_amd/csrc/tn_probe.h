@@ -24,9 +24,12 @@ TN_D V3 probe_uv_to_dir(V2 uv)
 {
     float theta = uv.y*kPi;
     float phi = uv.x*2.0f*kPi;
-    float x = -m_sinf(theta)*m_cosf(phi);
-    float y = m_cosf(theta);
-    float z = -m_sinf(theta)*m_sinf(phi);
+    float st, ct, sp, cp;
+    m_sincosf(theta, st, ct);
+    m_sincosf(phi, sp, cp);
+    float x = -st*cp;
+    float y = ct;
+    float z = -st*sp;
     return V3(x, y, z);
 }
 

@@ -86,7 +86,9 @@ struct alignas(128) Mat128
     float clearcoatAlpha;                   // Lerp(.1,.001,clearcoatGloss) (disney.h:387)
     float area;                             // PrimitiveArea (intersection.h:833-853)
     int32_t lightSamples;
-    float pad[8];
+    float clearcoatA2;                      // a*a and logf(a*a) of GTR1 (disney.h:59-61), a = clearcoatAlpha
+    float clearcoatLogA2;
+    float pad[6];
 };
 static_assert(sizeof(Mat128) == 128, "Mat128");
 
@@ -99,7 +101,7 @@ struct DevMesh
     uint32_t root;              // child ref of the root (leaf ref when the mesh has one triangle)
     int32_t numTris;
     int32_t stackNeed;          // worst-case traversal stack entries for this tree
-    int32_t pad;
+    int32_t inArena;            // 1: nodes/tris/normals/cdf live inside DevScene::arena (and follow it into LDS)
 };
 
 struct DevProbe
@@ -129,6 +131,14 @@ struct DevScene
     float horizon[3];
     float zenith[3];
     DevProbe probe;
+    // The scene-level records (BVH, Prim64, Mat128, moving poses, light list, mesh table) and the arrays
+    // of small meshes are ONE contiguous allocation, so a block can stage all of it into LDS with a
+    // single cooperative copy when it is small enough (arenaLdsBytes != 0); see stage_scene_lds().
+    const unsigned char* arena;
+    uint32_t arenaBytes;
+    uint32_t arenaLdsBytes;     // == arenaBytes when the kernels should stage it, else 0
+    int32_t numMeshes;
+    int32_t pad;
 };
 
 } // namespace tn
