@@ -434,52 +434,72 @@ int pick_stack(int need)
 
 size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes; }
 
+// kernel variant selection: COUNT (detail counters on) x LDS (whole scene staged into LDS, compile-time ds_read)
+#define TN_DISPATCH2(KERNEL, COUNTV, LDSV, ...)                                                   \
+    do {                                                                                           \
+        if (COUNTV) { if (LDSV) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__);            \
+                      else hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__); }              \
+        else        { if (LDSV) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__);           \
+                      else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); }             \
+    } while (0)
+
 void launch_extend(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
 {
-    if (r->countDetail)
-        hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
-    else
-        hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
+    TN_DISPATCH2(k_extend, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
 }
 
 void launch_shadow(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
 {
-    if (r->countDetail)
-        hipLaunchKernelGGL((k_shadow<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
-    else
-        hipLaunchKernelGGL((k_shadow<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
+    TN_DISPATCH2(k_shadow, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
 }
 
 void launch_mega(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
 {
+    TN_DISPATCH2(k_mega, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev, r->stackNeed);
+}
+
+template <bool FIRST>
+void launch_bounce_t(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, const CameraParams& cam, const FrameParams& fp)
+{
+    const size_t lds = stack_bytes(r);
     if (r->countDetail)
-        hipLaunchKernelGGL((k_mega<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev, r->stackNeed);
+    {
+        if (r->scene.allInArena)
+            hipLaunchKernelGGL((k_bounce<true, FIRST, true>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
+        else
+            hipLaunchKernelGGL((k_bounce<true, FIRST, false>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
+    }
     else
-        hipLaunchKernelGGL((k_mega<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev, r->stackNeed);
+    {
+        if (r->scene.allInArena)
+            hipLaunchKernelGGL((k_bounce<false, FIRST, true>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
+        else
+            hipLaunchKernelGGL((k_bounce<false, FIRST, false>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
+    }
 }
 
 void launch_bounce(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, const CameraParams& cam, const FrameParams& fp)
 {
-    const size_t lds = stack_bytes(r);
     if (bounce == 0)
-    {
-        if (r->countDetail)
-            hipLaunchKernelGGL((k_bounce<true, true>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
-        else
-            hipLaunchKernelGGL((k_bounce<false, true>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
-    }
+        launch_bounce_t<true>(r, st, grid, qin, qout, bounce, cam, fp);
     else
-    {
-        if (r->countDetail)
-            hipLaunchKernelGGL((k_bounce<true, false>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
-        else
-            hipLaunchKernelGGL((k_bounce<false, false>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
-    }
+        launch_bounce_t<false>(r, st, grid, qin, qout, bounce, cam, fp);
 }
 
 void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
 {
-    hipLaunchKernelGGL(k_normals, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum, r->stackNeed);
+    if (r->scene.allInArena)
+        hipLaunchKernelGGL((k_normals<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum, r->stackNeed);
+    else
+        hipLaunchKernelGGL((k_normals<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum, r->stackNeed);
+}
+
+void launch_shade(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, int maxDepth)
+{
+    if (r->scene.allInArena)
+        hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), r->scene.arenaBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth);
+    else
+        hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), r->scene.arenaLdsBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth);
 }
 
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp)
@@ -520,7 +540,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             }
             {
                 ScopedTimer t(r, KN_SHADE, st);
-                hipLaunchKernelGGL(k_shade, dim3(gridPersist), dim3(kBlock), r->scene.arenaLdsBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, fp.maxDepth);
+                launch_shade(r, st, gridPersist, qin, qout, bounce, fp.maxDepth);
             }
             if (r->neePerPath > 0)
             {
@@ -791,10 +811,10 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 {
                     // offsets for now; turned into pointers once the arena has its device address
                     dm.inArena = 1;
-                    dm.nodes = (const Node64*)arena.add(cb.nodes.data(), cb.nodes.size());
-                    dm.tris = (const Tri48*)arena.add(tris.data(), tris.size());
-                    dm.normals = (const float*)arena.add(&g.normals[0].x, (size_t)g.num_vertices*3);
-                    dm.cdf = (const float*)arena.add(g.cdf, (size_t)numTris);
+                    dm.offNodes = (uint32_t)arena.add(cb.nodes.data(), cb.nodes.size());
+                    dm.offTris = (uint32_t)arena.add(tris.data(), tris.size());
+                    dm.offNormals = (uint32_t)arena.add(&g.normals[0].x, (size_t)g.num_vertices*3);
+                    dm.offCdf = (uint32_t)arena.add(g.cdf, (size_t)numTris);
                 }
                 else
                 {
@@ -861,10 +881,10 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             {
                 if (hm[m].inArena)
                 {
-                    hm[m].nodes = reinterpret_cast<const Node64*>(arenaDev + (size_t)hm[m].nodes);
-                    hm[m].tris = reinterpret_cast<const Tri48*>(arenaDev + (size_t)hm[m].tris);
-                    hm[m].normals = reinterpret_cast<const float*>(arenaDev + (size_t)hm[m].normals);
-                    hm[m].cdf = reinterpret_cast<const float*>(arenaDev + (size_t)hm[m].cdf);
+                    hm[m].nodes = reinterpret_cast<const Node64*>(arenaDev + hm[m].offNodes);
+                    hm[m].tris = reinterpret_cast<const Tri48*>(arenaDev + hm[m].offTris);
+                    hm[m].normals = reinterpret_cast<const float*>(arenaDev + hm[m].offNormals);
+                    hm[m].cdf = reinterpret_cast<const float*>(arenaDev + hm[m].offCdf);
                 }
             }
             if (!meshes.empty() && hipMemcpy(arenaDev + offMeshes, hm, sizeof(DevMesh)*meshes.size(), hipMemcpyHostToDevice) != hipSuccess)
@@ -887,6 +907,10 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             sc.lights = reinterpret_cast<const int32_t*>(arenaDev + offLights);
             sc.meshes = reinterpret_cast<const DevMesh*>(arenaDev + offMeshes);
             sc.numMeshes = (int)meshes.size();
+            bool all = sc.arenaLdsBytes != 0;
+            for (const DevMesh& dmesh : meshes)
+                all = all && dmesh.inArena;
+            sc.allInArena = (all && !getenv("TINSEL_HIP_NO_LDS_TEMPLATE")) ? 1 : 0;
         }
         sc.root = sceneBvh.root;
         sc.numPrims = P;

@@ -121,7 +121,8 @@ struct NeeRec
 };
 
 // PrimitiveSample (intersection.h:855-904) for light `prim`
-TN_D void primitive_sample(const DevScene& sc, int index, float time, V3& pos, V3& normal, Rng& rng)
+template <class SC>
+TN_D void primitive_sample(const SC& sc, int index, float time, V3& pos, V3& normal, Rng& rng)
 {
     const Prim64 p = load_prim(sc.prims, index);
     const Xform x = prim_pose(sc, p, time);
@@ -136,6 +137,7 @@ TN_D void primitive_sample(const DevScene& sc, int index, float time, V3& pos, V
     else if (p.type == kPrimMesh)
     {
         const DevMesh m = sc.meshes[p.mesh];
+        const float* mcdf = mesh_cdf(sc, m);
         float r = rng.randf();
 
         // LowerBound(cdf, cdf+numTris, r) (probe.h:162-183), clamped (intersection.h:880-881)
@@ -143,7 +145,7 @@ TN_D void primitive_sample(const DevScene& sc, int index, float time, V3& pos, V
         while (lo < hi)
         {
             int mid = lo + (hi - lo)/2;
-            if (m.cdf[mid] < r)
+            if (mcdf[mid] < r)
                 lo = mid + 1;
             else
                 hi = mid;
@@ -153,11 +155,11 @@ TN_D void primitive_sample(const DevScene& sc, int index, float time, V3& pos, V
         float u, v;
         uniform_sample_triangle(rng, u, v);
 
-        const float4* tp = reinterpret_cast<const float4*>(m.tris + tri);
+        const float4* tp = reinterpret_cast<const float4*>(mesh_tris(sc, m) + tri);
         float4 ta = tp[0], tb = tp[1], tc = tp[2];
         V3 a(ta.x, ta.y, ta.z), b(tb.x, tb.y, tb.z), c(tc.x, tc.y, tc.z);
         int i0 = __float_as_int(ta.w), i1 = __float_as_int(tb.w), i2 = __float_as_int(tc.w);
-        const float* nr = m.normals;
+        const float* nr = mesh_normals(sc, m);
         V3 n1(nr[i0*3 + 0], nr[i0*3 + 1], nr[i0*3 + 2]);
         V3 n2(nr[i1*3 + 0], nr[i1*3 + 1], nr[i1*3 + 2]);
         V3 n3(nr[i2*3 + 0], nr[i2*3 + 1], nr[i2*3 + 2]);
@@ -169,7 +171,8 @@ TN_D void primitive_sample(const DevScene& sc, int index, float time, V3& pos, V
 }
 
 // render.cpp:158-170 + the BSDF terms of :198-199 (pure functions, hoisted above the trace)
-TN_D void nee_prepare_light(const DevScene& sc, const Mat& surf, const HitCtx& h, float time, int light, Rng& rng, NeeRec& r)
+template <class SC>
+TN_D void nee_prepare_light(const SC& sc, const Mat& surf, const HitCtx& h, float time, int light, Rng& rng, NeeRec& r)
 {
     V3 lightPos, lightNormal;
     primitive_sample(sc, light, time, lightPos, lightNormal, rng);

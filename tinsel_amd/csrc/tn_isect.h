@@ -145,14 +145,14 @@ struct MeshHit
 
 // IntersectRayMesh + MeshQuery (intersection.h:629-749).  `sp` = first free stack slot.
 template <class Stack, bool COUNT>
-TN_D bool ray_mesh(const DevMesh& m, Stack& st, int sp, V3 o, V3 d, MeshHit& hit, TraceCounters& ctr)
+TN_D bool ray_mesh(const Node64* mnodes, const Tri48* mtris, uint32_t mroot, Stack& st, int sp, V3 o, V3 d, MeshHit& hit, TraceCounters& ctr)
 {
     float closestT = kFltMax;
     float tmax = kFltMax;
     V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
 
     const int base = sp;
-    st.set(sp++, m.root);
+    st.set(sp++, mroot);
 
     while (sp > base)
     {
@@ -161,7 +161,7 @@ TN_D bool ray_mesh(const DevMesh& m, Stack& st, int sp, V3 o, V3 d, MeshHit& hit
         if (ref & kLeafBit)
         {
             const int i = (int)(ref & ~kLeafBit);
-            const float4* tp = reinterpret_cast<const float4*>(m.tris + i);
+            const float4* tp = reinterpret_cast<const float4*>(mtris + i);
             float4 ta = tp[0], tb = tp[1], tc = tp[2];
             if (COUNT) ctr.tris++;
 
@@ -181,7 +181,7 @@ TN_D bool ray_mesh(const DevMesh& m, Stack& st, int sp, V3 o, V3 d, MeshHit& hit
         }
         else
         {
-            Node64 nd = load_node(m.nodes, ref);
+            Node64 nd = load_node(mnodes, ref);
             if (COUNT) ctr.internal++;
 
             float tL, tR;
@@ -238,8 +238,8 @@ TN_D Prim64 load_prim(const Prim64* prims, int idx)
 }
 
 // PrimitiveIntersect (intersection.h:951-1020)
-template <class Stack, bool COUNT>
-TN_D bool prim_intersect(const DevScene& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr)
+template <class SC, class Stack, bool COUNT>
+TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr)
 {
     const Prim64 p = load_prim(sc.prims, index);
     if (COUNT) ctr.prims++;
@@ -265,14 +265,15 @@ TN_D bool prim_intersect(const DevScene& sc, int index, Stack& st, int sp, V3 o,
     V3 ld = inv_xform_vector(x, d);
 
     const DevMesh m = sc.meshes[p.mesh];
+    const Tri48* mtris = mesh_tris(sc, m);
     MeshHit h;
-    if (!ray_mesh<Stack, COUNT>(m, st, sp, lo, ld, h, ctr))
+    if (!ray_mesh<Stack, COUNT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, h, ctr))
         return false;
 
     // interpolate vertex normals (intersection.h:996-1012)
-    const float4* tp = reinterpret_cast<const float4*>(m.tris + h.tri);
+    const float4* tp = reinterpret_cast<const float4*>(mtris + h.tri);
     const int i0 = __float_as_int(tp[0].w), i1 = __float_as_int(tp[1].w), i2 = __float_as_int(tp[2].w);
-    const float* nr = m.normals;
+    const float* nr = mesh_normals(sc, m);
     V3 n1(nr[i0*3 + 0], nr[i0*3 + 1], nr[i0*3 + 2]);
     V3 n2(nr[i1*3 + 0], nr[i1*3 + 1], nr[i1*3 + 2]);
     V3 n3(nr[i2*3 + 0], nr[i2*3 + 1], nr[i2*3 + 2]);
@@ -288,8 +289,8 @@ TN_D bool prim_intersect(const DevScene& sc, int index, Stack& st, int sp, V3 o,
 
 // Trace (render.cpp:17-62) over QueryBVH (intersection.h:751-799).
 // Returns the primitive index or -1; outN is already FaceForward(n, -dir) (render.cpp:59).
-template <class Stack, bool COUNT>
-TN_D int trace(const DevScene& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr)
+template <class SC, class Stack, bool COUNT>
+TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr)
 {
     float minT = kFltMax;
     int closest = -1;
@@ -309,7 +310,7 @@ TN_D int trace(const DevScene& sc, Stack& st, V3 o, V3 d, float time, float& out
             float t;
             V3 n;
             const int index = (int)(ref & ~kLeafBit);
-            if (prim_intersect<Stack, COUNT>(sc, index, st, sp, o, d, time, t, n, ctr))
+            if (prim_intersect<SC, Stack, COUNT>(sc, index, st, sp, o, d, time, t, n, ctr))
             {
                 if (t < minT && t > 0.0f)
                 {

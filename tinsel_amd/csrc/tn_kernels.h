@@ -150,50 +150,57 @@ TN_D void wave_add_stat(unsigned long long* stats, int word, uint32_t v)
         atomicAdd(stats + (size_t)(blockIdx.x % kStatShards)*kStatWords + word, (unsigned long long)v);
 }
 
-// Stages the scene arena into LDS (cooperative 16-B copies) and re-points the DevScene at the LDS
-// copy.  The pointers stay generic (flat loads resolve the LDS aperture at run time), so one kernel
-// body serves both the staged and the HBM-resident case; for the config scenes everything a
-// traversal touches except large meshes then has LDS latency instead of an L1/L2 round trip.
+// Stages the scene arena into LDS (cooperative 16-B copies) and re-points the scene at the LDS copy.
+//   SceneT<true>  (host guarantees the arena holds EVERYTHING incl. every mesh and fits): pointers are
+//                 derived unconditionally from the LDS base, so every scene access compiles to ds_read.
+//   SceneT<false> generic pointers: staged only when arenaLdsBytes != 0, reached through flat loads, and
+//                 large meshes stay in HBM.  New pointers are derived FROM the LDS base (base + offset
+//                 inside the arena), never from the old global pointers: the back-end assumes
+//                 kernel-argument pointers are global, and global + delta would be issued as a global
+//                 load of an LDS aperture address.
 // MUST be reached by every thread of the block.
-TN_D void stage_scene_lds(DevScene& sc, uint32_t* ldsWords)
+template <bool LDS>
+TN_D void stage_scene_lds(SceneT<LDS>& sc, const DevScene& in, uint32_t* ldsWords)
 {
-    if (sc.arenaLdsBytes == 0)
-        return;
+    static_cast<DevScene&>(sc) = in;
     unsigned char* lds = reinterpret_cast<unsigned char*>(ldsWords);
-    const float4* src = reinterpret_cast<const float4*>(sc.arena);
+    sc.ldsBase = lds;
+    if (!LDS && in.arenaLdsBytes == 0)
+        return;
+
+    const float4* src = reinterpret_cast<const float4*>(in.arena);
     float4* dst = reinterpret_cast<float4*>(lds);
-    const uint32_t n16 = sc.arenaLdsBytes/16u;
+    const uint32_t n16 = (LDS ? in.arenaBytes : in.arenaLdsBytes)/16u;
     for (uint32_t i = threadIdx.x; i < n16; i += kBlock)
         dst[i] = src[i];
     __syncthreads();
 
-    // Re-point everything at the LDS copy.  The new pointers are derived FROM the LDS base (base +
-    // byte offset inside the arena), never from the old global pointers: the back-end assumes
-    // kernel-argument pointers are global, and global + delta would be issued as a global load of an
-    // LDS aperture address.
-    const unsigned char* g0 = sc.arena;
+    const unsigned char* g0 = in.arena;
     auto rebase = [&](const void* p) -> const unsigned char* {
         return lds + (reinterpret_cast<const unsigned char*>(p) - g0);
     };
-    DevMesh* lm = reinterpret_cast<DevMesh*>(lds + (reinterpret_cast<const unsigned char*>(sc.meshes) - g0));
-    for (int i = threadIdx.x; i < sc.numMeshes; i += kBlock)
+    if (!LDS)
     {
-        if (lm[i].inArena)
+        DevMesh* lm = reinterpret_cast<DevMesh*>(lds + (reinterpret_cast<const unsigned char*>(in.meshes) - g0));
+        for (int i = threadIdx.x; i < in.numMeshes; i += kBlock)
         {
-            lm[i].nodes = reinterpret_cast<const Node64*>(rebase(lm[i].nodes));
-            lm[i].tris = reinterpret_cast<const Tri48*>(rebase(lm[i].tris));
-            lm[i].normals = reinterpret_cast<const float*>(rebase(lm[i].normals));
-            lm[i].cdf = reinterpret_cast<const float*>(rebase(lm[i].cdf));
+            if (lm[i].inArena)
+            {
+                lm[i].nodes = reinterpret_cast<const Node64*>(lds + lm[i].offNodes);
+                lm[i].tris = reinterpret_cast<const Tri48*>(lds + lm[i].offTris);
+                lm[i].normals = reinterpret_cast<const float*>(lds + lm[i].offNormals);
+                lm[i].cdf = reinterpret_cast<const float*>(lds + lm[i].offCdf);
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
-    sc.nodes = reinterpret_cast<const Node64*>(rebase(sc.nodes));
-    sc.prims = reinterpret_cast<const Prim64*>(rebase(sc.prims));
-    sc.mats = reinterpret_cast<const Mat128*>(rebase(sc.mats));
-    sc.moving = reinterpret_cast<const Moving64*>(rebase(sc.moving));
-    sc.meshes = reinterpret_cast<const DevMesh*>(rebase(sc.meshes));
-    sc.lights = reinterpret_cast<const int32_t*>(rebase(sc.lights));
+    sc.nodes = reinterpret_cast<const Node64*>(rebase(in.nodes));
+    sc.prims = reinterpret_cast<const Prim64*>(rebase(in.prims));
+    sc.mats = reinterpret_cast<const Mat128*>(rebase(in.mats));
+    sc.moving = reinterpret_cast<const Moving64*>(rebase(in.moving));
+    sc.meshes = reinterpret_cast<const DevMesh*>(rebase(in.meshes));
+    sc.lights = reinterpret_cast<const int32_t*>(rebase(in.lights));
 }
 
 TN_D bool pixel_owned(const FrameParams& fp, int i, int j)
@@ -285,8 +292,8 @@ TN_D bool begin_path(const CameraParams& cam, const FrameParams& fp, const uint3
 // 96-B state back and appends it to queue[bounce+1].  Lanes are therefore always full at the
 // start of a bounce, and a path costs one state read + one state write per bounce.
 
-template <bool COUNT, bool FIRST>
-__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueIn,
+template <bool COUNT, bool FIRST, bool LDS>
+__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueIn,
                                                    uint32_t* __restrict__ queueOut, int bounce, int stackEntries, CameraParams cam,
                                                    FrameParams fp, const uint32_t* __restrict__ passSeeds)
 {
@@ -294,7 +301,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene sc, 
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
 
     uint32_t* s_scan = s_stack + stackEntries*kBlock;
-    stage_scene_lds(sc, s_scan + kScanWords);
+    SceneT<LDS> sc;
+    stage_scene_lds(sc, scIn, s_scan + kScanWords);
 
     const uint32_t count = FIRST ? (uint32_t)(fp.width*fp.height*fp.numPasses) : q.activeCount[bounce];
     const uint32_t rounds = block_rounds(count);
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene sc, 
 
             float t;
             V3 n;
-            const int prim = trace<LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n, ctr);
+            const int prim = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n, ctr);
             rays++;
 
             bool alive = false;
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene sc, 
                         }
                         float ts;
                         V3 nn;
-                        const int hp = trace<LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, p.time, ts, nn, ctr);
+                        const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, p.time, ts, nn, ctr);
                         rays++;
                         shadowRays++;
                         if (r.dist < 0.0f)
@@ -461,12 +469,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q
 // ---------------------------------------------------------------------------
 // k_extend: closest hit for every queued path
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce, int stackEntries)
+template <bool COUNT, bool LDS>
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce, int stackEntries)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
-    stage_scene_lds(sc, s_stack + stackEntries*kBlock + kScanWords);
+    SceneT<LDS> sc;
+    stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
     const uint32_t count = q.activeCount[bounce];
     const uint32_t rounds = block_rounds(count);
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene sc, 
 
             float t;
             V3 n;
-            const int prim = trace<LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, n, ctr);
+            const int prim = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, n, ctr);
 
             ps.hit[slot] = make_float4(t, n.x, n.y, n.z);
             ps.hitPrim[slot] = prim;
@@ -527,12 +536,14 @@ TN_D NeeRec load_nee(const PathState& ps, uint32_t slot, int k)
     return r;
 }
 
-__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue,
+template <bool LDS>
+__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ queueNext, uint32_t* __restrict__ queueNee, int bounce, int maxDepth)
 {
     __shared__ uint32_t s_scan[kScanWords];
     extern __shared__ uint32_t s_arena[];
-    stage_scene_lds(sc, s_arena);
+    SceneT<LDS> sc;
+    stage_scene_lds(sc, scIn, s_arena);
     const uint32_t count = q.activeCount[bounce];
     const uint32_t rounds = block_rounds(count);
     const uint32_t first = blockIdx.x*rounds*kBlock;
@@ -619,12 +630,13 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene sc, P
 // k_shadow: SampleLights, part 2 (render.cpp:118-139, 171-224): one thread per path resolves
 // its K shadow rays in the oracle's order, then totalRadiance += pathThroughput*sum (render.cpp:314)
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene sc, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce, int stackEntries)
+template <bool COUNT, bool LDS>
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce, int stackEntries)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
-    stage_scene_lds(sc, s_stack + stackEntries*kBlock + kScanWords);
+    SceneT<LDS> sc;
+    stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
     const uint32_t count = q.neeCount[bounce];
     const uint32_t rounds = block_rounds(count);
@@ -645,7 +657,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene sc, 
                 const NeeRec r = load_nee(ps, slot, k);
                 float t;
                 V3 n;
-                const int hp = trace<LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, time, t, n, ctr);
+                const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, time, t, n, ctr);
                 rays++;
                 if (r.dist < 0.0f)
                     return (hp < 0) ? r.f : V3(0.0f);       // probe sample: contributes iff unoccluded
@@ -672,13 +684,14 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene sc, 
 // ---------------------------------------------------------------------------
 // k_mega: the A/B arm -- one lane walks one whole path (render.cpp:230-388), same pieces.
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene sc, PathState ps, QueueCtl q, CameraParams cam, FrameParams fp,
+template <bool COUNT, bool LDS>
+__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene scIn, PathState ps, QueueCtl q, CameraParams cam, FrameParams fp,
                                                  const uint32_t* __restrict__ passSeeds, int stackEntries)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
-    stage_scene_lds(sc, s_stack + stackEntries*kBlock + kScanWords);
+    SceneT<LDS> sc;
+    stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
     const int npix = fp.width*fp.height;
     const int total = npix*fp.numPasses;
@@ -713,7 +726,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene sc, Pa
             {
                 float t;
                 V3 n;
-                const int prim = trace<LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n, ctr);
+                const int prim = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n, ctr);
                 rays++;
 
                 if (prim < 0)
@@ -753,7 +766,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene sc, Pa
                         }
                         float ts;
                         V3 nn;
-                        const int hp = trace<LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, p.time, ts, nn, ctr);
+                        const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, p.time, ts, nn, ctr);
                         rays++;
                         shadowRays++;
                         if (r.dist < 0.0f)
@@ -856,11 +869,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FramePar
 // ---------------------------------------------------------------------------
 // k_normals: eNormals mode of the CPU renderer (render.cpp:494-515): x=i, y=j, time 1, overwrite.
 
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_normals(DevScene sc, CameraParams cam, FrameParams fp, float4* __restrict__ accum, int stackEntries)
+template <bool LDS>
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_normals(DevScene scIn, CameraParams cam, FrameParams fp, float4* __restrict__ accum, int stackEntries)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
-    stage_scene_lds(sc, s_stack + stackEntries*kBlock + kScanWords);
+    SceneT<LDS> sc;
+    stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
     const int npix = fp.width*fp.height;
     const int pix = blockIdx.x*kBlock + threadIdx.x;
@@ -875,7 +890,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_normals(DevScene sc,
     float t;
     V3 n;
     TraceCounters ctr = { 0, 0, 0 };
-    const int prim = trace<LdsStack<kBlock>, false>(sc, st, o, d, 1.0f, t, n, ctr);
+    const int prim = trace<SceneT<LDS>, LdsStack<kBlock>, false>(sc, st, o, d, 1.0f, t, n, ctr);
     if (prim >= 0)
     {
         n = n*0.5f + V3(0.5f);

@@ -102,6 +102,7 @@ struct DevMesh
     int32_t numTris;
     int32_t stackNeed;          // worst-case traversal stack entries for this tree
     int32_t inArena;            // 1: nodes/tris/normals/cdf live inside DevScene::arena (and follow it into LDS)
+    uint32_t offNodes, offTris, offNormals, offCdf;     // byte offsets inside the arena (inArena only)
 };
 
 struct DevProbe
@@ -138,7 +139,34 @@ struct DevScene
     uint32_t arenaBytes;
     uint32_t arenaLdsBytes;     // == arenaBytes when the kernels should stage it, else 0
     int32_t numMeshes;
-    int32_t pad;
+    int32_t allInArena;         // every mesh rides in the arena: the LDS-only kernel variants may be used
 };
+
+// Compile-time view of where the scene lives.  SceneT<true>: the whole scene (arena incl. every mesh)
+// has been staged into LDS and all accessors resolve to LDS addresses at compile time (ds_read);
+// SceneT<false>: generic pointers (HBM, or an LDS copy reached through flat loads).
+template <bool LDS>
+struct SceneT : DevScene
+{
+    static constexpr bool kLds = LDS;
+    const unsigned char* ldsBase;
+};
+
+template <class SC> TN_D const Node64* mesh_nodes(const SC& sc, const DevMesh& m)
+{
+    if constexpr (SC::kLds) return reinterpret_cast<const Node64*>(sc.ldsBase + m.offNodes); else return m.nodes;
+}
+template <class SC> TN_D const Tri48* mesh_tris(const SC& sc, const DevMesh& m)
+{
+    if constexpr (SC::kLds) return reinterpret_cast<const Tri48*>(sc.ldsBase + m.offTris); else return m.tris;
+}
+template <class SC> TN_D const float* mesh_normals(const SC& sc, const DevMesh& m)
+{
+    if constexpr (SC::kLds) return reinterpret_cast<const float*>(sc.ldsBase + m.offNormals); else return m.normals;
+}
+template <class SC> TN_D const float* mesh_cdf(const SC& sc, const DevMesh& m)
+{
+    if constexpr (SC::kLds) return reinterpret_cast<const float*>(sc.ldsBase + m.offCdf); else return m.cdf;
+}
 
 } // namespace tn
