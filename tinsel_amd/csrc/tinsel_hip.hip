@@ -870,6 +870,27 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         const size_t offMoving = arena.add(moving.data(), moving.size());
         const size_t offLights = arena.add(lights.data(), lights.size());
         const size_t offMeshes = arena.add(meshes.data(), meshes.size());
+
+        // leaf boxes of the scene BVH, by primitive index (flat scene-level scan)
+        std::vector<PrimBox> boxes((size_t)P);
+        std::vector<char> seen((size_t)P, 0);
+        for (int k = 0; k < desc->num_bvh_nodes; ++k)
+        {
+            const tinsel_bvh_node& nd = desc->bvh_nodes[k];
+            if (!ref_is_leaf(nd) || nd.left_index >= (uint32_t)P)
+                continue;
+            PrimBox& b = boxes[nd.left_index];
+            memset(&b, 0, sizeof(b));
+            b.minx = nd.lower.x; b.miny = nd.lower.y; b.minz = nd.lower.z;
+            b.maxx = nd.upper.x; b.maxy = nd.upper.y; b.maxz = nd.upper.z;
+            b.alwaysHit = (nd.lower.x <= -1e7f && nd.lower.y <= -1e7f && nd.lower.z <= -1e7f &&
+                           nd.upper.x >= 1e7f && nd.upper.y >= 1e7f && nd.upper.z >= 1e7f) ? 1u : 0u;
+            seen[nd.left_index] = 1;
+        }
+        bool everyPrimHasALeaf = true;
+        for (int k = 0; k < P; ++k)
+            everyPrimHasALeaf = everyPrimHasALeaf && seen[(size_t)k];
+        const size_t offBoxes = arena.add(boxes.data(), boxes.size());
         arena.bytes.resize((arena.bytes.size() + 127) & ~size_t(127), 0);
 
         unsigned char* arenaDev = r->sceneMem.upload(arena.bytes.data(), arena.bytes.size());
@@ -907,6 +928,8 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             sc.lights = reinterpret_cast<const int32_t*>(arenaDev + offLights);
             sc.meshes = reinterpret_cast<const DevMesh*>(arenaDev + offMeshes);
             sc.numMeshes = (int)meshes.size();
+            sc.primBoxes = reinterpret_cast<const PrimBox*>(arenaDev + offBoxes);
+            sc.flatScan = (everyPrimHasALeaf && P <= 64 && !getenv("TINSEL_HIP_NO_FLAT_SCAN")) ? 1 : 0;
             bool all = sc.arenaLdsBytes != 0;
             for (const DevMesh& dmesh : meshes)
                 all = all && dmesh.inArena;

@@ -287,6 +287,60 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
     return true;
 }
 
+// Scene level as a WAVE-UNIFORM scan (scenes with few primitives -- every BASELINE config).
+//
+// The oracle's QueryBVH (intersection.h:751-799) has no closest-t cull at scene level: it calls
+// PrimitiveIntersect for exactly the primitives whose leaf box (and hence, the slab test being
+// monotone under box inclusion, every ancestor box) the ray hits, and keeps the smallest t > 0, the
+// FIRST VISITED winning exact ties (render.cpp:45).  So the set of tests and the winner do not depend
+// on the visit order unless two candidate hits tie.  This scan runs the same leaf-box tests and the
+// same PrimitiveIntersect calls in primitive order -- every lane is at the same primitive at the same
+// time, so the primitive records are wave-uniform loads, the type switch does not diverge and there is
+// no stack traffic -- and reports `tie` when two accepted hits are (nearly) equal; the caller then
+// re-traces that ray with the BVH walk, which IS the oracle's order.  Results are therefore identical
+// to the BVH walk in all cases.
+template <class SC, class Stack, bool COUNT>
+TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, float& outT, V3& outN, bool& tie, TraceCounters& ctr)
+{
+    float minT = kFltMax;
+    int closest = -1;
+    V3 cn;
+    tie = false;
+
+    for (int i = 0; i < sc.numPrims; ++i)
+    {
+        const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + i);
+        const float4 b0 = bp[0], b1 = bp[1];
+        if (__float_as_uint(b1.z) == 0u)
+        {
+            float tb;
+            if (!ray_aabb(o, rcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tb))
+                continue;
+        }
+        float t;
+        V3 n;
+        if (prim_intersect<SC, Stack, COUNT>(sc, i, st, 0, o, d, time, t, n, ctr))
+        {
+            if (t > 0.0f)
+            {
+                // two accepted hits closer than a few ulps: let the oracle's visit order decide
+                if (fabsf(t - minT) <= 1e-5f*fabsf(t))
+                    tie = true;
+                if (t < minT)
+                {
+                    minT = t;
+                    closest = i;
+                    cn = n;
+                }
+            }
+        }
+    }
+
+    outT = minT;
+    outN = face_forward(cn, -d);
+    return closest;
+}
+
 // Trace (render.cpp:17-62) over QueryBVH (intersection.h:751-799).
 // Returns the primitive index or -1; outN is already FaceForward(n, -dir) (render.cpp:59).
 template <class SC, class Stack, bool COUNT>
@@ -297,6 +351,20 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
     V3 cn;
 
     V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+
+    // detail counting (COUNT) always walks the BVH: the counters define the reference algorithm's
+    // per-ray constants I, T, P of the algorithmic-bytes model
+    if (!COUNT && sc.flatScan)
+    {
+        // "sane" rays only: the always-hit shortcut for infinite boxes assumes |origin| << 1e8
+        const bool sane = fabsf(o.x) < 1e6f && fabsf(o.y) < 1e6f && fabsf(o.z) < 1e6f;
+        bool tie = false;
+        int prim = -1;
+        if (sane)
+            prim = trace_flat<SC, Stack, COUNT>(sc, st, o, d, rcp, time, outT, outN, tie, ctr);
+        if (sane && !tie)
+            return prim;
+    }
 
     int sp = 0;
     st.set(sp++, sc.root);

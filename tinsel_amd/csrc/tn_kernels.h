@@ -201,6 +201,7 @@ TN_D void stage_scene_lds(SceneT<LDS>& sc, const DevScene& in, uint32_t* ldsWord
     sc.moving = reinterpret_cast<const Moving64*>(rebase(in.moving));
     sc.meshes = reinterpret_cast<const DevMesh*>(rebase(in.meshes));
     sc.lights = reinterpret_cast<const int32_t*>(rebase(in.lights));
+    sc.primBoxes = reinterpret_cast<const PrimBox*>(rebase(in.primBoxes));
 }
 
 TN_D bool pixel_owned(const FrameParams& fp, int i, int j)

@@ -92,6 +92,16 @@ struct alignas(128) Mat128
 };
 static_assert(sizeof(Mat128) == 128, "Mat128");
 
+// World-space leaf box of one primitive, copied from the reference's scene BVH leaves
+// (PrimitiveBounds, intersection.h:906-939).  Used by the flat scene-level scan (tn_isect.h).
+struct alignas(32) PrimBox
+{
+    float minx, miny, minz, maxx, maxy, maxz;
+    uint32_t alwaysHit;         // 1: an "infinite" box (planes: +-1e8) that every sane ray hits
+    uint32_t pad;
+};
+static_assert(sizeof(PrimBox) == 32, "PrimBox");
+
 struct DevMesh
 {
     const Node64* nodes;
@@ -140,6 +150,9 @@ struct DevScene
     uint32_t arenaLdsBytes;     // == arenaBytes when the kernels should stage it, else 0
     int32_t numMeshes;
     int32_t allInArena;         // every mesh rides in the arena: the LDS-only kernel variants may be used
+    const PrimBox* primBoxes;   // [numPrims], in the arena
+    int32_t flatScan;           // 1: few primitives -> scene level is a wave-uniform scan (trace_flat)
+    int32_t pad2;
 };
 
 // Compile-time view of where the scene lives.  SceneT<true>: the whole scene (arena incl. every mesh)
