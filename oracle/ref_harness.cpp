@@ -126,6 +126,17 @@ void SetDefaults(RefScene* rs)
 
 size_t Align16(size_t x) { return (x + 15) & ~size_t(15); }
 
+// BVHBuilder leaves `rightIndex` of leaf nodes uninitialised (bvh.h:236-240): zero it in the serialised
+// copy so packs are byte-reproducible (no consumer reads it for leaves)
+std::vector<BVHNode> CleanNodes(const BVHNode* nodes, int n)
+{
+    std::vector<BVHNode> out(nodes, nodes + n);
+    for (int i = 0; i < n; ++i)
+        if (out[i].leaf)
+            out[i].rightIndex = 0;
+    return out;
+}
+
 } // namespace
 
 extern "C" {
@@ -289,6 +300,16 @@ size_t ref_scene_write_pack(void* h, const char* path)
         Primitive& p = prims[i];
         // bump maps are dead in the reference; never serialise host pointers
         p.material.bumpMap = Texture();
+        // struct padding is uninitialised in the reference's constructors: zero it so packs are byte-reproducible
+        {
+            unsigned char* raw = (unsigned char*)&p;
+            memset(raw + offsetof(Primitive, type) + sizeof(GeometryType), 0, offsetof(Primitive, mesh) - offsetof(Primitive, type) - sizeof(GeometryType));
+            memset(raw + offsetof(Primitive, material) + offsetof(Material, transmission) + sizeof(float), 0,
+                   offsetof(Material, bumpMap) - offsetof(Material, transmission) - sizeof(float));
+            memset(raw + offsetof(Primitive, material) + offsetof(Material, bumpMap) + offsetof(Texture, depth) + sizeof(int), 0,
+                   sizeof(Texture) - offsetof(Texture, depth) - sizeof(int));
+            memset(raw + offsetof(Primitive, lightSamples) + sizeof(int), 0, sizeof(Primitive) - offsetof(Primitive, lightSamples) - sizeof(int));
+        }
         if (p.type != eMesh)
         {
             // zero the unused tail of the geometry union so packs are byte-reproducible
@@ -310,7 +331,8 @@ size_t ref_scene_write_pack(void* h, const char* path)
             o.positions = (const Vec3*)append(g.positions, sizeof(Vec3)*g.numVertices);
             o.normals = (const Vec3*)append(g.normals, sizeof(Vec3)*g.numVertices);
             o.indices = (const int*)append(g.indices, sizeof(int)*g.numIndices);
-            o.nodes = (const BVHNode*)append(g.nodes, sizeof(BVHNode)*g.numNodes);
+            std::vector<BVHNode> cleanMeshNodes = CleanNodes(g.nodes, g.numNodes);
+            o.nodes = (const BVHNode*)append(cleanMeshNodes.data(), sizeof(BVHNode)*g.numNodes);
             o.cdf = (const float*)append(g.cdf, sizeof(float)*(g.numIndices/3));
             o.id = (unsigned long)(k + 1);
             ids.push_back(p.mesh.id);
@@ -321,7 +343,8 @@ size_t ref_scene_write_pack(void* h, const char* path)
     hdr.num_meshes = (uint32_t)packed.size();
 
     hdr.off_primitives = append(prims.empty() ? NULL : &prims[0], sizeof(Primitive)*prims.size());
-    hdr.off_bvh_nodes = append(s.bvh.nodes, sizeof(BVHNode)*s.bvh.numNodes);
+    std::vector<BVHNode> cleanSceneNodes = CleanNodes(s.bvh.nodes, s.bvh.numNodes);
+    hdr.off_bvh_nodes = append(cleanSceneNodes.data(), sizeof(BVHNode)*s.bvh.numNodes);
 
     const Probe& pr = s.sky.probe;
     if (pr.valid)

@@ -67,6 +67,15 @@ def main():
     R.write_pack(h, os.path.join(HERE, "features_probe.pack"))
     make_outputs(R, h, "features_probe", 96, 64, 4, None)
 
+    # data/ajax.tin with a deterministic 18,432-triangle stand-in for the missing ajax.obj (see make_large.py for
+    # the 524,288-triangle config): a real SAH mesh BVH (deep stack), gloss material, sphere light
+    import subprocess
+    subprocess.run([sys.executable, os.path.join(HERE, "make_large.py"), "96", "96", args.ref], check=True)
+    os.replace(os.path.join(HERE, "large", "ajax_standin_96.pack"), os.path.join(HERE, "ajax_standin_96.pack"))
+    h = R.load_pack(os.path.join(HERE, "ajax_standin_96.pack"))
+    make_outputs(R, h, "ajax_standin_96", 96, 96, 3, None)
+    R.free(h)
+
     # cornell + probe (open box is lit by the probe through the camera side)
     h = R.load_tin(os.path.join(args.ref, "data/cornell.tin"))
     R.lib.ref_scene_set_procedural_probe(h, 64, 32)

@@ -23,7 +23,7 @@ from tests.oracle_api import GOLDEN, image_l2
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell", "veach", "glass", "simple", "conservation", "furnace", "emitter", "gloss", "features",
-          "features_probe", "cornell_probe"]
+          "features_probe", "cornell_probe", "ajax_standin_96"]
 
 
 def _load(name):
@@ -145,7 +145,8 @@ def test_shards_sum_to_whole():
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libtinsel_ref.so")),
                     reason="oracle/_ref not built")
 @pytest.mark.parametrize("name,W,H,passes,depth", [("cornell", 256, 256, 16, 4), ("veach", 192, 192, 4, 4), ("glass", 160, 160, 4, 12),
-                                                   ("features", 192, 128, 32, 6), ("features_probe", 192, 128, 32, 6)])
+                                                   ("features", 192, 128, 32, 6), ("features_probe", 192, 128, 32, 6),
+                                                   ("ajax_standin_96", 200, 200, 8, 4)])
 def test_against_reference_live(name, W, H, passes, depth):
     """BASELINE config-1-sized check against the reference's PathTrace run HERE on the host cores."""
     from tests.oracle_api import RefOracle
