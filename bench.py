@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--maxdepth", type=int, default=0, help="0 = the scene's own / BASELINE value")
-    ap.add_argument("--pipeline", choices=["wavefront", "mega", "split"], default="wavefront")
+    ap.add_argument("--pipeline", choices=["auto", "wavefront", "mega", "split"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-core-seconds of oracle work")
     ap.add_argument("--tile", type=int, default=32)
@@ -108,7 +108,7 @@ def main():
     opt.mode = abi.MODE_PATHTRACE
 
     r = tinsel_amd.create_gpu_renderer(scene, local)
-    r.set_pipeline({"wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
+    r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
     if world > 1:
         r.set_shard(rank, world, args.tile)
         r.set_batch_paths((4 << 20)*world)       # keep the same number of LIVE paths per batch as N = 1
@@ -191,6 +191,9 @@ def main():
     dom = max(ktimes.items(), key=lambda kv: kv[1][1]) if ktimes else (None, (0, 0.0))
     dom_name, (dom_launches, dom_ms) = dom
     rays_by_kernel = {"k_extend": st["rays"] - st["shadow_rays"], "k_shadow": st["shadow_rays"], "k_mega": st["rays"], "k_bounce": st["rays"]}
+    if "k_shade" in ktimes and dom_name == "k_shade":
+        # k_shade only moves path state (no algorithmic bytes by SURVEY 8(d)): rate the heaviest TRACE kernel instead
+        dom_name, (dom_launches, dom_ms) = max(((k, v) for k, v in ktimes.items() if k in ("k_extend", "k_shadow")), key=lambda kv: kv[1][1])
     if dom_name in rays_by_kernel:
         dom_bytes = rays_by_kernel[dom_name]*B_ray
     elif dom_name == "k_accumulate":
@@ -234,7 +237,8 @@ def main():
         "ms_per_step": elapsed*1e3/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s.tin %dx%d maxDepth=%d, %d pass(es) per step, pipeline=%s" % (
-            args.scene, opt.width, opt.height, opt.max_depth, passes_per_step, args.pipeline),
+            args.scene, opt.width, opt.height, opt.max_depth, passes_per_step,
+            args.pipeline if args.pipeline != "auto" else "auto->" + ("wavefront(fused)" if "k_bounce" in ktimes else "wavefront(split)")),
             "scene_pack": os.path.relpath(pack, ROOT), "parallelism": "pixel-tile shard x%d + RCCL reduce" % world if world > 1 else "1 GPU",
             "filter": "gaussian w=%.2f" % fw, "rays_per_sample": tot_rays/max(1.0, tot_samples)},
         "mrays_per_s": tot_rays/elapsed/1e6,

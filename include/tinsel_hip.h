@@ -164,7 +164,11 @@ typedef struct tinsel_hip tinsel_hip;       /* opaque */
  * kernel per bounce over HBM ray queues with wave64 compaction.  MEGAKERNEL (one lane per whole
  * path) and WAVEFRONT_SPLIT (extend / shade / shadow kernels per bounce) are A/B arms with
  * identical per-path arithmetic. */
-enum { TINSEL_PIPELINE_WAVEFRONT = 0, TINSEL_PIPELINE_MEGAKERNEL = 1, TINSEL_PIPELINE_WAVEFRONT_SPLIT = 2 };
+enum { TINSEL_PIPELINE_WAVEFRONT = 0, TINSEL_PIPELINE_MEGAKERNEL = 1, TINSEL_PIPELINE_WAVEFRONT_SPLIT = 2,
+       /* default: WAVEFRONT (fused bounce kernel) when the whole scene is LDS-resident and a bounce casts at
+        * most one NEE ray, else WAVEFRONT_SPLIT, whose trace-only kernels run at twice the occupancy
+        * (measured crossover: DESIGN.md section 5) */
+       TINSEL_PIPELINE_AUTO = 3 };
 
 /* Replaces GpuRenderer::GpuRenderer (render.cu:989-1053): deep-copies the scene
  * to device `device_index` (dedupes meshes by MeshGeometry::id, re-lays BVHs out

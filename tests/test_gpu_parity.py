@@ -54,8 +54,8 @@ def _render(scene, cam, opt, passes, pipeline, batch=None, want_radiance=False):
 L2_FIXTURES = [s for s in SCENES if not s.startswith("features")]
 
 
-@pytest.mark.parametrize("pipeline", [abi.PIPELINE_WAVEFRONT, abi.PIPELINE_MEGAKERNEL, abi.PIPELINE_WAVEFRONT_SPLIT],
-                         ids=["wavefront", "mega", "split"])
+@pytest.mark.parametrize("pipeline", [abi.PIPELINE_AUTO, abi.PIPELINE_WAVEFRONT, abi.PIPELINE_MEGAKERNEL, abi.PIPELINE_WAVEFRONT_SPLIT],
+                         ids=["auto", "wavefront", "mega", "split"])
 @pytest.mark.parametrize("name", SCENES)
 def test_accum_matches_golden(name, pipeline):
     scene, cam, opt, g = _load(name)

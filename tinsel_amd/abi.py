@@ -114,7 +114,7 @@ class KernelTime(C.Structure):
 MODE_NORMALS, MODE_COMPLEXITY, MODE_PATHTRACE = 0, 1, 2
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 GEOM_SPHERE, GEOM_PLANE, GEOM_MESH = 0, 1, 2
-PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT_SPLIT = 0, 1, 2
+PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT_SPLIT, PIPELINE_AUTO = 0, 1, 2, 3
 
 assert C.sizeof(Transform) == 32 and C.sizeof(BVHNode) == 32 and C.sizeof(Camera) == 40
 assert C.sizeof(Material) == 128 and C.sizeof(MeshGeometry) == 64 and C.sizeof(Primitive) == 272

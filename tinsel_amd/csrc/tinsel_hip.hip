@@ -269,7 +269,7 @@ struct tinsel_hip
 
     size_t lastBatchSlots = 0;
     size_t maxBatchSlots = 4u << 20;
-    int pipeline = TINSEL_PIPELINE_WAVEFRONT;
+    int pipeline = TINSEL_PIPELINE_AUTO;
     bool countDetail = false;
 
     uint32_t passIndex = 0;
@@ -511,12 +511,16 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
     r->lastBatchSlots = slots;
 
-    if (r->pipeline == TINSEL_PIPELINE_MEGAKERNEL)
+    int pipeline = r->pipeline;
+    if (pipeline == TINSEL_PIPELINE_AUTO)
+        pipeline = (r->scene.allInArena && r->neePerPath <= 1) ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
+
+    if (pipeline == TINSEL_PIPELINE_MEGAKERNEL)
     {
         ScopedTimer t(r, KN_MEGA, st);
         launch_mega(r, st, gridFlat, cam, fp);
     }
-    else if (r->pipeline == TINSEL_PIPELINE_WAVEFRONT)
+    else if (pipeline == TINSEL_PIPELINE_WAVEFRONT)
     {
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
@@ -1083,7 +1087,7 @@ int tinsel_hip_set_shard(tinsel_hip* r, int rank, int world, int tile)
 
 int tinsel_hip_set_pipeline(tinsel_hip* r, int pipeline)
 {
-    if (!r || pipeline < TINSEL_PIPELINE_WAVEFRONT || pipeline > TINSEL_PIPELINE_WAVEFRONT_SPLIT)
+    if (!r || pipeline < TINSEL_PIPELINE_WAVEFRONT || pipeline > TINSEL_PIPELINE_AUTO)
         return fail("set_pipeline: bad arguments");
     r->pipeline = pipeline;
     return 0;

@@ -98,7 +98,9 @@ TN_D float bsdf_pdf(const Mat& mat, float etaI, float etaO, V3 n, V3 V, V3 L)
     }
     else
     {
-        float F = fresnel_dielectric(dot(n, V), etaI, etaO);
+        // F only enters through Lerp(brdfPdf, pdfSpec*F, transmission): with transmission == 0 that is
+        // brdfPdf + (finite)*0 == brdfPdf for any F in [0,1], so opaque materials skip the Fresnel term
+        float F = (mat.transmission != 0.0f) ? fresnel_dielectric(dot(n, V), etaI, etaO) : 1.0f;
         const float a = maxT(0.001f, mat.roughness);
         const V3 half = safe_normalize(L + V, V3(0.0f));
         const float cosThetaHalf = absf(dot(half, n));
@@ -111,15 +113,13 @@ TN_D float bsdf_pdf(const Mat& mat, float etaI, float etaO, V3 n, V3 V, V3 L)
     }
 }
 
-// the GTR2 half-vector sampling shared by both specular branches (disney.h:184-204 == 265-285)
-TN_D V3 sample_ggx_reflection(const Mat& mat, V3 U, V3 Vt, V3 N, V3 view, float r1, float r2)
+// the GTR2 half-vector sampling shared by both specular branches (disney.h:184-204 == 265-285);
+// sin/cos of phiHalf = r1*k2Pi are passed in
+TN_D V3 sample_ggx_reflection(const Mat& mat, V3 U, V3 Vt, V3 N, V3 view, float sinPhiHalf, float cosPhiHalf, float r2)
 {
     const float a = maxT(0.001f, mat.roughness);
-    const float phiHalf = r1*k2Pi;
     const float cosThetaHalf = sqrtf((1.0f - r2)/(1.0f + (sqr(a) - 1.0f)*r2));
     const float sinThetaHalf = sqrtf(maxT(0.0f, 1.0f - sqr(cosThetaHalf)));
-    float sinPhiHalf, cosPhiHalf;
-    m_sincosf(phiHalf, sinPhiHalf, cosPhiHalf);
 
     V3 half = U*(sinThetaHalf*cosPhiHalf) + Vt*(sinThetaHalf*sinPhiHalf) + N*cosThetaHalf;
     if (dot(half, view) <= 0.0f)
@@ -172,21 +172,44 @@ TN_D void bsdf_sample(const Mat& mat, float etaI, float etaO, V3 U, V3 Vt, V3 N,
             lobe = kLobeGgx;                                                         // disney.h:264-287
     }
 
+    // every lobe takes sin/cos of ONE angle: GGX phiHalf = r1*k2Pi (disney.h:185), cosine-hemisphere
+    // theta = k2Pi*u2 (maths.h:1307), inside-hemisphere phi = k2Pi*Randf (maths.h:1297, after its z draw)
+    float zIn = 0.0f;
+    float angle;
+    if (lobe == kLobeInside)
+    {
+        zIn = rng.randf();
+        angle = k2Pi*rng.randf();
+    }
+    else
+    {
+        angle = (lobe == kLobeGgx) ? r1*k2Pi : k2Pi*r2;
+    }
+    float sn, cs;
+    m_sincosf(angle, sn, cs);
+
     if (lobe == kLobeGgx)
     {
-        light = sample_ggx_reflection(mat, U, Vt, N, view, r1, r2);
+        light = sample_ggx_reflection(mat, U, Vt, N, view, sn, cs, r2);
         type = kReflected;
     }
     else if (lobe == kLobeCosine)
     {
-        const V3 d = cosine_sample_hemisphere(r1, r2);
-        light = U*d.x + Vt*d.y + N*d.z;
+        // CosineSampleHemisphere (maths.h:1304-1310, 1319-1325)
+        const float r = sqrtf(r1);
+        const float sx = r*cs;
+        const float sy = r*sn;
+        const float z = sqrtf(maxT(0.0f, 1.0f - sx*sx - sy*sy));
+        light = U*sx + Vt*sy + N*z;
         type = kReflected;
     }
     else
     {
-        const V3 d = uniform_sample_hemisphere(rng);
-        light = U*d.x + Vt*d.y - N*d.z;
+        // UniformSampleHemisphere (maths.h:1291-1302), z negated to sample inside the surface
+        const float w = sqrtf(1.0f - zIn*zIn);
+        const float x = cs*w;
+        const float y = sn*w;
+        light = U*x + Vt*y - N*zIn;
         type = kTransmitted;
     }
 
@@ -254,11 +277,17 @@ TN_D V3 bsdf_eval(const Mat& mat, float etaI, float etaO, V3 N, V3 V, V3 L)
             float Fd90 = 0.5f + 2.0f*LDotH*LDotH*mat.roughness;
             float Fd = lerpf(1.0f, Fd90, FL)*lerpf(1.0f, Fd90, FV);
 
-            float Dr = gtr1(NDotH, mat.clearcoatAlpha, mat.clearcoatA2, mat.clearcoatLogA2);
-            float Fc = lerpf(.04f, 1.0f, FH);
-            float Gr = smith_ggx(NDotL, .25f)*smith_ggx(NDotV, .25f);
+            // clearcoat == 0: the lobe is 0*Gr*Fc*Dr with Gr, Fc, Dr finite here (NDotL > 0), i.e. +V3(0)
+            float coat = 0.0f;
+            if (mat.clearcoat != 0.0f)
+            {
+                float Dr = gtr1(NDotH, mat.clearcoatAlpha, mat.clearcoatA2, mat.clearcoatLogA2);
+                float Fc = lerpf(.04f, 1.0f, FH);
+                float Gr = smith_ggx(NDotL, .25f)*smith_ggx(NDotV, .25f);
+                coat = mat.clearcoat*Gr*Fc*Dr;
+            }
 
-            brdf = kInvPi*Fd*Cdlin*(1.0f - mat.metallic)*(1.0f - mat.subsurface) + Gs*Fs*Ds + V3(mat.clearcoat*Gr*Fc*Dr);
+            brdf = kInvPi*Fd*Cdlin*(1.0f - mat.metallic)*(1.0f - mat.subsurface) + Gs*Fs*Ds + V3(coat);
         }
     }
 
