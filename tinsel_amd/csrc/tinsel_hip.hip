@@ -933,6 +933,10 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             sc.meshes = reinterpret_cast<const DevMesh*>(arenaDev + offMeshes);
             sc.numMeshes = (int)meshes.size();
             sc.primBoxes = reinterpret_cast<const PrimBox*>(arenaDev + offBoxes);
+            sc.hasMedia = 0;
+            for (const Mat128& mm : mats)
+                if (mm.absorption[0] != 0.0f || mm.absorption[1] != 0.0f || mm.absorption[2] != 0.0f)
+                    sc.hasMedia = 1;
             sc.flatScan = (everyPrimHasALeaf && P <= 64 && !getenv("TINSEL_HIP_NO_FLAT_SCAN")) ? 1 : 0;
             bool all = sc.arenaLdsBytes != 0;
             for (const DevMesh& dmesh : meshes)

@@ -242,10 +242,11 @@ TN_D void camera_sample(const CameraParams& cam, const FrameParams& fp, int i, i
 // ---------------------------------------------------------------------------
 // path-state load/store
 
-TN_D void load_path(const PathState& ps, uint32_t slot, PathRegs& p, float& rasterX, float& rasterY)
+TN_D void load_path(const PathState& ps, uint32_t slot, PathRegs& p, float& rasterX, float& rasterY, bool hasMedia)
 {
     const float4 ro = ps.rayO[slot], rd = ps.rayD[slot], th = ps.thr[slot], ra = ps.rad[slot];
-    const float4 ab = ps.absorb[slot], rr = ps.rngRaster[slot];
+    const float4 ab = hasMedia ? ps.absorb[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 rr = ps.rngRaster[slot];
     p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
     p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
     p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
@@ -255,13 +256,14 @@ TN_D void load_path(const PathState& ps, uint32_t slot, PathRegs& p, float& rast
     rasterX = rr.z; rasterY = rr.w;
 }
 
-TN_D void store_path(const PathState& ps, uint32_t slot, const PathRegs& p, float rasterX, float rasterY)
+TN_D void store_path(const PathState& ps, uint32_t slot, const PathRegs& p, float rasterX, float rasterY, bool hasMedia)
 {
     ps.rayO[slot] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
     ps.rayD[slot] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
     ps.thr[slot] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
     ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
-    ps.absorb[slot] = make_float4(p.absorption.x, p.absorption.y, p.absorption.z, 0.0f);
+    if (hasMedia)
+        ps.absorb[slot] = make_float4(p.absorption.x, p.absorption.y, p.absorption.z, 0.0f);
     ps.rngRaster[slot] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), rasterX, rasterY);
 }
 
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
             }
             else
             {
-                load_path(ps, slot, p, rx, ry);
+                load_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
             }
 
             float t;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
 
             if (alive)
             {
-                store_path(ps, slot, p, rx, ry);
+                store_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
                 keep |= 1u << g;
             }
             else
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q
             float rx, ry;
             if (begin_path(cam, fp, passSeeds, slot, p, rx, ry))
             {
-                store_path(ps, slot, p, rx, ry);
+                store_path(ps, slot, p, rx, ry, true);
                 keep |= 1u << g;
                 samples++;
             }
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
 
             PathRegs p;
             float rx, ry;
-            load_path(ps, slot, p, rx, ry);
+            load_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
 
             const int prim = ps.hitPrim[slot];
             if (prim < 0)
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
 
             if (res == kContinue)
             {
-                store_path(ps, slot, p, rx, ry);
+                store_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
                 keepNext |= 1u << g;
             }
             else

@@ -152,7 +152,7 @@ struct DevScene
     int32_t allInArena;         // every mesh rides in the arena: the LDS-only kernel variants may be used
     const PrimBox* primBoxes;   // [numPrims], in the arena
     int32_t flatScan;           // 1: few primitives -> scene level is a wave-uniform scan (trace_flat)
-    int32_t pad2;
+    int32_t hasMedia;           // 0: no material absorbs, rayAbsorption stays 0 -> its 16-B state record is skipped
 };
 
 // Compile-time view of where the scene lives.  SceneT<true>: the whole scene (arena incl. every mesh)
