@@ -1,7 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out/r1b
+mkdir -p gpurun_out/r1c
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r1b
+O=$GRAFT_REPO_ROOT/gpurun_out/r1c
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -2 $O/bench_default.err; cat $O/bench_default.json
 cd /tmp
