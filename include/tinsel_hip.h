@@ -254,6 +254,14 @@ int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths);
  * float4 records {r,g,b,-} in slot order (slot = pass_in_batch*W*H + j*W + i) and returns the count. */
 long long tinsel_hip_read_batch_radiance(tinsel_hip* r, float* out_rgbx, unsigned long long max_paths);
 
+/* Test hook: evaluates one device leaf function on caller arrays (host pointers; rows of `in_stride` /
+ * `out_stride` floats, one thread per row) so tests can table the HIP restatements against the reference's
+ * inline functions.  op: 0 Random, 1 CameraSampler::GenerateRay, 2 BSDFEval+BSDFPdf, 3 BSDFSample,
+ * 4 PrimitiveIntersect, 5 PrimitiveSample, 6 ProbeSample/ProbePdf/Sky::Eval (row layouts: tn_kernels.h LeafOp).
+ * `index` = primitive (its material for ops 2,3). */
+int tinsel_hip_leaf(tinsel_hip* r, int op, int index, int n, const float* in, int in_stride, const uint32_t* seeds,
+                    float* out, int out_stride, const tinsel_camera* camera, int width, int height);
+
 /* Introspection: LDS traversal-stack entries per lane chosen for this scene, NEE rays per bounce. */
 int tinsel_hip_stack_entries(tinsel_hip* r);
 int tinsel_hip_nee_per_path(tinsel_hip* r);

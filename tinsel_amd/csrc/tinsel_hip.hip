@@ -1220,6 +1220,46 @@ long long tinsel_hip_read_batch_radiance(tinsel_hip* r, float* out_rgbx, unsigne
     return (long long)n;
 }
 
+int tinsel_hip_leaf(tinsel_hip* r, int op, int index, int n, const float* in, int in_stride, const uint32_t* seeds,
+                    float* out, int out_stride, const tinsel_camera* camera, int width, int height)
+{
+    if (!r || n <= 0 || !out || out_stride <= 0 || op < 0 || op > kLeafProbe)
+        return fail("leaf: bad arguments");
+    if ((op == kLeafBsdfEval || op == kLeafBsdfSample || op == kLeafPrimIntersect || op == kLeafPrimSample) &&
+        (index < 0 || index >= r->scene.numPrims))
+        return fail("leaf: primitive index out of range");
+    HIP_TRY(hipSetDevice(r->device));
+    float* dIn = nullptr;
+    uint32_t* dSeeds = nullptr;
+    float* dOut = nullptr;
+    int rc = 0;
+    CameraParams cam;
+    memset(&cam, 0, sizeof(cam));
+    if (camera && width > 0 && height > 0)
+        make_camera(*camera, width, height, cam);
+    do {
+        if (in && in_stride > 0)
+        {
+            if (hipMalloc((void**)&dIn, sizeof(float)*(size_t)n*in_stride) != hipSuccess ||
+                hipMemcpy(dIn, in, sizeof(float)*(size_t)n*in_stride, hipMemcpyHostToDevice) != hipSuccess) { rc = fail("leaf: input upload failed"); break; }
+        }
+        if (seeds)
+        {
+            if (hipMalloc((void**)&dSeeds, sizeof(uint32_t)*(size_t)n) != hipSuccess ||
+                hipMemcpy(dSeeds, seeds, sizeof(uint32_t)*(size_t)n, hipMemcpyHostToDevice) != hipSuccess) { rc = fail("leaf: seed upload failed"); break; }
+        }
+        if (hipMalloc((void**)&dOut, sizeof(float)*(size_t)n*out_stride) != hipSuccess) { rc = fail("leaf: output allocation failed"); break; }
+        hipLaunchKernelGGL(k_leaf, dim3((n + kBlock - 1)/kBlock), dim3(kBlock), stack_bytes(r), nullptr, r->scene, op, index, n, dIn, in_stride,
+                           dSeeds, dOut, out_stride, cam, r->stackNeed);
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail("leaf: kernel failed"); break; }
+        if (hipMemcpy(out, dOut, sizeof(float)*(size_t)n*out_stride, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("leaf: download failed"); break; }
+    } while (0);
+    if (dIn) (void)hipFree(dIn);
+    if (dSeeds) (void)hipFree(dSeeds);
+    if (dOut) (void)hipFree(dOut);
+    return rc;
+}
+
 int tinsel_hip_stack_entries(tinsel_hip* r) { return r ? r->stackNeed : 0; }
 int tinsel_hip_nee_per_path(tinsel_hip* r) { return r ? r->neePerPath : 0; }
 

@@ -905,4 +905,107 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_normals(DevScene scI
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_leaf: test hook -- the device restatements of the reference's leaf functions evaluated on caller
+// arrays, so tests can table them against the reference's own inline functions.
+
+enum LeafOp : int
+{
+    kLeafRandom = 0,            // seeds -> 4 x Rand(), 4 x Randf() (as float bits)              out stride 8
+    kLeafCameraRay = 1,         // in: rasterX, rasterY -> origin(3), dir(3)                       out stride 6
+    kLeafBsdfEval = 2,          // in: n(3) V(3) L(3) etaI etaO -> f(3), pdf                       out stride 4
+    kLeafBsdfSample = 3,        // in: n(3) V(3) etaI etaO + seed -> L(3), pdf, type, s1, s2       out stride 7
+    kLeafPrimIntersect = 4,     // in: origin(3) dir(3) time -> hit, t, n(3)                       out stride 5
+    kLeafPrimSample = 5,        // in: time + seed -> pos(3), normal(3), s1, s2                    out stride 8
+    kLeafProbe = 6,             // seed -> dir(3), color(3), pdf, ProbePdf(dir), Sky::Eval(dir)(3)  out stride 11
+};
+
+__global__ __launch_bounds__(kBlock) void k_leaf(DevScene scIn, int op, int index, int n, const float* __restrict__ in, int inStride,
+                                                 const uint32_t* __restrict__ seeds, float* __restrict__ out, int outStride,
+                                                 CameraParams cam, int stackEntries)
+{
+    extern __shared__ uint32_t s_stack[];
+    LdsStack<kBlock> st = { s_stack + threadIdx.x };
+    SceneT<false> sc;
+    stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
+
+    const int i = blockIdx.x*kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    const float* r = in ? in + (size_t)i*inStride : nullptr;
+    float* o = out + (size_t)i*outStride;
+    Rng rng = Rng::seeded(seeds ? seeds[i] : 0u);
+
+    if (op == kLeafRandom)
+    {
+        Rng a = rng, b = rng;
+        for (int k = 0; k < 4; ++k)
+        {
+            o[k] = __uint_as_float(a.rand());
+            o[4 + k] = b.randf();
+        }
+    }
+    else if (op == kLeafCameraRay)
+    {
+        V3 ro, rd;
+        generate_ray(cam, r[0], r[1], ro, rd);
+        o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
+    }
+    else if (op == kLeafBsdfEval)
+    {
+        const Mat mat = load_mat(sc.mats, index);
+        V3 N(r[0], r[1], r[2]), V(r[3], r[4], r[5]), L(r[6], r[7], r[8]);
+        V3 f = bsdf_eval(mat, r[9], r[10], N, V, L);
+        o[0] = f.x; o[1] = f.y; o[2] = f.z;
+        o[3] = bsdf_pdf(mat, r[9], r[10], N, V, L);
+    }
+    else if (op == kLeafBsdfSample)
+    {
+        const Mat mat = load_mat(sc.mats, index);
+        V3 N(r[0], r[1], r[2]), V(r[3], r[4], r[5]);
+        V3 u, v;
+        basis_from_vector(N, u, v);
+        V3 L(0.0f);
+        float pdf = 0.0f;
+        int type = kReflected;
+        bsdf_sample(mat, r[6], r[7], u, v, N, V, L, pdf, type, rng);
+        o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = pdf; o[4] = __int_as_float(type);
+        o[5] = __uint_as_float(rng.s1); o[6] = __uint_as_float(rng.s2);
+    }
+    else if (op == kLeafPrimIntersect)
+    {
+        float t = 0.0f;
+        V3 nrm(0.0f);
+        TraceCounters ctr = { 0, 0, 0 };
+        const bool hit = prim_intersect<SceneT<false>, LdsStack<kBlock>, false>(sc, index, st, 0, V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), r[6], t, nrm, ctr);
+        o[0] = hit ? 1.0f : 0.0f;
+        o[1] = hit ? t : 0.0f;
+        o[2] = hit ? nrm.x : 0.0f; o[3] = hit ? nrm.y : 0.0f; o[4] = hit ? nrm.z : 0.0f;
+    }
+    else if (op == kLeafPrimSample)
+    {
+        V3 pos, nrm;
+        primitive_sample(sc, index, r[0], pos, nrm, rng);
+        o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = nrm.x; o[4] = nrm.y; o[5] = nrm.z;
+        o[6] = __uint_as_float(rng.s1); o[7] = __uint_as_float(rng.s2);
+    }
+    else if (op == kLeafProbe)
+    {
+        V3 dir(0.0f), color(0.0f);
+        float pdf = 0.0f;
+        if (sc.probe.valid)
+            probe_sample(sc.probe, dir, color, pdf, rng);
+        else
+        {
+            float u1 = rng.randf();
+            float u2 = rng.randf();
+            dir = uniform_sample_sphere(u1, u2);
+        }
+        const float pdf2 = sc.probe.valid ? probe_pdf(sc.probe, dir) : 0.0f;
+        const V3 e = sky_eval(sc, dir);
+        o[0] = dir.x; o[1] = dir.y; o[2] = dir.z; o[3] = color.x; o[4] = color.y; o[5] = color.z;
+        o[6] = pdf; o[7] = pdf2; o[8] = e.x; o[9] = e.y; o[10] = e.z;
+    }
+}
+
 } // namespace tn

@@ -74,6 +74,7 @@ def load_library():
     L.tinsel_hip_set_batch_paths.argtypes = [vp, C.c_ulonglong]
     L.tinsel_hip_read_batch_radiance.restype = C.c_longlong
     L.tinsel_hip_read_batch_radiance.argtypes = [vp, vp, C.c_ulonglong]
+    L.tinsel_hip_leaf.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, ci, C.POINTER(abi.Camera), ci, ci]
     L.tinsel_hip_stack_entries.argtypes = [vp]
     L.tinsel_hip_nee_per_path.argtypes = [vp]
     L.tinsel_hip_last_error.restype = C.c_char_p
@@ -88,7 +89,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_set_pipeline", "tinsel_hip_set_pass_index", "tinsel_hip_get_pass_index", "tinsel_hip_stats",
     "tinsel_hip_reset_stats", "tinsel_hip_stats_detail", "tinsel_hip_set_detail_counters", "tinsel_hip_kernel_times",
     "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
-    "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance",
+    "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
 ]
 
 
@@ -217,6 +218,21 @@ class HipRenderer:
         if got != n:
             raise TinselHipError("batch holds %d paths, wanted %d" % (got, n))
         return out[:, :3].reshape(passes, height, width, 3).copy()
+
+    def leaf(self, op, index, n, out_stride, rows=None, seeds=None, camera=None, width=0, height=0):
+        """Test hook: device leaf function `op` on `n` rows (see include/tinsel_hip.h: tinsel_hip_leaf)."""
+        out = np.zeros((n, out_stride), np.float32)
+        rp, rs = None, 0
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, np.float32)
+            rp, rs = rows.ctypes.data_as(C.c_void_p), rows.shape[1]
+        sp = None
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, np.uint32)
+            sp = seeds.ctypes.data_as(C.c_void_p)
+        _check(self._L.tinsel_hip_leaf(self._h, op, index, n, rp, rs, sp, out.ctypes.data_as(C.c_void_p), out_stride,
+                                       C.byref(camera) if camera is not None else None, width, height), "tinsel_hip_leaf")
+        return out
 
     def reset_stats(self):
         self._L.tinsel_hip_reset_stats(self._h)
