@@ -3,14 +3,15 @@
 Oracle = the reference's own PathTrace (oracle/_ref, when its prebuilt .so travelled here) and the
 committed golden fixtures generated from it (tests/golden/*.golden.npz) -- same per-path seeds.
 
-Tolerances (fp32 path tracing; north_star: per-pixel L2 <= 1e-3 vs the CPU reference):
-  * per-pixel L2 of rgb/w  <= 1e-3  (the stated bar) wherever the image has enough samples for the
-    statistic to mean something: every live-reference test below (>= 4 spp at >= 160^2) and every
-    golden fixture except the two `features*` ones, whose 96x64x4spp frame is moved past 1e-3 by a
-    SINGLE path that took another branch inside the glass sphere (DESIGN.md "Divergent paths");
-  * per path (all fixtures): >= 95 % of paths bit-identical to the reference's PathTrace, and
-    <= 1e-3 of paths off by more than 1e-3 relative;
-  * eNormals image: max-abs <= 2e-5 except on <= 0.2 % silhouette / tie pixels.
+Tolerances.  The north_star bar is per-pixel L2 <= 1e-3 of rgb/w against the CPU reference on identical
+seeds.  The HIP path does far better, and the tests hold it to what it actually achieves:
+  * scenes WITHOUT an environment probe: per-path radiance AND the accumulated framebuffer must be
+    BIT-IDENTICAL to the reference's PathTrace / AddSample (the device restates the reference's fp32
+    operation order and glibc's sinf/cosf/expf algorithms, DESIGN.md section 3);
+  * scenes WITH a probe (acosf/atan2f in ProbePdf are ocml-double, not glibc's): >= 99 % of paths
+    bit-identical, <= 1e-3 of paths off by more than 1e-3 relative, per-pixel L2 <= 1e-5 (bar: 1e-3);
+  * every live-reference run: per-pixel L2 <= 1e-3 (the stated bar; measured 0 or ~1e-8);
+  * eNormals image: bit-identical (no transcendental on that path).
 """
 import os
 
@@ -71,12 +72,14 @@ def test_accum_matches_golden(name, pipeline):
     rad, rref = st["radiance"], g["radiance"]
     exact = (rad == rref).all(axis=-1)
     rel = np.abs(rad - rref).max(axis=-1)/np.maximum(1e-3, np.abs(rref).max(axis=-1))
-    assert exact.mean() >= 0.95, "only %.2f %% of paths bit-identical" % (100*exact.mean())
-    assert (rel > 1e-3).mean() <= 1e-3, "%d of %d paths diverge" % ((rel > 1e-3).sum(), rel.size)
-
     l2 = image_l2(out, ref)
-    if name in L2_FIXTURES:
-        assert l2 <= 1e-3, "per-pixel L2 %.3e" % l2
+    if name.endswith("probe"):
+        assert exact.mean() >= 0.99, "only %.2f %% of paths bit-identical" % (100*exact.mean())
+        assert (rel > 1e-3).mean() <= 1e-3, "%d of %d paths diverge" % ((rel > 1e-3).sum(), rel.size)
+        assert l2 <= 1e-5, "per-pixel L2 %.3e" % l2
+    else:
+        assert exact.all(), "%d of %d paths are not bit-identical to the reference" % ((~exact).sum(), exact.size)
+        assert np.array_equal(out, ref), "framebuffer differs from the reference's AddSample (L2 %.3e)" % l2
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -86,10 +89,7 @@ def test_normals_mode(name):
     nopt.mode = abi.MODE_NORMALS
     out, _ = _render(scene, cam, nopt, 1, abi.PIPELINE_WAVEFRONT)
     ref = g["normals"]
-    diff = np.abs(out - ref).max(axis=-1)
-    bad = diff > 2e-5
-    # silhouette / tie pixels may flip hit<->miss or primitive: allow a handful
-    assert bad.mean() <= 2e-3, "%d of %d pixels differ" % (bad.sum(), bad.size)
+    assert np.array_equal(out, ref), "%d pixels differ" % int((np.abs(out - ref).max(axis=-1) > 0).sum())
 
 
 @pytest.mark.parametrize("name", ["features", "features_probe", "glass"])
@@ -158,5 +158,8 @@ def test_against_reference_live(name, W, H, passes, depth):
     R.free(h)
     out, st = _render(scene, cam, opt, passes, abi.PIPELINE_WAVEFRONT, batch=W*H*passes)
     l2 = image_l2(out, ref)
-    print("%s %dx%d spp=%d depth=%d: per-pixel L2 vs live reference = %.3e" % (name, W, H, passes, depth, l2))
+    print("%s %dx%d spp=%d depth=%d: per-pixel L2 vs live reference = %.3e, framebuffer bit-identical: %s" % (
+        name, W, H, passes, depth, l2, np.array_equal(out, ref)))
     assert l2 <= 1e-3, "per-pixel L2 %.3e" % l2
+    if not name.endswith("probe"):
+        assert np.array_equal(out, ref)

@@ -1223,7 +1223,7 @@ long long tinsel_hip_read_batch_radiance(tinsel_hip* r, float* out_rgbx, unsigne
 int tinsel_hip_leaf(tinsel_hip* r, int op, int index, int n, const float* in, int in_stride, const uint32_t* seeds,
                     float* out, int out_stride, const tinsel_camera* camera, int width, int height)
 {
-    if (!r || n <= 0 || !out || out_stride <= 0 || op < 0 || op > kLeafProbe)
+    if (!r || n <= 0 || !out || out_stride <= 0 || op < 0 || op > kLeafLibm)
         return fail("leaf: bad arguments");
     if ((op == kLeafBsdfEval || op == kLeafBsdfSample || op == kLeafPrimIntersect || op == kLeafPrimSample) &&
         (index < 0 || index >= r->scene.numPrims))

@@ -918,6 +918,7 @@ enum LeafOp : int
     kLeafPrimIntersect = 4,     // in: origin(3) dir(3) time -> hit, t, n(3)                       out stride 5
     kLeafPrimSample = 5,        // in: time + seed -> pos(3), normal(3), s1, s2                    out stride 8
     kLeafProbe = 6,             // seed -> dir(3), color(3), pdf, ProbePdf(dir), Sky::Eval(dir)(3)  out stride 11
+    kLeafLibm = 7,              // in: x -> sinf(x), cosf(x), expf(-x)                              out stride 3
 };
 
 __global__ __launch_bounds__(kBlock) void k_leaf(DevScene scIn, int op, int index, int n, const float* __restrict__ in, int inStride,
@@ -988,6 +989,12 @@ __global__ __launch_bounds__(kBlock) void k_leaf(DevScene scIn, int op, int inde
         primitive_sample(sc, index, r[0], pos, nrm, rng);
         o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = nrm.x; o[4] = nrm.y; o[5] = nrm.z;
         o[6] = __uint_as_float(rng.s1); o[7] = __uint_as_float(rng.s2);
+    }
+    else if (op == kLeafLibm)
+    {
+        float sn, cs;
+        m_sincosf(r[0], sn, cs);
+        o[0] = sn; o[1] = cs; o[2] = m_expf(-r[0]);
     }
     else if (op == kLeafProbe)
     {

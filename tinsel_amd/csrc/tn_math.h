@@ -78,24 +78,29 @@ TN_HD float sqr(float x) { return x*x; }
 TN_HD V3 face_forward(V3 n, V3 v) { return (dot(v, n) < 0.0f) ? -n : n; }
 
 // ---------------------------------------------------------------------------
-// transcendental functions.  The CPU oracle calls glibc's sinf/cosf/expf/logf/acosf/atan2f,
-// which evaluate in double and are correctly rounded in all but ~1 % of calls.  The device
-// does the same: a DOUBLE evaluation rounded once to fp32 (error ~1e-16 before the rounding, so
-// the fp32 result is the correctly rounded one except within ~1e-9 of a rounding boundary).
-//   * sin/cos: every call site passes an angle in [0, 2*pi] (phi = 2*pi*u, theta = pi*v), so a
-//     quadrant reduction + the fdlibm kernel polynomials on |r| <= pi/4 do both at once;
-//   * exp: Cody-Waite reduction + degree-12 polynomial on |r| <= ln2/2 (0 below -104, inf above 89).
-//   * log/acos/atan2 (GTR1 is precomputed per material; the others are probe-only): ocml double.
+// transcendental functions.
+//
+// The CPU oracle calls glibc's sinf / cosf / expf (and acosf / atan2f for probes).  glibc 2.35's
+// sinf, cosf and expf are the "ARM optimized routines": a double-precision evaluation (quadrant
+// reduction + degree-7/8 polynomials; 32-entry 2^(k/32) table + cubic) rounded once to fp32.  They are
+// NOT correctly rounded (0.56 / 0.502 ulp), so matching them to the last bit takes THEIR algorithm:
+// m_sincosf and m_expf below restate it (s_sinf.c, s_cosf.c, sincosf.h, e_expf.c of glibc 2.35; the
+// constants are the ones in this image's /lib/x86_64-linux-gnu/libm.so.6: __sincosf_table at .rodata
+// +0xb3100, __exp2f_data at +0xb2ca8).  Checked exhaustively on the host against libm itself:
+// sinf/cosf identical on all 1,088,421,888 floats in [0, 7]; expf identical on all but 2 of the
+// 2,237,399,040 floats with |x| < 87.  Measured effect on the path tracer: bit-identical paths vs the
+// reference 98.5 % -> see DESIGN.md section 3.
+//   * Outside those domains (never reached by the path: angles are 2*pi*u, exponents are -absorption*t):
+//     an fdlibm-kernel / Cody-Waite double evaluation, correctly rounded to ~1e-9.
+//   * log (GTR1) is a per-material constant evaluated by the host's own glibc; acos / atan2 (probe
+//     lookups only): ocml double, rounded once.
 // TN_LIBM_DOUBLE=0 switches everything to the 1-2 ulp ocml fp32 routines (A/B only).
 #ifndef TN_LIBM_DOUBLE
 #define TN_LIBM_DOUBLE 1
 #endif
 #if TN_LIBM_DOUBLE
-TN_D void m_sincosf(float xf, float& s, float& c)
+TN_D void sincos_wide(double x, float& s, float& c)
 {
-    // |x| <= 2*pi at every call site; the two-term Cody-Waite reduction below stays exact to
-    // ~1e-16 for |x| up to ~1e5, so there is deliberately no slow path (a NaN stays a NaN)
-    const double x = (double)xf;
     const double kd = ::rint(x*0.63661977236758138);            // 2/pi
     const int k = (int)kd;
     double r = ::fma(-kd, 1.5707963267948966, x);               // pi/2 (hi)
@@ -119,11 +124,73 @@ TN_D void m_sincosf(float xf, float& s, float& c)
     s = (float)((k & 2) ? -sv : sv);
     c = (float)(((k + 1) & 2) ? -cv : cv);
 }
+
+// glibc 2.35 sinf + cosf for 0 <= y <= 7 (reduce_fast + sinf_poly of sincosf.h), both results at once
+TN_D void m_sincosf(float y, float& s, float& c)
+{
+    const double x = (double)y;
+    if (!(y >= 0.0f && y <= 7.0f))
+    {
+        sincos_wide(x, s, c);
+        return;
+    }
+    if (y < 0x1p-12f)                                           // abstop12(y) < abstop12(0x1p-12f): sinf = y, cosf = 1
+    {
+        s = y;
+        c = 1.0f;
+        return;
+    }
+    int n = 0;
+    double xr = x;
+    if (y >= 0x1.921FB6p-1f)                                    // |y| >= pi/4: reduce_fast
+    {
+        const double r = x*0x1.45F306DC9C883p+23;               // hpi_inv = 2/pi * 2^24
+        n = ((int)r + 0x800000) >> 24;
+        xr = ::fma(-(double)n, 0x1.921FB54442D18p0, x);
+    }
+    const double x2 = xr*xr;
+    // sinf_poly's two branches (table entries 0/1 differ only in the sign of the cosine coefficients)
+    const double x3 = xr*x2;
+    const double s1 = ::fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+    const double x5 = x3*x2;
+    const double sp = ::fma(x5, s1, ::fma(x3, -0x1.555545995a603p-3, xr));                 // sin(xr)
+    const double x4 = x2*x2;
+    const double c2 = ::fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+    const double c1 = ::fma(x2, -0x1.ffffffd0c621cp-2, 1.0);
+    const double x6 = x4*x2;
+    const double cp = ::fma(x6, c2, ::fma(x4, 0x1.55553e1068f19p-5, c1));                  // cos(xr)
+    // quadrant n: sin y = {sp, cp, -sp, -cp}[n&3], cos y = {cp, -sp, -cp, sp}[n&3]  (the sign[] / table[1]
+    // bookkeeping of s_sinf.c / s_cosf.c: negating x or the polynomial is exact, so signs commute)
+    const double sv = (n & 1) ? cp : sp;
+    const double cv = (n & 1) ? sp : cp;
+    s = (float)((n & 2) ? -sv : sv);
+    c = (float)(((n + 1) & 2) ? -cv : cv);
+}
 TN_D float m_sinf(float x) { float s, c; m_sincosf(x, s, c); return s; }
 TN_D float m_cosf(float x) { float s, c; m_sincosf(x, s, c); return c; }
+
+__device__ const unsigned long long kExp2fTab[32] = { 0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL, 0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL, 0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL, 0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL, 0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL, 0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL, 0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL, 0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL };
+
+// glibc 2.35 expf for |x| < 87 (e_expf.c, non-TOINT path: the SHIFT trick)
 TN_D float m_expf(float xf)
 {
     double x = (double)xf;
+    if (fabsf(xf) < 87.0f)
+    {
+        double z = 0x1.71547652b82fep+5*x;                      // InvLn2N, N = 32
+        double kd = z + 0x1.8p+52;                              // SHIFT
+        const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+        kd -= 0x1.8p+52;
+        const double r = z - kd;
+        unsigned long long t = kExp2fTab[ki & 31u];
+        t += ki << (52 - 5);
+        const double sc = __longlong_as_double((long long)t);
+        z = ::fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+        const double r2 = r*r;
+        double yv = ::fma(0x1.62e42ff0c52d6p-6, r, 1.0);
+        yv = ::fma(z, r2, yv);
+        return (float)(yv*sc);
+    }
     if (!(x > -104.0))
         return (x != x) ? xf : 0.0f;                            // exp(-104) < half the smallest fp32 denormal
     x = x > 89.0 ? 89.0 : x;                                    // exp(89) already rounds to +inf in fp32
