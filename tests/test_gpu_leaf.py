@@ -145,14 +145,15 @@ def test_probe_sample_pdf_eval():
     # direction of a texel CORNER (u = col/W exactly, probe.h:224-225), i.e. this feeds them the worst case:
     # a 1-ulp uv lands on the neighbouring texel.  Measured agreement 98.2 %; in a render these functions see
     # BSDF-sampled directions, not corners.
-    _close(out[:, 7], pdf2, "ProbePdf(dir)", frac=0.97)
-    _close(out[:, 8:11], ev, "Sky::Eval(dir)", frac=0.97)
+    _close(out[:, 7], pdf2, "ProbePdf(dir)", frac=0.9999)
+    _close(out[:, 8:11], ev, "Sky::Eval(dir)", frac=0.9999)
     r.close(); R.free(h)
 
 
 def test_device_libm_is_glibc_bit_for_bit():
-    """sinf / cosf / expf on the device restate glibc 2.35's algorithms (tn_math.h): every one of 4 M angles in
-    [0, 2*pi] and exponents in [-80, 0] must equal THIS host's libm to the last bit."""
+    """sinf / cosf / expf / acosf / atan2f on the device restate glibc 2.35's algorithms (tn_math.h): every one of
+    4 M angles in [0, 2*pi], exponents in [-80, 0], cosines in [-1, 1] and (y, x) pairs must equal THIS host's
+    libm to the last bit."""
     scene, r, R, h = _setup("cornell")
     libm = C.CDLL("libm.so.6")
     for f in (libm.sinf, libm.cosf, libm.expf):
@@ -162,17 +163,23 @@ def test_device_libm_is_glibc_bit_for_bit():
     n = 4_000_000
     x = np.concatenate([(rng.random(n//2)*2*np.pi), rng.random(n//4)*80.0, rng.random(n//4)*1e-2]).astype(np.float32)
     x[:8] = [0.0, 1e-30, 2.0**-12, np.float32(np.pi/4), np.float32(np.pi/2), np.float32(np.pi), np.float32(2*np.pi), 6.2831855]
-    out = r.leaf(7, 0, len(x), 3, rows=x[:, None])
+    yv = (rng.random(len(x))*2 - 1).astype(np.float32)
+    yv[:4] = [1.0, -1.0, 0.0, 0.5]
+    out = r.leaf(7, 0, len(x), 5, rows=np.stack([x, yv], axis=1))
     # vectorised host libm through numpy would not be glibc's scalar routine: call it per element on a sample,
     # and on everything through a tiny C loop compiled here
     import subprocess, tempfile
-    src = "#include <math.h>\nvoid f(int n,const float*x,float*o){for(int i=0;i<n;i++){o[3*i]=sinf(x[i]);o[3*i+1]=cosf(x[i]);o[3*i+2]=expf(-x[i]);}}"
+    src = "#include <math.h>\nvoid f(int n,const float*x,const float*y,float*o){for(int i=0;i<n;i++){o[5*i]=sinf(x[i]);o[5*i+1]=cosf(x[i]);o[5*i+2]=expf(-x[i]);o[5*i+3]=acosf(y[i]);o[5*i+4]=atan2f(y[i],x[i]-3.0f);}}"
     d = tempfile.mkdtemp()
     open(os.path.join(d, "l.c"), "w").write(src)
     subprocess.run(["gcc", "-O1", "-fno-builtin", "-shared", "-fPIC", "-o", os.path.join(d, "l.so"), os.path.join(d, "l.c"), "-lm"], check=True)
     L = C.CDLL(os.path.join(d, "l.so"))
-    ref = np.zeros((len(x), 3), np.float32)
-    L.f(len(x), x.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p))
+    ref = np.zeros((len(x), 5), np.float32)
+    L.f(len(x), x.ctypes.data_as(C.c_void_p), yv.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p))
+    bad_a = int((out[:, 3].view(np.uint32) != ref[:, 3].view(np.uint32)).sum())
+    bad_t = int((out[:, 4].view(np.uint32) != ref[:, 4].view(np.uint32)).sum())
+    print("acosf mismatches %d, atan2f %d of %d" % (bad_a, bad_t, len(x)))
+    assert bad_a == 0 and bad_t == 0
     ang = x <= 7.0
     bad_s = int((out[ang, 0] != ref[ang, 0]).sum()); bad_c = int((out[ang, 1] != ref[ang, 1]).sum())
     bad_e = int((out[:, 2] != ref[:, 2]).sum())

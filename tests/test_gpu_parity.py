@@ -5,12 +5,10 @@ committed golden fixtures generated from it (tests/golden/*.golden.npz) -- same 
 
 Tolerances.  The north_star bar is per-pixel L2 <= 1e-3 of rgb/w against the CPU reference on identical
 seeds.  The HIP path does far better, and the tests hold it to what it actually achieves:
-  * scenes WITHOUT an environment probe: per-path radiance AND the accumulated framebuffer must be
-    BIT-IDENTICAL to the reference's PathTrace / AddSample (the device restates the reference's fp32
-    operation order and glibc's sinf/cosf/expf algorithms, DESIGN.md section 3);
-  * scenes WITH a probe (acosf/atan2f in ProbePdf are ocml-double, not glibc's): >= 99 % of paths
-    bit-identical, <= 1e-3 of paths off by more than 1e-3 relative, per-pixel L2 <= 1e-5 (bar: 1e-3);
-  * every live-reference run: per-pixel L2 <= 1e-3 (the stated bar; measured 0 or ~1e-8);
+  * every fixture: per-path radiance AND the accumulated framebuffer must be BIT-IDENTICAL to the
+    reference's PathTrace / AddSample (the device restates the reference's fp32 operation order and
+    glibc 2.35's sinf/cosf/expf/acosf/atan2f algorithms, DESIGN.md section 3);
+  * every live-reference run: per-pixel L2 <= 1e-3 (the stated bar) AND bit-identical framebuffer;
   * eNormals image: bit-identical (no transcendental on that path).
 """
 import os
@@ -73,13 +71,10 @@ def test_accum_matches_golden(name, pipeline):
     exact = (rad == rref).all(axis=-1)
     rel = np.abs(rad - rref).max(axis=-1)/np.maximum(1e-3, np.abs(rref).max(axis=-1))
     l2 = image_l2(out, ref)
-    if name.endswith("probe"):
-        assert exact.mean() >= 0.99, "only %.2f %% of paths bit-identical" % (100*exact.mean())
-        assert (rel > 1e-3).mean() <= 1e-3, "%d of %d paths diverge" % ((rel > 1e-3).sum(), rel.size)
-        assert l2 <= 1e-5, "per-pixel L2 %.3e" % l2
-    else:
-        assert exact.all(), "%d of %d paths are not bit-identical to the reference" % ((~exact).sum(), exact.size)
-        assert np.array_equal(out, ref), "framebuffer differs from the reference's AddSample (L2 %.3e)" % l2
+    assert l2 <= 1e-3, "per-pixel L2 %.3e (north_star bar)" % l2
+    assert exact.all(), "%d of %d paths are not bit-identical to the reference (%d off by > 1e-3)" % (
+        (~exact).sum(), exact.size, (rel > 1e-3).sum())
+    assert np.array_equal(out, ref), "framebuffer differs from the reference's AddSample (L2 %.3e)" % l2
 
 
 @pytest.mark.parametrize("name", SCENES)
@@ -161,5 +156,4 @@ def test_against_reference_live(name, W, H, passes, depth):
     print("%s %dx%d spp=%d depth=%d: per-pixel L2 vs live reference = %.3e, framebuffer bit-identical: %s" % (
         name, W, H, passes, depth, l2, np.array_equal(out, ref)))
     assert l2 <= 1e-3, "per-pixel L2 %.3e" % l2
-    if not name.endswith("probe"):
-        assert np.array_equal(out, ref)
+    assert np.array_equal(out, ref)

@@ -918,7 +918,7 @@ enum LeafOp : int
     kLeafPrimIntersect = 4,     // in: origin(3) dir(3) time -> hit, t, n(3)                       out stride 5
     kLeafPrimSample = 5,        // in: time + seed -> pos(3), normal(3), s1, s2                    out stride 8
     kLeafProbe = 6,             // seed -> dir(3), color(3), pdf, ProbePdf(dir), Sky::Eval(dir)(3)  out stride 11
-    kLeafLibm = 7,              // in: x -> sinf(x), cosf(x), expf(-x)                              out stride 3
+    kLeafLibm = 7,              // in: x, y -> sinf(x), cosf(x), expf(-x), acosf(y), atan2f(y, x - 3)  out stride 5
 };
 
 __global__ __launch_bounds__(kBlock) void k_leaf(DevScene scIn, int op, int index, int n, const float* __restrict__ in, int inStride,
@@ -995,6 +995,7 @@ __global__ __launch_bounds__(kBlock) void k_leaf(DevScene scIn, int op, int inde
         float sn, cs;
         m_sincosf(r[0], sn, cs);
         o[0] = sn; o[1] = cs; o[2] = m_expf(-r[0]);
+        o[3] = m_acosf(r[1]); o[4] = m_atan2f(r[1], r[0] - 3.0f);
     }
     else if (op == kLeafProbe)
     {
