@@ -1,0 +1,106 @@
+"""BASELINE.json configs at their FULL frame sizes.
+
+The full renders are far beyond what the CPU oracle can produce in a test (config 5 is 3.4e10 samples), so
+each config is checked through size-independent properties:
+  * a 96x96 WINDOW of the full-resolution frame, at an arbitrary pass index, must be bit-identical per path to
+    the oracle's PathTrace on the same seeds (seeds depend on the full-frame pixel index, so this exercises the
+    real camera, the real seed contract and the real batch geometry of the big frame);
+  * the pass loop is a pure function of (pixel, pass): rendering passes [a, b) then [b, c) equals [a, c) bitwise,
+    and two renderers give the same bits (no atomics, no scheduling dependence);
+  * the filter-weight channel depends on the camera sample only: it must equal the oracle's on the window interior.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tinsel_amd import abi
+from tests import oracle_api as oa
+
+pytestmark = pytest.mark.gpu
+
+LARGE = os.path.join(oa.GOLDEN, "large", "ajax_standin.pack")
+
+CONFIGS = [
+    # name, pack, W, H, maxDepth, window origin
+    ("cfg2 cornell 1024x1024", "cornell", 1024, 1024, 4, (400, 500)),
+    ("cfg4 glass 1920x1080 depth 12", "glass", 1920, 1080, 12, (900, 500)),
+    ("cfg5 veach 3840x2160", "veach", 3840, 2160, 4, (1800, 1200)),
+    ("cfg3 ajax stand-in 18k tris 1920x1080", "ajax_standin_96", 1920, 1080, 4, (900, 480)),
+]
+
+
+def _oracle():
+    if oa.have_ref():
+        return oa.RefOracle()
+    if not oa.have_port():
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(oa.ROOT, "oracle"), "port"], check=True)
+    return oa.PortOracle()
+
+
+@pytest.mark.parametrize("label,pack,W,H,depth,origin", CONFIGS, ids=[c[0].split()[0] for c in CONFIGS])
+def test_full_frame_window_is_bit_identical(label, pack, W, H, depth, origin):
+    import tinsel_amd
+    path = os.path.join(oa.GOLDEN, pack + ".pack")
+    scene = tinsel_amd.Scene.load_pack(path)
+    cam, opt = scene.camera, scene.options.copy()
+    opt.width, opt.height, opt.max_depth, opt.mode = W, H, depth, abi.MODE_PATHTRACE
+    x0, y0 = origin
+    win = (x0, y0, x0 + 96, y0 + 96)
+    pass_index = 5
+
+    r = tinsel_amd.create_gpu_renderer(scene)
+    r.init(W, H)
+    r.set_pass_index(pass_index)
+    r.render(cam, opt, passes=1, readback=False)
+    rad = r.batch_radiance(1, H, W)[0, y0:y0 + 96, x0:x0 + 96]
+    acc = r.read_accum()
+    r.close()
+
+    O = _oracle()
+    h = O.load_pack(path)
+    oacc, orad, _ = O.render_seeded(h, cam, opt, pass_index, 1, window=win, want_radiance=True)
+    O.free(h)
+
+    exact = (rad == orad[0]).all(axis=-1)
+    assert exact.all(), "%s: %d of %d window paths differ from the oracle" % (label, (~exact).sum(), exact.size)
+    # interior of the window (footprint radius <= 2 px): accumulated pixels only receive window paths
+    inner = (slice(y0 + 3, y0 + 93), slice(x0 + 3, x0 + 93))
+    assert np.array_equal(acc[inner], oacc[inner]), label
+
+
+def test_pass_ranges_compose_bitwise():
+    import tinsel_amd
+    scene = tinsel_amd.Scene.load_pack(os.path.join(oa.GOLDEN, "cornell.pack"))
+    cam, opt = scene.camera, scene.options.copy()
+    opt.width = opt.height = 1024
+    a = tinsel_amd.create_gpu_renderer(scene); a.init(1024, 1024)
+    a.render(cam, opt, passes=5, readback=False)
+    a.render(cam, opt, passes=7, readback=False)
+    b = tinsel_amd.create_gpu_renderer(scene); b.init(1024, 1024)
+    b.set_batch_paths(1 << 20)
+    out_b = b.render(cam, opt, passes=12)
+    out_a = a.read_accum()
+    a.close(); b.close()
+    assert np.array_equal(out_a, out_b)
+    assert np.isfinite(out_a).all() and (out_a[..., 3] > 0).all()
+
+
+@pytest.mark.skipif(not os.path.exists(LARGE), reason="tests/golden/large/ajax_standin.pack not generated (make_large.py)")
+def test_cfg3_524k_triangle_standin_window():
+    import tinsel_amd
+    scene = tinsel_amd.Scene.load_pack(LARGE)
+    cam, opt = scene.camera, scene.options.copy()
+    opt.width, opt.height, opt.max_depth = 1920, 1080, 4
+    r = tinsel_amd.create_gpu_renderer(scene)
+    assert r.stack_entries >= 24
+    r.init(1920, 1080)
+    r.render(cam, opt, passes=1, readback=False)
+    rad = r.batch_radiance(1, 1080, 1920)[0, 480:576, 900:996]
+    r.close()
+    O = _oracle()
+    h = O.load_pack(LARGE)
+    _, orad, _ = O.render_seeded(h, cam, opt, 0, 1, window=(900, 480, 996, 576), want_accum=False, want_radiance=True)
+    O.free(h)
+    assert np.array_equal(rad, orad[0])
