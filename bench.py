@@ -111,7 +111,7 @@ def main():
     r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
     if world > 1:
         r.set_shard(rank, world, args.tile)
-        r.set_batch_paths((4 << 20)*world)       # keep the same number of LIVE paths per batch as N = 1
+        r.set_batch_paths((8 << 20)*world)       # keep the same number of LIVE paths per batch as N = 1
     accum = torch.zeros((opt.height, opt.width, 4), dtype=torch.float32, device="cuda")
     r.init(opt.width, opt.height, accum_tensor=accum)
     stream = torch.cuda.current_stream().cuda_stream

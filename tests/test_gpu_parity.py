@@ -157,3 +157,26 @@ def test_against_reference_live(name, W, H, passes, depth):
         name, W, H, passes, depth, l2, np.array_equal(out, ref)))
     assert l2 <= 1e-3, "per-pixel L2 %.3e" % l2
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libtinsel_ref.so")),
+                    reason="oracle/_ref not built")
+@pytest.mark.parametrize("ftype,width,falloff", [(0, 1.0, 2.0), (0, 2.0, 2.0), (1, 0.5, 2.0), (1, 1.0, 2.0), (1, 1.5, 1.0),
+                                                 (1, 2.0, 0.5), (1, 2.5, 0.5), (1, 3.0, 1.0)],
+                         ids=["box1", "box2", "gauss0.5", "gauss1", "gauss1.5", "gauss2", "gauss2.5", "gauss3"])
+@pytest.mark.parametrize("W,H", [(64, 64), (70, 37)])
+def test_filter_footprints(ftype, width, falloff, W, H):
+    """AddSample footprints (render.cpp:401-445) for box and Gaussian filters of several widths, frame sizes that
+    are and are not multiples of the accumulate tile: framebuffer incl. the weight channel bit-identical.
+    Widths <= 2 take the LDS-tiled gather (separable per-path weights), wider ones the per-pixel gather."""
+    from tests.oracle_api import RefOracle
+    R = RefOracle()
+    scene, cam, opt, g = _load("cornell")
+    opt.width, opt.height = W, H
+    opt.filter = R.make_filter(ftype, width, falloff)
+    h = R.load_pack(os.path.join(GOLDEN, "cornell.pack"))
+    ref, _, _ = R.render_seeded(h, cam, opt, 0, 3)
+    R.free(h)
+    for pipeline in (abi.PIPELINE_WAVEFRONT, abi.PIPELINE_WAVEFRONT_SPLIT, abi.PIPELINE_MEGAKERNEL):
+        out, _ = _render(scene, cam, opt, 3, pipeline)
+        assert np.array_equal(out, ref), "pipeline %d" % pipeline

@@ -268,7 +268,7 @@ struct tinsel_hip
     unsigned long long* statsDev = nullptr;
 
     size_t lastBatchSlots = 0;
-    size_t maxBatchSlots = 4u << 20;
+    size_t maxBatchSlots = 8u << 20;
     int pipeline = TINSEL_PIPELINE_AUTO;
     bool countDetail = false;
 
@@ -556,8 +556,17 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
 
     {
         ScopedTimer t(r, KN_ACCUMULATE, st);
-        const int gridPix = (int)((npix + kBlock - 1)/kBlock);
-        hipLaunchKernelGGL(k_accumulate, dim3(gridPix), dim3(kBlock), 0, st, r->ps, fp, r->accum);
+        const int halo = 1 + (int)floorf(fp.filterWidth) + (int)ceilf(fp.filterWidth);
+        if (halo <= kAccMaxHalo && fp.filterWidth >= 0.0f && fp.width < 65536 && fp.height < 65536)
+        {
+            const int tiles = ((fp.width + kAccTile - 1)/kAccTile)*((fp.height + kAccTile - 1)/kAccTile);
+            hipLaunchKernelGGL(k_accumulate_tiled, dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, r->accum, r->passSeedsDev);
+        }
+        else
+        {
+            const int gridPix = (int)((npix + kBlock - 1)/kBlock);
+            hipLaunchKernelGGL(k_accumulate, dim3(gridPix), dim3(kBlock), 0, st, r->ps, fp, r->accum);
+        }
     }
     HIP_TRY(hipGetLastError());
     return 0;

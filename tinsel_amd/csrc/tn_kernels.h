@@ -869,6 +869,124 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FramePar
     accum[pix] = acc;
 }
 
+// k_accumulate_tiled: the same gather, one 16x16 pixel tile per block.  Per pass the block stages the
+// (16 + halo)^2 candidate paths of its tile into LDS once -- raster position and the ALREADY CLAMPED sample
+// (ClampLength is per path, render.cpp:412/431, not per covered pixel) -- instead of every pixel re-reading
+// its 16 candidates from L2.  HBM traffic: one 16-B radiance record per path.  Same adds, same order; used when the footprint halo fits (filter width <= 2).
+
+constexpr int kAccTile = 16;
+constexpr int kAccMaxHalo = 5;      // reachLo + reachHi
+constexpr int kAccSide = kAccTile + kAccMaxHalo;
+constexpr int kAccEntries = kAccSide*kAccSide;
+constexpr int kAccMaxFoot = 5;      // widest footprint (pixels per axis) for filter widths <= 2
+
+__global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, FrameParams fp, float4* __restrict__ accum,
+                                                                const uint32_t* __restrict__ passSeeds)
+{
+    // per candidate path of the tile: clamped sample, footprint [startX, startX+nX) x [startY, startY+nY)
+    // and the separable Gaussian weights of its footprint columns / rows (each shared by up to 5 pixels)
+    __shared__ float4 s_c[kAccEntries];                 // rgb, .w = bits(startX | nX << 16)
+    __shared__ uint32_t s_y[kAccEntries];               // startY | nY << 16
+    __shared__ float s_wx[kAccMaxFoot][kAccEntries];
+    __shared__ float s_wy[kAccMaxFoot][kAccEntries];
+
+    const int tilesX = (fp.width + kAccTile - 1)/kAccTile;
+    const int tx = blockIdx.x % tilesX, ty = blockIdx.x/tilesX;
+    const int lx = threadIdx.x % kAccTile, ly = threadIdx.x/kAccTile;
+    const int px = tx*kAccTile + lx, py = ty*kAccTile + ly;
+    const bool inside = px < fp.width && py < fp.height;
+
+    const float fw = fp.filterWidth;
+    const int reachLo = 1 + (int)floorf(fw);
+    const int reachHi = (int)ceilf(fw);
+    const int side = kAccTile + reachLo + reachHi;
+    const int ox = tx*kAccTile - reachLo, oy = ty*kAccTile - reachLo;     // frame coordinates of LDS entry (0,0)
+    const int npix = fp.width*fp.height;
+    const bool gauss = fp.filterType != 0;
+
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (inside)
+        acc = accum[py*fp.width + px];
+
+    // this pixel's candidate window, in LDS coordinates (clipped to the frame like the reference's loops)
+    const int i0 = maxI(0, px - reachLo) - ox, i1 = minI(fp.width - 1, px + reachHi) - ox;
+    const int j0 = maxI(0, py - reachLo) - oy, j1 = minI(fp.height - 1, py + reachHi) - oy;
+
+    for (int s = 0; s < fp.numPasses; ++s)
+    {
+        const size_t passBase = (size_t)s*npix;
+        for (int e = threadIdx.x; e < side*side; e += kBlock)
+        {
+            const int ex = e % side, ey = e/side;
+            const int gx = ox + ex, gy = oy + ey;
+            const int le = ey*kAccSide + ex;
+            float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // nX == 0: covers nothing
+            uint32_t ym = 0;
+            if (gx >= 0 && gy >= 0 && gx < fp.width && gy < fp.height && pixel_owned(fp, gx, gy))
+            {
+                // the raster position is the first two draws of the path's own stream (camera_sample):
+                // two LCG steps are cheaper than reading it back from the 16-B rngRaster record
+                Rng rng = Rng::seeded((uint32_t)gx + (uint32_t)gy*(uint32_t)fp.width + passSeeds[fp.passBase + s]);
+                const float x = rng.randf();
+                const float y = rng.randf();
+                const float rx = x + gx, ry = y + gy;
+                const float4 ra = ps.rad[passBase + (size_t)gy*fp.width + gx];
+                const V3 cl = clamp_length(V3(ra.x, ra.y, ra.z), fp.clampLen);
+
+                const int startX = maxI(0, int(rx - fw));
+                const int startY = maxI(0, int(ry - fw));
+                const int endX = minI(int(rx + fw), fp.width - 1);
+                const int endY = minI(int(ry + fw), fp.height - 1);
+                const int nX = maxI(0, endX - startX + 1), nY = maxI(0, endY - startY + 1);
+                c = make_float4(cl.x, cl.y, cl.z, __uint_as_float((uint32_t)startX | (uint32_t)nX << 16));
+                ym = (uint32_t)startY | (uint32_t)nY << 16;
+                if (gauss)
+                {
+                    for (int k = 0; k < kAccMaxFoot; ++k)
+                    {
+                        if (k < nX)
+                            s_wx[k][le] = filter_gauss((startX + k) - rx, fp.filterFalloff, fp.filterOffset);
+                        if (k < nY)
+                            s_wy[k][le] = filter_gauss((startY + k) - ry, fp.filterFalloff, fp.filterOffset);
+                    }
+                }
+            }
+            s_c[le] = c;
+            s_y[le] = ym;
+        }
+        __syncthreads();
+
+        if (inside)
+        {
+            for (int j = j0; j <= j1; ++j)
+            {
+                for (int i = i0; i <= i1; ++i)
+                {
+                    const int le = j*kAccSide + i;
+                    const float4 c = s_c[le];
+                    const uint32_t xm = __float_as_uint(c.w), ym = s_y[le];
+                    const uint32_t kx = (uint32_t)(px - (int)(xm & 0xffffu)), ky = (uint32_t)(py - (int)(ym & 0xffffu));
+                    if (kx >= (xm >> 16) || ky >= (ym >> 16))
+                        continue;
+                    if (!gauss)
+                    {
+                        acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
+                    }
+                    else
+                    {
+                        const float w = s_wx[kx][le]*s_wy[ky][le];
+                        acc.x += c.x*w; acc.y += c.y*w; acc.z += c.z*w; acc.w += w;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (inside)
+        accum[py*fp.width + px] = acc;
+}
+
 // ---------------------------------------------------------------------------
 // k_normals: eNormals mode of the CPU renderer (render.cpp:494-515): x=i, y=j, time 1, overwrite.
 
