@@ -208,6 +208,29 @@ float* tinsel_hip_accum_device_ptr(tinsel_hip* r);
 /* Blocking copy of the accumulator to host (W*H*4 floats). */
 int tinsel_hip_read_accum(tinsel_hip* r, float* out_rgba);
 
+/* Resume a progressive render: replaces the accumulator with a saved one (W*H*4 floats, as read_accum returned
+ * it) and sets the index of the next pass, so that `read_accum after k passes` + `write_accum(.., k)` + more passes
+ * gives the same image bit for bit as one uninterrupted render (pass seeds depend on the pass index only). */
+int tinsel_hip_write_accum(tinsel_hip* r, const float* rgba, uint32_t next_pass_index);
+
+/* ---- display stage: what main.cpp does with the accumulator every frame (main.cpp:258-282) ----
+ *
+ * g_filtered[i] = LinearToSrgb(ToneMap(g_pixels[i]*(exposure/g_pixels[i].w), limit))   util.h:25-42, maths.h:1545-1555
+ * and, when nlm_width != 0, NonLocalMeansFilter(g_filtered, g_exposed, W, H, nlm_falloff, nlm_width)  (nlm.cpp:35-77;
+ * main.cpp:59-60 defaults: width 0 = off, falloff 200).  Runs on the device accumulator (the sum of all passes since
+ * Init); options->mode != ePathTrace presents the raw accumulator, as the reference does.  The float image is
+ * bit-identical to the host code's (same operation order; powf/expf as glibc 2.35 evaluates them).
+ * out_rgba (W*H*4 floats, the array main.cpp hands to glDrawPixels / WritePng) may be NULL. */
+int tinsel_hip_present(tinsel_hip* r, const tinsel_options* options, int nlm_width, float nlm_falloff, float* out_rgba);
+int tinsel_hip_present_async(tinsel_hip* r, const tinsel_options* options, int nlm_width, float nlm_falloff, void* stream);
+/* Device pointer to the most recently presented W*H*4 float image. */
+const float* tinsel_hip_present_device_ptr(tinsel_hip* r);
+
+/* WritePng's float -> 8-bit RGB conversion (png.cpp:323-343): x*255 + Randf + Randf - 0.5 from ONE default-seeded
+ * serial Random stream over all pixels and channels, clamped and truncated.  Host code (the generator has no
+ * skip-ahead); rgb receives W*H*3 bytes, top row first -- the payload of the PNG the reference writes. */
+int tinsel_image_quantize_rgb8(const float* rgba, int width, int height, unsigned char* rgb);
+
 /* Pixel-tile sharding for multi-GPU: this renderer traces only paths whose
  * generating pixel lies in a tile t with (t % world) == rank, tiles of
  * `tile`x`tile` pixels in raster order.  Seeds depend on (pixel, pass) only, so
@@ -257,7 +280,8 @@ long long tinsel_hip_read_batch_radiance(tinsel_hip* r, float* out_rgbx, unsigne
 /* Test hook: evaluates one device leaf function on caller arrays (host pointers; rows of `in_stride` /
  * `out_stride` floats, one thread per row) so tests can table the HIP restatements against the reference's
  * inline functions.  op: 0 Random, 1 CameraSampler::GenerateRay, 2 BSDFEval+BSDFPdf, 3 BSDFSample,
- * 4 PrimitiveIntersect, 5 PrimitiveSample, 6 ProbeSample/ProbePdf/Sky::Eval (row layouts: tn_kernels.h LeafOp).
+ * 4 PrimitiveIntersect, 5 PrimitiveSample, 6 ProbeSample/ProbePdf/Sky::Eval, 7 libm restatements,
+ * 8 display-stage functions (row layouts: tn_kernels.h LeafOp).
  * `index` = primitive (its material for ops 2,3). */
 int tinsel_hip_leaf(tinsel_hip* r, int op, int index, int n, const float* in, int in_stride, const uint32_t* seeds,
                     float* out, int out_stride, const tinsel_camera* camera, int width, int height);

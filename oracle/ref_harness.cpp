@@ -25,6 +25,9 @@
 #include "loader.h"
 #include "mesh.h"
 #include "scene.h"
+#include "nlm.h"
+#include "png.h"
+#include "pfm.h"
 
 #include "../include/tinsel_hip.h"
 
@@ -682,6 +685,45 @@ void ref_leaf_probe(void* h, int n, const uint32_t* seeds, float* outDir, float*
         Vec3 e = sky.Eval(dir);
         memcpy(outEvalOfDir + i*3, &e, 12);
     }
+}
+
+// ---------------------------------------------------------------------------
+// display stage: the per-frame post-processing of main.cpp:258-282 and the image writers
+
+// g_filtered[i] = LinearToSrgb(ToneMap(g_pixels[i]*(exposure/w), limit))  -- main.cpp:262-271
+void ref_present(const float* pixels, int numPixels, float exposure, float limit, float* filtered)
+{
+    const Color* in = (const Color*)pixels;
+    Color* out = (Color*)filtered;
+    for (int i = 0; i < numPixels; ++i)
+    {
+        float s = exposure/in[i].w;
+        out[i] = LinearToSrgb(ToneMap(in[i]*s, limit));
+    }
+}
+
+// NonLocalMeansFilter (nlm.cpp:35-77), as main.cpp:273-277 calls it
+void ref_nlm(const float* in, float* out, int width, int height, float falloff, int radius)
+{
+    NonLocalMeansFilter((const Color*)in, (Color*)out, width, height, falloff, radius);
+}
+
+// WritePng (png.cpp:323-371) / PfmSave (pfm.cpp:70-85) to `path`
+void ref_write_png(const float* pixels, int width, int height, const char* path)
+{
+    WritePng((const Color*)pixels, width, height, path);
+}
+
+void ref_pfm_save(const float* rgb, int width, int height, const char* path)
+{
+    PfmImage image;
+    memset(&image, 0, sizeof(image));
+    image.width = width;
+    image.height = height;
+    image.depth = 1;
+    image.data = const_cast<float*>(rgb);
+    PfmSave(path, image);
+    fflush(NULL);       // PfmSave never closes its FILE (pfm.cpp:70-85)
 }
 
 int ref_hardware_threads() { return (int)std::thread::hardware_concurrency(); }

@@ -1309,3 +1309,103 @@ void port_render_normals(void* h, const tinsel_camera* cam, const tinsel_options
             }
         }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Display stage: what main.cpp does with the accumulated pixels every frame (main.cpp:258-282)
+ * and the 8-bit conversion of WritePng (png.cpp:323-343).  powf / expf are the host libm's.
+ * ------------------------------------------------------------------------------------------- */
+
+static float max_t(float a, float b) { return (a < b) ? b : a; }                              /* maths.h:58-59 */
+static float min_t(float a, float b) { return (a < b) ? a : b; }                              /* maths.h:55-56 */
+
+/* ToneMap (util.h:25-42): filmic curve per channel, then SrgbToLinear (maths.h:1551-1555) */
+static float tonemap_channel(float c)
+{
+    float x = max_t(0.0f, c - 0.004f);
+    float num = x*(6.2f*x + 0.5f);
+    float den = x*(6.2f*x + 1.7f) + 0.06f;     /* Vec3(0.06): the double literal narrows in the float ctor */
+    return powf(num/den, 2.2f);
+}
+
+/* g_filtered[i] = LinearToSrgb(ToneMap(g_pixels[i]*(exposure/w), limit))   main.cpp:262-271 */
+void port_present(const float* pixels, int numPixels, float exposure, float limit, float* filtered)
+{
+    const float kInvGamma = 1.0f/2.2f;                                                         /* maths.h:1547 */
+    (void)limit;                                                                               /* only the disabled Reinhard curve read it */
+    for (int i = 0; i < numPixels; ++i)
+    {
+        const float* p = pixels + 4*i;
+        float s = exposure/p[3];
+        filtered[4*i + 0] = powf(tonemap_channel(p[0]*s), kInvGamma);
+        filtered[4*i + 1] = powf(tonemap_channel(p[1]*s), kInvGamma);
+        filtered[4*i + 2] = powf(tonemap_channel(p[2]*s), kInvGamma);
+        filtered[4*i + 3] = powf(0.0f, 2.2f);  /* ToneMap rebuilds the colour with w = 0; LinearToSrgb keeps w */
+    }
+}
+
+/* AverageFilter + NonLocalMeansFilter (nlm.cpp:4-77): windows clipped to the image, walked column by column */
+void port_nlm(const float* in, float* out, int width, int height, float falloff, int radius)
+{
+    float* means = (float*)malloc(sizeof(float)*4*(size_t)width*height);
+    for (int y = 0; y < height; ++y)
+    {
+        for (int x = 0; x < width; ++x)
+        {
+            int xlower = x - radius > 0 ? x - radius : 0, xupper = x + radius < width - 1 ? x + radius : width - 1;
+            int ylower = y - radius > 0 ? y - radius : 0, yupper = y + radius < height - 1 ? y + radius : height - 1;
+            int count = 0;
+            float sum[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int fx = xlower; fx <= xupper; ++fx)
+                for (int fy = ylower; fy <= yupper; ++fy)
+                {
+                    for (int c = 0; c < 4; ++c)
+                        sum[c] = sum[c] + in[4*(fy*width + fx) + c];
+                    count += 1;
+                }
+            float rc = 1.0f/count;
+            for (int c = 0; c < 4; ++c)
+                means[4*(y*width + x) + c] = sum[c]*rc;
+        }
+    }
+    for (int y = 0; y < height; ++y)
+    {
+        for (int x = 0; x < width; ++x)
+        {
+            int xlower = x - radius > 0 ? x - radius : 0, xupper = x + radius < width - 1 ? x + radius : width - 1;
+            int ylower = y - radius > 0 ? y - radius : 0, yupper = y + radius < height - 1 ? y + radius : height - 1;
+            float totalWeight = 0.0f;
+            float sum[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            const float* mean = means + 4*(y*width + x);
+            for (int fx = xlower; fx <= xupper; ++fx)
+                for (int fy = ylower; fy <= yupper; ++fy)
+                {
+                    const float* m = means + 4*(fy*width + fx);
+                    float dx = mean[0] - m[0], dy = mean[1] - m[1], dz = mean[2] - m[2], dw = mean[3] - m[3];
+                    float lsq = dx*dx + dy*dy + dz*dz + dw*dw;                                 /* maths.h:331-332 */
+                    float weight = expf(-falloff*lsq);
+                    for (int c = 0; c < 4; ++c)
+                        sum[c] = sum[c] + in[4*(fy*width + fx) + c]*weight;
+                    totalWeight += weight;
+                }
+            float rc = 1.0f/totalWeight;
+            for (int c = 0; c < 4; ++c)
+                out[4*(y*width + x) + c] = sum[c]*rc;
+        }
+    }
+    free(means);
+}
+
+/* the float -> byte step of WritePng (png.cpp:331-343): Quantize(c*255.0 + Randf + Randf - 0.5f), default-seeded stream */
+void port_quantize_rgb8(const float* rgba, int width, int height, unsigned char* rgb)
+{
+    rng_t rand = rng_seeded(0u);
+    for (size_t i = 0; i < (size_t)width*height; ++i)
+        for (int c = 0; c < 3; ++c)
+        {
+            double a = rgba[4*i + c]*255.0;
+            a = a + rng_randf(&rand);
+            a = a + rng_randf(&rand);
+            float x = (float)(a - 0.5f);
+            rgb[3*i + c] = (unsigned char)min_t(max_t(x, 0.0f), 255.0f);                       /* Quantize, png.cpp:323-326 */
+        }
+}

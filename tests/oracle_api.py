@@ -279,6 +279,78 @@ def _port_extra():
 _port_extra()
 
 
+def _display_api():
+    """Display stage (main.cpp:258-282, nlm.cpp, png.cpp, pfm.cpp) on both oracles: the reference's own code
+    (ref_*) and the C restatement (port_*)."""
+    def present(self, pixels, exposure=1.0, limit=1.5):
+        pixels = np.ascontiguousarray(pixels, np.float32)
+        out = np.empty_like(pixels)
+        fn = getattr(self.lib, self.prefix + "present")
+        fn.restype = None
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        fn(_fp(pixels), pixels.size//4, exposure, limit, _fp(out))
+        return out
+
+    def nlm(self, image, falloff=200.0, radius=1):
+        image = np.ascontiguousarray(image, np.float32)
+        out = np.empty_like(image)
+        fn = getattr(self.lib, self.prefix + "nlm")
+        fn.restype = None
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]
+        fn(_fp(image), _fp(out), image.shape[1], image.shape[0], falloff, radius)
+        return out
+
+    def write_png(self, image, path):
+        image = np.ascontiguousarray(image, np.float32)
+        self.lib.ref_write_png.restype = None
+        self.lib.ref_write_png.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        self.lib.ref_write_png(_fp(image), image.shape[1], image.shape[0], path.encode())
+
+    def pfm_save(self, rgb, path):
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        assert rgb.shape[-1] == 3
+        self.lib.ref_pfm_save.restype = None
+        self.lib.ref_pfm_save.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        self.lib.ref_pfm_save(_fp(rgb), rgb.shape[1], rgb.shape[0], path.encode())
+
+    def quantize_rgb8(self, image):
+        image = np.ascontiguousarray(image, np.float32)
+        out = np.empty(image.shape[:2] + (3,), np.uint8)
+        self.lib.port_quantize_rgb8.restype = None
+        self.lib.port_quantize_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.lib.port_quantize_rgb8(_fp(image), image.shape[1], image.shape[0], _fp(out))
+        return out
+
+    for cls in (RefOracle, PortOracle):
+        cls.present = present
+        cls.nlm = nlm
+    RefOracle.write_png = write_png
+    RefOracle.pfm_save = pfm_save
+    PortOracle.quantize_rgb8 = quantize_rgb8
+
+
+_display_api()
+
+
+def png_pixels(data):
+    """Decodes the 8-bit RGB pixels of a PNG file (any encoder) -> [H,W,3] uint8; filter type 0 rows only."""
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    off, idat, w, h = 8, b"", 0, 0
+    while off < len(data):
+        n, tag = struct.unpack(">I4s", data[off:off + 8])
+        body = data[off + 8:off + 8 + n]
+        if tag == b"IHDR":
+            w, h = struct.unpack(">II", body[:8])
+        elif tag == b"IDAT":
+            idat += body
+        off += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w*3 + 1)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(h, w, 3).copy()
+
+
 def image_l2(a, b):
     """Per-pixel L2 of SURVEY.md 8c: sqrt(mean_px ||rgb_a/w_a - rgb_b/w_b||^2)."""
     wa = np.where(a[..., 3:4] > 0, a[..., 3:4], 1.0)

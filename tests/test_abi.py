@@ -19,7 +19,7 @@ HEADER = os.path.join(ROOT, "include", "tinsel_hip.h")
 def _declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(tinsel_(?:hip|pack)_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(tinsel_(?:hip|pack|image)_\w+)\s*\(", text)))
 
 
 def test_library_is_built_in_tree():

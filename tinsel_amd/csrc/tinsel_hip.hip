@@ -231,8 +231,9 @@ struct DeviceArena
     }
 };
 
-const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals", "k_bounce" };
-enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_COUNT };
+const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals", "k_bounce",
+                               "k_present", "k_nlm_means", "k_nlm" };
+enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_COUNT };
 
 struct TimedSpan { int kernel; hipEvent_t start, stop; };
 
@@ -251,6 +252,11 @@ struct tinsel_hip
     int width = 0, height = 0;
     float4* accum = nullptr;
     bool accumOwned = true;
+
+    // display stage (tn_display.h): [0] filtered, [1] NLM means, [2] NLM output; sized width*height on first use
+    float4* display[3] = { nullptr, nullptr, nullptr };
+    size_t displayPixels = 0;
+    const float4* presented = nullptr;
 
     // path batch buffers
     size_t batchSlots = 0;
@@ -1016,6 +1022,8 @@ void tinsel_hip_destroy(tinsel_hip* r)
     free_batch(r);
     r->sceneMem.release();
     if (r->accum && r->accumOwned) (void)hipFree(r->accum);
+    for (float4* d : r->display)
+        if (d) (void)hipFree(d);
     if (r->passSeedsDev) (void)hipFree(r->passSeedsDev);
     if (r->statsDev) (void)hipFree(r->statsDev);
     for (TimedSpan& s : r->spans)
@@ -1085,6 +1093,108 @@ int tinsel_hip_read_accum(tinsel_hip* r, float* out_rgba)
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_rgba, r->accum, sizeof(float4)*(size_t)r->width*r->height, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// The display stage of the reference's frame loop (main.cpp:258-282) on the device accumulator.
+int tinsel_hip_present_async(tinsel_hip* r, const tinsel_options* options, int nlm_width, float nlm_falloff, void* stream)
+{
+    if (!r || !r->accum || !options || nlm_width < 0)
+        return fail("present: bad arguments (Init and Render first)");
+    HIP_TRY(hipSetDevice(r->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)r->width*r->height;
+    if (options->mode != TINSEL_MODE_PATHTRACE)
+    {
+        r->presented = r->accum;        // main.cpp:258: the other modes present the raw pixels
+        return 0;
+    }
+    if (r->displayPixels != n)
+    {
+        HIP_TRY(hipDeviceSynchronize());
+        for (float4*& d : r->display)
+        {
+            if (d) (void)hipFree(d);
+            d = nullptr;
+        }
+        r->displayPixels = 0;
+    }
+    const int needed = nlm_width ? 3 : 1;
+    for (int i = 0; i < needed; ++i)
+        if (!r->display[i])
+            HIP_TRY(hipMalloc((void**)&r->display[i], sizeof(float4)*n));
+    r->displayPixels = n;
+
+    {
+        ScopedTimer t(r, KN_PRESENT, st);
+        hipLaunchKernelGGL(k_present, dim3((unsigned)((n + 255)/256)), dim3(256), 0, st, r->accum, r->display[0], (int)n,
+                           options->exposure, options->limit);
+    }
+    r->presented = r->display[0];
+    if (nlm_width)
+    {
+        const dim3 grid((r->width + 15)/16, (r->height + 15)/16);
+        {
+            ScopedTimer t(r, KN_NLM_MEANS, st);
+            hipLaunchKernelGGL(k_nlm_means, grid, dim3(256), 0, st, r->display[0], r->display[1], r->width, r->height, nlm_width);
+        }
+        {
+            ScopedTimer t(r, KN_NLM, st);
+            hipLaunchKernelGGL(k_nlm, grid, dim3(256), 0, st, r->display[0], r->display[1], r->display[2], r->width, r->height,
+                               nlm_falloff, nlm_width);
+        }
+        r->presented = r->display[2];
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int tinsel_hip_present(tinsel_hip* r, const tinsel_options* options, int nlm_width, float nlm_falloff, float* out_rgba)
+{
+    if (tinsel_hip_present_async(r, options, nlm_width, nlm_falloff, nullptr))
+        return -1;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (out_rgba)
+        HIP_TRY(hipMemcpy(out_rgba, r->presented, sizeof(float4)*(size_t)r->width*r->height, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+const float* tinsel_hip_present_device_ptr(tinsel_hip* r) { return r ? (const float*)r->presented : nullptr; }
+
+// WritePng's 8-bit quantisation (png.cpp:323-343): one serial default-seeded Random stream dithers every
+// channel (two Randf per channel), all in double until the narrowing at the Quantize(float) call.  Host code:
+// the generator is a nonlinear recurrence (no skip-ahead), 6 draws per pixel.
+int tinsel_image_quantize_rgb8(const float* rgba, int width, int height, unsigned char* rgb)
+{
+    if (!rgba || !rgb || width <= 0 || height <= 0)
+        return fail("quantize: bad arguments");
+    Rng rand = Rng::seeded(0u);
+    const size_t n = (size_t)width*height;
+    for (size_t i = 0; i < n; ++i)
+    {
+        for (int c = 0; c < 3; ++c)
+        {
+            const double a = (double)rgba[i*4 + c]*255.0;
+            const float r1 = rand.randf();
+            const float r2 = rand.randf();
+            const float x = (float)(((a + (double)r1) + (double)r2) - (double)0.5f);
+            // Clamp = Min(Max(x, 0), 255) with Max(a,b) = (a < b) ? b : a, Min(a,b) = (a < b) ? a : b  (maths.h:55-64)
+            const float lo = (x < 0.0f) ? 0.0f : x;
+            const float cl = (lo < 255.0f) ? lo : 255.0f;
+            rgb[i*3 + c] = (unsigned char)(int)cl;
+        }
+    }
+    return 0;
+}
+
+int tinsel_hip_write_accum(tinsel_hip* r, const float* rgba, uint32_t next_pass_index)
+{
+    if (!r || !r->accum || !rgba)
+        return fail("write_accum: bad arguments (Init first)");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(r->accum, rgba, sizeof(float4)*(size_t)r->width*r->height, hipMemcpyHostToDevice));
+    r->passIndex = next_pass_index;
     return 0;
 }
 
@@ -1232,7 +1342,7 @@ long long tinsel_hip_read_batch_radiance(tinsel_hip* r, float* out_rgbx, unsigne
 int tinsel_hip_leaf(tinsel_hip* r, int op, int index, int n, const float* in, int in_stride, const uint32_t* seeds,
                     float* out, int out_stride, const tinsel_camera* camera, int width, int height)
 {
-    if (!r || n <= 0 || !out || out_stride <= 0 || op < 0 || op > kLeafLibm)
+    if (!r || n <= 0 || !out || out_stride <= 0 || op < 0 || op > kLeafDisplay)
         return fail("leaf: bad arguments");
     if ((op == kLeafBsdfEval || op == kLeafBsdfSample || op == kLeafPrimIntersect || op == kLeafPrimSample) &&
         (index < 0 || index >= r->scene.numPrims))

@@ -26,7 +26,19 @@ struct TraceCounters
     uint32_t internal;      // Node64 records visited (= internal BVH nodes, both levels)
     uint32_t tris;          // triangle tests
     uint32_t prims;         // PrimitiveIntersect calls
+#ifdef TN_PROFILE_TRACE
+    uint32_t cyc[6];        // dev-only: s_memtime deltas of trace_flat by section (boxes, plane, sphere, mesh, finish, fallback walk)
+    long long tp;
+#endif
 };
+
+#ifdef TN_PROFILE_TRACE
+#define TN_TTICK0(c) { __builtin_amdgcn_sched_barrier(0); (c).tp = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#define TN_TTICK(c, k) { __builtin_amdgcn_sched_barrier(0); const long long _t = clock64(); (c).cyc[k] += (uint32_t)(_t - (c).tp); (c).tp = _t; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TN_TTICK0(c)
+#define TN_TTICK(c, k)
+#endif
 
 TN_D float minf_ref(float a, float b) { return a < b ? a : b; }     // intersection.h:369
 TN_D float maxf_ref(float a, float b) { return a > b ? a : b; }     // intersection.h:370
@@ -307,8 +319,10 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
     V3 cn;
     tie = false;
 
+    TN_TTICK0(ctr)
     for (int i = 0; i < sc.numPrims; ++i)
     {
+        TN_TTICK(ctr, 4)
         const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + i);
         const float4 b0 = bp[0], b1 = bp[1];
         if (__float_as_uint(b1.z) == 0u)
@@ -317,9 +331,14 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
             if (!ray_aabb(o, rcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tb))
                 continue;
         }
+        TN_TTICK(ctr, 0)
         float t;
         V3 n;
-        if (prim_intersect<SC, Stack, COUNT>(sc, i, st, 0, o, d, time, t, n, ctr))
+        const bool primHit = prim_intersect<SC, Stack, COUNT>(sc, i, st, 0, o, d, time, t, n, ctr);
+#ifdef TN_PROFILE_TRACE
+        { const uint32_t ty = __builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float4*>(sc.prims + i)[3].x)); TN_TTICK(ctr, ty == kPrimPlane ? 1 : ty == kPrimSphere ? 2 : 3) }
+#endif
+        if (primHit)
         {
             if (t > 0.0f)
             {
@@ -365,6 +384,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
         if (sane && !tie)
             return prim;
     }
+    TN_TTICK0(ctr)
 
     int sp = 0;
     st.set(sp++, sc.root);
@@ -412,6 +432,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
 
     outT = minT;
     outN = face_forward(cn, -d);
+    TN_TTICK(ctr, 5)
     return closest;
 }
 

@@ -17,6 +17,7 @@
 #pragma once
 
 #include "tn_integrator.h"
+#include "tn_display.h"
 
 namespace tn {
 
@@ -295,6 +296,27 @@ TN_D bool begin_path(const CameraParams& cam, const FrameParams& fp, const uint3
 // 96-B state back and appends it to queue[bounce+1].  Lanes are therefore always full at the
 // start of a bounce, and a path costs one state read + one state write per bounce.
 
+// Developer-only section timer (-DTN_PROFILE_SECTIONS, never in the shipped library): per-wave s_memtime
+// deltas of the k_bounce sections, summed into the stats words 2..7 instead of the traversal counters.
+#ifdef TN_PROFILE_SECTIONS
+#define TN_PROF_DECL uint32_t prof[6] = { 0, 0, 0, 0, 0, 0 }; long long tprev = clock64();
+#define TN_TICK(k) { const long long _t = clock64(); prof[k] += (uint32_t)(_t - tprev); tprev = _t; }
+#define TN_PROF_FLUSH if (lane_id() == 0) { for (int k = 0; k < 6; ++k) atomicAdd(q.stats + (size_t)(blockIdx.x % kStatShards)*kStatWords + 2 + k, (unsigned long long)prof[k]); } if (true) return;
+#else
+#define TN_TICK(k)
+#ifdef TN_PROFILE_TRACE
+#define TN_PROF_DECL TraceCounters ctrN = { 0, 0, 0 };
+#define TN_CTR_NEE ctrN
+#define TN_PROF_FLUSH if (lane_id() == 0) { for (int k = 0; k < 6; ++k) atomicAdd(q.stats + (size_t)(blockIdx.x % kStatShards)*kStatWords + 2 + k, (unsigned long long)(TN_PROFILE_TRACE == 2 ? ctrN.cyc[k] : ctr.cyc[k])); } if (true) return;
+#else
+#define TN_PROF_DECL
+#define TN_PROF_FLUSH
+#endif
+#endif
+#ifndef TN_CTR_NEE
+#define TN_CTR_NEE ctr
+#endif
+
 template <bool COUNT, bool FIRST, bool LDS>
 __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueIn,
                                                    uint32_t* __restrict__ queueOut, int bounce, int stackEntries, CameraParams cam,
@@ -312,6 +334,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
     const uint32_t first = blockIdx.x*rounds*kBlock;       // this block's contiguous range
     uint32_t rays = 0, shadowRays = 0, samples = 0;
     TraceCounters ctr = { 0, 0, 0 };
+    TN_PROF_DECL
 
     for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
     {
@@ -326,6 +349,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
                 continue;
             const uint32_t slot = FIRST ? idx : queueIn[idx];
 
+            TN_TICK(4)
             PathRegs p;
             float rx, ry;
             if (FIRST)
@@ -343,10 +367,12 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
                 load_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
             }
 
+            TN_TICK(0)
             float t;
             V3 n;
             const int prim = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n, ctr);
             rays++;
+            TN_TICK(1)
 
             bool alive = false;
             if (prim < 0)
@@ -376,9 +402,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
                             nee_prepare_light(sc, mat, h, p.time, sc.lights[li], p.rng, r);
                             ++sInLight;
                         }
+                        TN_TICK(2)
                         float ts;
                         V3 nn;
-                        const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, p.time, ts, nn, ctr);
+                        const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, p.time, ts, nn, TN_CTR_NEE);
+                        TN_TICK(3)
                         rays++;
                         shadowRays++;
                         if (r.dist < 0.0f)
@@ -389,10 +417,12 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
                 }
 
                 // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
+                TN_TICK(2)
                 if (bounce + 1 < fp.maxDepth)
                     alive = (bsdf_step(p, mat, h) == kContinue);
             }
 
+            TN_TICK(5)
             if (alive)
             {
                 store_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
@@ -414,7 +444,10 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
 
     wave_add_stat(q.stats, 0, rays);
     wave_add_stat(q.stats, 1, samples);
+#if !defined(TN_PROFILE_SECTIONS) && !defined(TN_PROFILE_TRACE)
     wave_add_stat(q.stats, 5, shadowRays);
+#endif
+    TN_PROF_FLUSH
     if (COUNT)
     {
         wave_add_stat(q.stats, 2, ctr.internal);
@@ -1037,6 +1070,7 @@ enum LeafOp : int
     kLeafPrimSample = 5,        // in: time + seed -> pos(3), normal(3), s1, s2                    out stride 8
     kLeafProbe = 6,             // seed -> dir(3), color(3), pdf, ProbePdf(dir), Sky::Eval(dir)(3)  out stride 11
     kLeafLibm = 7,              // in: x, y -> sinf(x), cosf(x), expf(-x), acosf(y), atan2f(y, x - 3)  out stride 5
+    kLeafDisplay = 8,           // in: x, y -> powf(x, 2.2f), powf(x, 1/2.2f), expf(y), tonemap_channel(x)  out stride 4
 };
 
 __global__ __launch_bounds__(kBlock) void k_leaf(DevScene scIn, int op, int index, int n, const float* __restrict__ in, int inStride,
@@ -1114,6 +1148,10 @@ __global__ __launch_bounds__(kBlock) void k_leaf(DevScene scIn, int op, int inde
         m_sincosf(r[0], sn, cs);
         o[0] = sn; o[1] = cs; o[2] = m_expf(-r[0]);
         o[3] = m_acosf(r[1]); o[4] = m_atan2f(r[1], r[0] - 3.0f);
+    }
+    else if (op == kLeafDisplay)
+    {
+        o[0] = m_powf(r[0], 2.2f); o[1] = m_powf(r[0], 1.0f/2.2f); o[2] = m_expf(r[1]); o[3] = tonemap_channel(r[0]);
     }
     else if (op == kLeafProbe)
     {

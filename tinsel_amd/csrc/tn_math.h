@@ -172,47 +172,38 @@ TN_D float m_cosf(float x) { float s, c; m_sincosf(x, s, c); return c; }
 
 __device__ const unsigned long long kExp2fTab[32] = { 0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL, 0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL, 0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL, 0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL, 0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL, 0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL, 0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL, 0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL };
 
-// glibc 2.35 expf for |x| < 87 (e_expf.c, non-TOINT path: the SHIFT trick)
+// glibc 2.35 expf, the __expf_fma ifunc variant an FMA-capable x86-64 host runs (e_expf.c, non-TOINT path: the
+// SHIFT trick; the compiler contracted InvLn2N*x + SHIFT and InvLn2N*x - kd into FMAs there, so they are FMAs here)
 TN_D float m_expf(float xf)
 {
-    double x = (double)xf;
-    if (fabsf(xf) < 87.0f)
+    const uint32_t ix = __float_as_uint(xf);
+    const uint32_t abstop = (ix >> 20) & 0x7ffu;
+    if (abstop > 0x42au)                                        // |x| >= 88 or NaN
     {
-        double z = 0x1.71547652b82fep+5*x;                      // InvLn2N, N = 32
-        double kd = z + 0x1.8p+52;                              // SHIFT
-        const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
-        kd -= 0x1.8p+52;
-        const double r = z - kd;
-        unsigned long long t = kExp2fTab[ki & 31u];
-        t += ki << (52 - 5);
-        const double sc = __longlong_as_double((long long)t);
-        z = ::fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
-        const double r2 = r*r;
-        double yv = ::fma(0x1.62e42ff0c52d6p-6, r, 1.0);
-        yv = ::fma(z, r2, yv);
-        return (float)(yv*sc);
+        if (ix == 0xff800000u)
+            return 0.0f;
+        if (abstop > 0x7f7u)
+            return xf + xf;
+        if (xf > 0x1.62e42ep6f)
+            return __uint_as_float(0x7f800000u);                // overflow
+        if (xf < -0x1.9fe368p6f)
+            return 0.0f;                                        // underflow
+        if (xf < -0x1.9d1d9ep6f)
+            return __uint_as_float(1u);                         // 0x1.4p-75f*0x1.4p-75f: the smallest subnormal
     }
-    if (!(x > -104.0))
-        return (x != x) ? xf : 0.0f;                            // exp(-104) < half the smallest fp32 denormal
-    x = x > 89.0 ? 89.0 : x;                                    // exp(89) already rounds to +inf in fp32
-    const double kd = ::rint(x*1.4426950408889634);             // log2(e)
-    double r = ::fma(-kd, 6.93147180369123816490e-01, x);       // ln2 (hi)
-    r = ::fma(-kd, 1.90821492927058770002e-10, r);              // ln2 (lo)
-    double p = 2.08767569878680989792e-09;                      // 1/12!
-    p = ::fma(r, p, 2.50521083854417187751e-08);
-    p = ::fma(r, p, 2.75573192239858906526e-07);
-    p = ::fma(r, p, 2.75573192239858906526e-06);
-    p = ::fma(r, p, 2.48015873015873015873e-05);
-    p = ::fma(r, p, 1.98412698412698412698e-04);
-    p = ::fma(r, p, 1.38888888888888888889e-03);
-    p = ::fma(r, p, 8.33333333333333333333e-03);
-    p = ::fma(r, p, 4.16666666666666666667e-02);
-    p = ::fma(r, p, 1.66666666666666666667e-01);
-    p = ::fma(r, p, 0.5);
-    p = ::fma(r, p, 1.0);
-    p = ::fma(r, p, 1.0);
-    const long long bits = ((long long)(int)kd + 1023ll) << 52; // 2^k
-    return (float)(p*__longlong_as_double(bits));
+    const double x = (double)xf;
+    double kd = ::fma(0x1.71547652b82fep+5, x, 0x1.8p+52);       // InvLn2N (N = 32), SHIFT
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= 0x1.8p+52;
+    const double r = ::fma(0x1.71547652b82fep+5, x, -kd);
+    unsigned long long t = kExp2fTab[ki & 31u];
+    t += ki << (52 - 5);
+    const double sc = __longlong_as_double((long long)t);
+    const double z = ::fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+    const double r2 = r*r;
+    double yv = ::fma(0x1.62e42ff0c52d6p-6, r, 1.0);
+    yv = ::fma(z, r2, yv);
+    return (float)(yv*sc);
 }
 TN_D float m_logf(float x) { return (float)::log((double)x); }
 

@@ -75,6 +75,12 @@ def load_library():
     L.tinsel_hip_read_batch_radiance.restype = C.c_longlong
     L.tinsel_hip_read_batch_radiance.argtypes = [vp, vp, C.c_ulonglong]
     L.tinsel_hip_leaf.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, ci, C.POINTER(abi.Camera), ci, ci]
+    L.tinsel_hip_write_accum.argtypes = [vp, vp, C.c_uint32]
+    L.tinsel_hip_present.argtypes = [vp, C.POINTER(abi.Options), ci, C.c_float, vp]
+    L.tinsel_hip_present_async.argtypes = [vp, C.POINTER(abi.Options), ci, C.c_float, vp]
+    L.tinsel_hip_present_device_ptr.restype = vp
+    L.tinsel_hip_present_device_ptr.argtypes = [vp]
+    L.tinsel_image_quantize_rgb8.argtypes = [vp, ci, ci, vp]
     L.tinsel_hip_stack_entries.argtypes = [vp]
     L.tinsel_hip_nee_per_path.argtypes = [vp]
     L.tinsel_hip_last_error.restype = C.c_char_p
@@ -90,6 +96,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_reset_stats", "tinsel_hip_stats_detail", "tinsel_hip_set_detail_counters", "tinsel_hip_kernel_times",
     "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
     "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
+    "tinsel_hip_write_accum", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
 ]
 
 
@@ -170,6 +177,21 @@ class HipRenderer:
     def read_accum(self):
         out = np.empty((self.height, self.width, 4), np.float32)
         _check(self._L.tinsel_hip_read_accum(self._h, out.ctypes.data_as(C.c_void_p)), "tinsel_hip_read_accum")
+        return out
+
+    def write_accum(self, accum, next_pass_index):
+        """Restores a saved accumulator [H,W,4] and the index of the next pass (resume a progressive render)."""
+        accum = np.ascontiguousarray(accum, np.float32)
+        assert accum.shape == (self.height, self.width, 4)
+        _check(self._L.tinsel_hip_write_accum(self._h, accum.ctypes.data_as(C.c_void_p), int(next_pass_index)), "tinsel_hip_write_accum")
+
+    def present(self, options, nlm_width=0, nlm_falloff=200.0, readback=True):
+        """The display stage of the reference's frame loop (main.cpp:258-282) on the device accumulator:
+        normalise by the filter weight, ToneMap, LinearToSrgb, optional NonLocalMeansFilter.
+        Returns the float image [H,W,4] main.cpp presents / hands to WritePng."""
+        out = np.empty((self.height, self.width, 4), np.float32) if readback else None
+        ptr = out.ctypes.data_as(C.c_void_p) if readback else None
+        _check(self._L.tinsel_hip_present(self._h, C.byref(options), int(nlm_width), float(nlm_falloff), ptr), "tinsel_hip_present")
         return out
 
     @property
