@@ -208,6 +208,15 @@ float* tinsel_hip_accum_device_ptr(tinsel_hip* r);
 /* Blocking copy of the accumulator to host (W*H*4 floats). */
 int tinsel_hip_read_accum(tinsel_hip* r, float* out_rgba);
 
+/* Mesh BVHs.  TINSEL_BVH_REFERENCE (default): the trees the reference's host builder made (bvh.h:30-263), as
+ * passed in tinsel_mesh_geometry::nodes -- the parity path, since a tree's visit order resolves exact-t ties.
+ * TINSEL_BVH_LBVH: rebuild every mesh that does not live in LDS on the DEVICE (Morton-code linear BVH, one
+ * triangle per leaf like the reference's trees; tn_lbvh.h) -- for meshes rebuilt per frame (main.cpp:318-327
+ * re-inits per batch frame) or too large to wait for the host SAH sweep.  Same hits except exact ties; slower
+ * to traverse than the SAH tree, far faster to build.  *build_ms (may be NULL) receives the device build time. */
+enum { TINSEL_BVH_REFERENCE = 0, TINSEL_BVH_LBVH = 1 };
+int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms);
+
 /* Resume a progressive render: replaces the accumulator with a saved one (W*H*4 floats, as read_accum returned
  * it) and sets the index of the next pass, so that `read_accum after k passes` + `write_accum(.., k)` + more passes
  * gives the same image bit for bit as one uninterrupted render (pass seeds depend on the pass index only). */

@@ -7,6 +7,9 @@
 #include "../../include/tinsel_hip.h"
 
 #include "tn_kernels.h"
+#include "tn_lbvh.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <hip/hip_runtime.h>
 
@@ -248,6 +251,12 @@ struct tinsel_hip
     DevScene scene;
     int stackNeed = 16;
     int neePerPath = 0;
+
+    // mesh table as uploaded (reference trees) and as it currently is; device-built trees (tn_lbvh.h)
+    std::vector<DevMesh> meshesRef, meshesNow;
+    int sceneStackNeed = 1;
+    int bvhMode = TINSEL_BVH_REFERENCE;
+    std::vector<void*> lbvhAllocs;
 
     int width = 0, height = 0;
     float4* accum = nullptr;
@@ -672,6 +681,92 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
 // ===========================================================================
 // C-ABI
 
+// ---------------------------------------------------------------------------
+// device-side mesh BVH build (tn_lbvh.h); the reference trees stay the default and the parity path
+
+namespace {
+
+// one device allocation carved into aligned pieces (hipMalloc / hipFree dominate a small build otherwise)
+struct ScratchPool
+{
+    unsigned char* base = nullptr;
+    size_t size = 0, used = 0;
+    ~ScratchPool() { if (base) (void)hipFree(base); }
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+    bool reserve(size_t bytes) { size = bytes; return hipMalloc((void**)&base, bytes ? bytes : 1) == hipSuccess; }
+    template <class T> T* get(size_t count)
+    {
+        T* p = (T*)(base + used);
+        used += padded(sizeof(T)*count);
+        return used <= size ? p : nullptr;
+    }
+};
+
+// Builds a linear BVH over mesh `dm`'s triangles; on success fills nodes/root/stackNeed of `out`.
+int build_lbvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out)
+{
+    const int n = dm.numTris;
+    size_t sortBytes = 0;
+    if (rocprim::radix_sort_keys(nullptr, sortBytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)n, 0, 62, nullptr) != hipSuccess)
+        return fail("build_mesh_bvh: sort sizing failed");
+    const size_t N = (size_t)n;
+    ScratchPool tmp;
+    if (!tmp.reserve(ScratchPool::padded(6*4) + 2*ScratchPool::padded(N*8) + ScratchPool::padded((N - 1)*8) + 2*ScratchPool::padded((2*N - 1)*4) +
+                     ScratchPool::padded((2*N - 1)*24) + ScratchPool::padded((N - 1)*4) + ScratchPool::padded(sortBytes)))
+        return fail("build_mesh_bvh: device allocation failed");
+    uint32_t* bounds = tmp.get<uint32_t>(6);
+    unsigned long long* keys = tmp.get<unsigned long long>(N);
+    unsigned long long* sorted = tmp.get<unsigned long long>(N);
+    int2* children = tmp.get<int2>(N - 1);
+    int* parent = tmp.get<int>(2*N - 1);
+    float* boxes = tmp.get<float>((2*N - 1)*6);
+    int* height = tmp.get<int>(2*N - 1);
+    int* visits = tmp.get<int>(N - 1);
+    unsigned char* sortTmp = tmp.get<unsigned char>(sortBytes);
+    Node64* nodes = nullptr;
+    if (!bounds || !keys || !sorted || !children || !parent || !boxes || !height || !visits || !sortTmp ||
+        hipMalloc((void**)&nodes, sizeof(Node64)*(N - 1)) != hipSuccess)
+        return fail("build_mesh_bvh: device allocation failed");
+
+    const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+    const unsigned grid = (unsigned)((n + 255)/256);
+    int rc = 0;
+    do
+    {
+        if (hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, nullptr) != hipSuccess ||
+            hipMemsetAsync(visits, 0, sizeof(int)*((size_t)n - 1), nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: init failed"); break; }
+        hipLaunchKernelGGL(k_lbvh_bounds, dim3(grid < 256u ? grid : 256u), dim3(256), 0, nullptr, dm.tris, n, bounds);
+        hipLaunchKernelGGL(k_lbvh_keys, dim3(grid), dim3(256), 0, nullptr, dm.tris, n, bounds, keys);
+        if (rocprim::radix_sort_keys(sortTmp, sortBytes, keys, sorted, (size_t)n, 0, 62, nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: sort failed"); break; }
+        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(grid), dim3(256), 0, nullptr, sorted, n, children, parent);
+        hipLaunchKernelGGL(k_lbvh_leaves, dim3(grid), dim3(256), 0, nullptr, dm.tris, sorted, n, boxes, height);
+        // one pass per tree level (<= 63 for 62-bit keys); look at the root every 16 passes
+        int rootGen = 0;
+        for (int pass = 2; pass <= 66 && !rootGen; )
+        {
+            for (int k = 0; k < 16; ++k, ++pass)
+                hipLaunchKernelGGL(k_lbvh_fit_pass, dim3(grid), dim3(256), 0, nullptr, n, pass, children, boxes, height, visits);
+            if (hipMemcpy(&rootGen, visits, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+                break;
+        }
+        if (!rootGen) { rc = fail("build_mesh_bvh: box fitting did not reach the root"); break; }
+        hipLaunchKernelGGL(k_lbvh_emit, dim3(grid), dim3(256), 0, nullptr, sorted, n, children, boxes, nodes);
+        int rootHeight = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpy(&rootHeight, height, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("build_mesh_bvh: kernels failed"); break; }
+        out = dm;
+        out.nodes = nodes;
+        out.root = 0;
+        out.stackNeed = rootHeight + 1;
+    } while (false);
+    if (rc)
+        (void)hipFree(nodes);
+    else
+        r->lbvhAllocs.push_back(nodes);
+    return rc;
+}
+
+} // namespace
+
 extern "C" {
 
 const char* tinsel_hip_last_error(void) { return g_error.c_str(); }
@@ -929,6 +1024,8 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             }
             if (!meshes.empty() && hipMemcpy(arenaDev + offMeshes, hm, sizeof(DevMesh)*meshes.size(), hipMemcpyHostToDevice) != hipSuccess)
                 arenaDev = nullptr;
+            r->meshesRef.assign(hm, hm + meshes.size());
+            r->meshesNow = r->meshesRef;
         }
         if (!arenaDev)
         {
@@ -947,6 +1044,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             sc.lights = reinterpret_cast<const int32_t*>(arenaDev + offLights);
             sc.meshes = reinterpret_cast<const DevMesh*>(arenaDev + offMeshes);
             sc.numMeshes = (int)meshes.size();
+            r->sceneStackNeed = sceneBvh.maxLeafDepth + 1;
             sc.primBoxes = reinterpret_cast<const PrimBox*>(arenaDev + offBoxes);
             sc.hasMedia = 0;
             for (const Mat128& mm : mats)
@@ -1024,6 +1122,8 @@ void tinsel_hip_destroy(tinsel_hip* r)
     if (r->accum && r->accumOwned) (void)hipFree(r->accum);
     for (float4* d : r->display)
         if (d) (void)hipFree(d);
+    for (void* p : r->lbvhAllocs)
+        (void)hipFree(p);
     if (r->passSeedsDev) (void)hipFree(r->passSeedsDev);
     if (r->statsDev) (void)hipFree(r->statsDev);
     for (TimedSpan& s : r->spans)
@@ -1183,6 +1283,59 @@ int tinsel_image_quantize_rgb8(const float* rgba, int width, int height, unsigne
             const float cl = (lo < 255.0f) ? lo : 255.0f;
             rgb[i*3 + c] = (unsigned char)(int)cl;
         }
+    }
+    return 0;
+}
+
+int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
+{
+    if (!r || (mode != TINSEL_BVH_REFERENCE && mode != TINSEL_BVH_LBVH))
+        return fail("set_mesh_bvh: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (build_ms)
+        *build_ms = 0.0;
+
+    std::vector<DevMesh> next = r->meshesRef;
+    if (mode == TINSEL_BVH_LBVH)
+    {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        (void)hipEventRecord(e0, nullptr);
+        int rc = 0;
+        for (size_t m = 0; m < next.size() && !rc; ++m)
+            if (!next[m].inArena && next[m].numTris >= 2)       // LDS-resident meshes keep their (tiny) reference trees
+                rc = build_lbvh(r, r->meshesRef[m], next[m]);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (rc)
+            return -1;
+        if (build_ms)
+            *build_ms = ms;
+    }
+
+    int maxMeshNeed = 0;
+    for (const DevMesh& dm : next)
+        if (dm.stackNeed > maxMeshNeed)
+            maxMeshNeed = dm.stackNeed;
+    const int stack = pick_stack(r->sceneStackNeed + maxMeshNeed);
+    if (stack < 0)
+        return fail("set_mesh_bvh: tree too deep for the 156-entry LDS traversal stack (reference trees kept)");
+    if (!next.empty())
+        HIP_TRY(hipMemcpy((void*)r->scene.meshes, next.data(), sizeof(DevMesh)*next.size(), hipMemcpyHostToDevice));
+    r->meshesNow = next;
+    r->stackNeed = stack;
+    r->bvhMode = mode;
+    if (mode == TINSEL_BVH_REFERENCE)
+    {
+        for (void* p : r->lbvhAllocs)
+            (void)hipFree(p);
+        r->lbvhAllocs.clear();
     }
     return 0;
 }

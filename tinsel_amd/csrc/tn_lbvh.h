@@ -1,0 +1,221 @@
+// tn_lbvh.h -- device-side BVH construction for large meshes (opt-in).
+//
+// The reference builds every mesh BVH on the host with a SAH sweep that std::sorts the items at every node
+// (bvh.h:30-263: 172 ms for 107 k triangles) and ships that tree; the parity path keeps it, because the visit
+// order of a different tree resolves exact-t ties differently.  This is the alternative for meshes that are
+// re-built often or are too large to wait for: a linear BVH over the triangle centroids' 30-bit Morton codes
+// (keys made unique with the triangle index), radix-sorted, hierarchy by longest common prefix, boxes fitted
+// bottom-up.  One triangle per leaf, like the reference's trees, emitted straight into the traversal layout
+// (Node64: both children's boxes and refs per internal node, leaves referenced by triangle index).
+//
+// All kernels are streaming passes over n triangles: HBM-bound, one launch each.
+#pragma once
+
+#include "tn_scene.h"
+
+namespace tn {
+
+// order-preserving float <-> uint (for atomicMin / atomicMax on floats of either sign)
+TN_D uint32_t float_ordered(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+TN_D float ordered_float(uint32_t u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+TN_D void tri_box(const Tri48* tris, int i, float* lo, float* hi)
+{
+    const float4* tp = reinterpret_cast<const float4*>(tris + i);
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    lo[0] = fminf(a.x, fminf(b.x, c.x)); hi[0] = fmaxf(a.x, fmaxf(b.x, c.x));
+    lo[1] = fminf(a.y, fminf(b.y, c.y)); hi[1] = fmaxf(a.y, fmaxf(b.y, c.y));
+    lo[2] = fminf(a.z, fminf(b.z, c.z)); hi[2] = fmaxf(a.z, fmaxf(b.z, c.z));
+}
+
+// bounds[0..2] = min, bounds[3..5] = max of the triangle CENTROIDS (ordered-uint encoded); init to ~0 / 0.
+// Fixed grid, grid-stride loop, block reduction: one atomic pair per BLOCK per axis (single-address atomics are slow).
+__global__ __launch_bounds__(256) void k_lbvh_bounds(const Tri48* __restrict__ tris, int n, uint32_t* __restrict__ bounds)
+{
+    uint32_t mn[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, mx[3] = { 0u, 0u, 0u };
+    for (int i = blockIdx.x*256 + threadIdx.x; i < n; i += gridDim.x*256)
+    {
+        float lo[3], hi[3];
+        tri_box(tris, i, lo, hi);
+        for (int k = 0; k < 3; ++k)
+        {
+            const uint32_t c = float_ordered(0.5f*(lo[k] + hi[k]));
+            mn[k] = c < mn[k] ? c : mn[k];
+            mx[k] = c > mx[k] ? c : mx[k];
+        }
+    }
+    __shared__ uint32_t s_mn[4][3], s_mx[4][3];
+    for (int k = 0; k < 3; ++k)
+    {
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            const uint32_t a = __shfl_down(mn[k], off), b = __shfl_down(mx[k], off);
+            mn[k] = a < mn[k] ? a : mn[k];
+            mx[k] = b > mx[k] ? b : mx[k];
+        }
+        if ((threadIdx.x & 63) == 0)
+        {
+            s_mn[threadIdx.x >> 6][k] = mn[k];
+            s_mx[threadIdx.x >> 6][k] = mx[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+    {
+        const int k = threadIdx.x;
+        uint32_t a = s_mn[0][k], b = s_mx[0][k];
+        for (int w = 1; w < 4; ++w)
+        {
+            a = s_mn[w][k] < a ? s_mn[w][k] : a;
+            b = s_mx[w][k] > b ? s_mx[w][k] : b;
+        }
+        atomicMin(bounds + k, a);
+        atomicMax(bounds + 3 + k, b);
+    }
+}
+
+TN_D uint32_t expand_bits10(uint32_t v)     // 10 bits -> every third bit
+{
+    v = (v*0x00010001u) & 0xFF0000FFu;
+    v = (v*0x00000101u) & 0x0F00F00Fu;
+    v = (v*0x00000011u) & 0xC30C30C3u;
+    v = (v*0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_keys(const Tri48* __restrict__ tris, int n, const uint32_t* __restrict__ bounds,
+                                                   unsigned long long* __restrict__ keys)
+{
+    const int i = blockIdx.x*256 + threadIdx.x;
+    if (i >= n)
+        return;
+    float lo[3], hi[3];
+    tri_box(tris, i, lo, hi);
+    uint32_t code = 0;
+    for (int k = 0; k < 3; ++k)
+    {
+        const float mn = ordered_float(bounds[k]), mx = ordered_float(bounds[3 + k]);
+        const float ext = mx - mn;
+        float u = ext > 0.0f ? (0.5f*(lo[k] + hi[k]) - mn)/ext : 0.0f;
+        u = fminf(fmaxf(u*1024.0f, 0.0f), 1023.0f);
+        code |= expand_bits10((uint32_t)u) << (2 - k);
+    }
+    keys[i] = ((unsigned long long)code << 32) | (unsigned long long)(uint32_t)i;
+}
+
+// longest common prefix of two sorted keys (unique: the low word is the triangle index); -1 outside the array
+TN_D int lbvh_delta(const unsigned long long* keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n)
+        return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+// Node ids: internal nodes 0..n-2 (root = 0), leaf of sorted position j = (n-1) + j.
+// children[i] = (left id, right id) of internal node i; parent[id] for every node but the root.
+__global__ __launch_bounds__(256) void k_lbvh_hierarchy(const unsigned long long* __restrict__ keys, int n, int2* __restrict__ children,
+                                                        int* __restrict__ parent)
+{
+    const int i = blockIdx.x*256 + threadIdx.x;
+    if (i >= n - 1)
+        return;
+    const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, n, i, i + lmax*d) > dmin)
+        lmax *= 2;
+    int l = 0;
+    for (int t = lmax/2; t >= 1; t /= 2)
+        if (lbvh_delta(keys, n, i, i + (l + t)*d) > dmin)
+            l += t;
+    const int j = i + l*d;
+    const int dnode = lbvh_delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do
+    {
+        t = (t + 1)/2;
+        if (lbvh_delta(keys, n, i, i + (s + t)*d) > dnode)
+            s += t;
+    } while (t > 1);
+    const int gamma = i + s*d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int left = (lo == gamma) ? (n - 1 + gamma) : gamma;
+    const int right = (hi == gamma + 1) ? (n - 1 + gamma + 1) : (gamma + 1);
+    children[i] = make_int2(left, right);
+    parent[left] = i;
+    parent[right] = i;
+}
+
+// Box fitting, bottom-up, WITHOUT inter-thread hand-off inside a kernel (an atomic climb needs an agent-scope
+// fence per level per thread, which on 8 XCDs with private L2s costs a cache write-back each: 4 ms for 524 k
+// triangles).  Instead: leaves first, then one pass per tree level -- an internal node is fitted in pass k when
+// both children were finished in an EARLIER pass (gen[child] in [1, k)); kernel boundaries are the fences.
+// A tree over 62-bit unique keys is at most 63 levels high, so 63 passes always suffice; the host stops earlier
+// when the root is done.   boxes[id] = {min.xyz, max.xyz} for all 2n-1 nodes; gen[] zero-initialised.
+__global__ __launch_bounds__(256) void k_lbvh_leaves(const Tri48* __restrict__ tris, const unsigned long long* __restrict__ keys, int n,
+                                                     float* __restrict__ boxes, int* __restrict__ height)
+{
+    const int j = blockIdx.x*256 + threadIdx.x;
+    if (j >= n)
+        return;
+    const int id = n - 1 + j;
+    float lo[3], hi[3];
+    tri_box(tris, (int)(uint32_t)keys[j], lo, hi);
+    float* b = boxes + (size_t)id*6;
+    b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+    height[id] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_fit_pass(int n, int pass, const int2* __restrict__ children, float* __restrict__ boxes,
+                                                       int* __restrict__ height, int* __restrict__ gen)
+{
+    const int i = blockIdx.x*256 + threadIdx.x;
+    if (i >= n - 1 || gen[i] != 0)
+        return;
+    const int2 ch = children[i];
+    const int gl = ch.x >= n - 1 ? 1 : gen[ch.x];
+    const int gr = ch.y >= n - 1 ? 1 : gen[ch.y];
+    const bool leftDone = ch.x >= n - 1 || (gl != 0 && gl < pass);
+    const bool rightDone = ch.y >= n - 1 || (gr != 0 && gr < pass);
+    if (!leftDone || !rightDone)
+        return;
+    const float* bl = boxes + (size_t)ch.x*6;
+    const float* br = boxes + (size_t)ch.y*6;
+    float* bo = boxes + (size_t)i*6;
+    for (int k = 0; k < 3; ++k)
+    {
+        bo[k] = fminf(bl[k], br[k]);
+        bo[3 + k] = fmaxf(bl[3 + k], br[3 + k]);
+    }
+    const int hl = height[ch.x], hr = height[ch.y];
+    height[i] = 1 + (hl > hr ? hl : hr);
+    gen[i] = pass;
+}
+
+__global__ __launch_bounds__(256) void k_lbvh_emit(const unsigned long long* __restrict__ keys, int n, const int2* __restrict__ children,
+                                                   const float* __restrict__ boxes, Node64* __restrict__ out)
+{
+    const int i = blockIdx.x*256 + threadIdx.x;
+    if (i >= n - 1)
+        return;
+    const int2 ch = children[i];
+    const float* bl = boxes + (size_t)ch.x*6;
+    const float* br = boxes + (size_t)ch.y*6;
+    Node64 o;
+    o.lminx = bl[0]; o.lminy = bl[1]; o.lminz = bl[2]; o.lmaxx = bl[3]; o.lmaxy = bl[4]; o.lmaxz = bl[5];
+    o.rminx = br[0]; o.rminy = br[1]; o.rminz = br[2]; o.rmaxx = br[3]; o.rmaxy = br[4]; o.rmaxz = br[5];
+    o.left = ch.x >= n - 1 ? (kLeafBit | (uint32_t)keys[ch.x - (n - 1)]) : (uint32_t)ch.x;
+    o.right = ch.y >= n - 1 ? (kLeafBit | (uint32_t)keys[ch.y - (n - 1)]) : (uint32_t)ch.y;
+    o.pad0 = 0; o.pad1 = 0;
+    out[i] = o;
+}
+
+} // namespace tn

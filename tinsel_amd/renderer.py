@@ -76,6 +76,7 @@ def load_library():
     L.tinsel_hip_read_batch_radiance.argtypes = [vp, vp, C.c_ulonglong]
     L.tinsel_hip_leaf.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, ci, C.POINTER(abi.Camera), ci, ci]
     L.tinsel_hip_write_accum.argtypes = [vp, vp, C.c_uint32]
+    L.tinsel_hip_set_mesh_bvh.argtypes = [vp, ci, C.POINTER(C.c_double)]
     L.tinsel_hip_present.argtypes = [vp, C.POINTER(abi.Options), ci, C.c_float, vp]
     L.tinsel_hip_present_async.argtypes = [vp, C.POINTER(abi.Options), ci, C.c_float, vp]
     L.tinsel_hip_present_device_ptr.restype = vp
@@ -96,7 +97,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_reset_stats", "tinsel_hip_stats_detail", "tinsel_hip_set_detail_counters", "tinsel_hip_kernel_times",
     "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
     "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
-    "tinsel_hip_write_accum", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
+    "tinsel_hip_write_accum", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
 ]
 
 
@@ -178,6 +179,13 @@ class HipRenderer:
         out = np.empty((self.height, self.width, 4), np.float32)
         _check(self._L.tinsel_hip_read_accum(self._h, out.ctypes.data_as(C.c_void_p)), "tinsel_hip_read_accum")
         return out
+
+    def set_mesh_bvh(self, mode):
+        """abi.BVH_REFERENCE (the reference's host-built trees, parity path) or abi.BVH_LBVH (rebuild large meshes on
+        the device); returns the device build time in ms."""
+        ms = C.c_double(0.0)
+        _check(self._L.tinsel_hip_set_mesh_bvh(self._h, int(mode), C.byref(ms)), "tinsel_hip_set_mesh_bvh")
+        return ms.value
 
     def write_accum(self, accum, next_pass_index):
         """Restores a saved accumulator [H,W,4] and the index of the next pass (resume a progressive render)."""
