@@ -81,3 +81,11 @@ extern "C" int HipRendererRenderPasses(Renderer* r, const Camera& camera, const 
     HipRenderer* h = static_cast<HipRenderer*>(r);
     return h->handle ? tinsel_hip_render(h->handle, (const tinsel_camera*)&camera, (const tinsel_options*)&options, (float*)output, passes) : -1;
 }
+
+// The display stage of main.cpp:258-282 on the device accumulator: `filtered` receives what main.cpp calls
+// g_filtered (or g_exposed when nlmWidth != 0) -- the array it hands to glDrawPixels and WritePng.
+extern "C" int HipRendererPresent(Renderer* r, const Options& options, Color* filtered, int nlmWidth, float nlmFalloff)
+{
+    HipRenderer* h = static_cast<HipRenderer*>(r);
+    return h->handle ? tinsel_hip_present(h->handle, (const tinsel_options*)&options, nlmWidth, nlmFalloff, (float*)filtered) : -1;
+}

@@ -4,6 +4,7 @@
 // Renderer interface, with the reference's CreateCpuRenderer() timed beside it.
 //
 //   tinsel_headless scene.tin [-spp=N] [-width=W] [-height=H] [-maxdepth=D] [-cpuspp=M] [-out=file.pfm]
+//                              [-png=file.png] [-nlm=RADIUS]      display stage on the GPU, file by the reference's WritePng
 //
 // Prints per-back-end wall time and the image-level difference of the two estimates (different RNG
 // streams: statistical agreement only; the per-seed parity tests live in tests/).
@@ -12,6 +13,7 @@
 #include "scene.h"
 #include "util.h"
 #include "pfm.h"
+#include "png.h"
 
 #include <chrono>
 #include <cmath>
@@ -21,6 +23,7 @@
 #include <vector>
 
 extern "C" int HipRendererRenderPasses(Renderer* r, const Camera& camera, const Options& options, Color* output, int passes);
+extern "C" int HipRendererPresent(Renderer* r, const Options& options, Color* filtered, int nlmWidth, float nlmFalloff);
 
 int main(int argc, char* argv[])
 {
@@ -42,8 +45,9 @@ int main(int argc, char* argv[])
     camera.rotation = Quat();
     camera.fov = DegToRad(35.0f);
 
-    int spp = 64, cpuSpp = 0;
+    int spp = 64, cpuSpp = 0, nlmWidth = 0;
     const char* out = NULL;
+    const char* png = NULL;
     const char* file = NULL;
 
     for (int i = 1; i < argc; ++i)      // "-key=value" overrides after the scene file (main.cpp:143-149)
@@ -63,8 +67,11 @@ int main(int argc, char* argv[])
         sscanf(argv[i], "-width=%d", &options.width);
         sscanf(argv[i], "-height=%d", &options.height);
         sscanf(argv[i], "-maxdepth=%d", &options.maxDepth);
+        sscanf(argv[i], "-nlm=%d", &nlmWidth);
         if (strncmp(argv[i], "-out=", 5) == 0)
             out = argv[i] + 5;
+        if (strncmp(argv[i], "-png=", 5) == 0)
+            png = argv[i] + 5;
     }
 
     scene.Build();      // main.cpp:199
@@ -83,6 +90,16 @@ int main(int argc, char* argv[])
     auto t1 = std::chrono::steady_clock::now();
     const double gpuSec = std::chrono::duration<double>(t1 - t0).count();
     printf("gpu: %d spp %dx%d in %.4f s (%.2f Msamples/s)\n", spp, options.width, options.height, gpuSec, spp*npix/gpuSec/1e6);
+    if (png)
+    {
+        // main.cpp:258-282 on the device, then the reference's own WritePng (main.cpp:307-312)
+        std::vector<Color> filtered(npix);
+        if (HipRendererPresent(gpu, options, &filtered[0], nlmWidth, 200.0f) == 0)
+        {
+            WritePng(&filtered[0], options.width, options.height, png);
+            printf("wrote %s\n", png);
+        }
+    }
     delete gpu;
 
     if (cpuSpp > 0)

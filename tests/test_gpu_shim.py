@@ -23,3 +23,19 @@ def test_reference_main_loop_drives_the_hip_backend():
     # two independent Monte-Carlo estimates of the same image (different RNG streams): means agree to ~1 %
     assert abs(gpu/cpu - 1) < 0.03, out.stdout
     assert l2 < 0.5
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="shim/_build/tinsel_headless not built (needs /root/reference)")
+def test_cxx_caller_writes_the_same_png_as_the_python_caller(tmp_path):
+    """The C++ caller (reference loader + Scene::Build + shim + the device display stage + the reference's OWN
+    WritePng) and the Python caller (scene pack + tinsel_amd.display's writer) produce byte-identical files."""
+    import sys
+    a, b = tmp_path / "cxx.png", tmp_path / "py.png"
+    tin = os.path.join(ROOT, "tests", "golden", "scenes", "features.tin")
+    out = subprocess.run([EXE, tin, "-spp=24", "-width=96", "-height=64", "-png=%s" % a], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and os.path.exists(a), out.stdout + out.stderr
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-m", "tinsel_amd.headless", "-spp=24", "-width=96", "-height=64", "-out=%s" % b,
+                          os.path.join(ROOT, "tests", "golden", "features.pack")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
