@@ -18,18 +18,29 @@ namespace tn {
 // Max<T>(a,b) = (a < b) ? b : a  (maths.h:58-59)
 TN_D float max_ref(float a, float b) { return (a < b) ? b : a; }
 
-// ToneMap (util.h:25-42): filmic curve, then SrgbToLinear (maths.h:1551-1555)
-TN_D float tonemap_channel(float c)
+// ToneMap (util.h:25-42): the filmic curve; SrgbToLinear (maths.h:1551-1555) is applied by the caller
+TN_D float filmic_channel(float c)
 {
     const float x = max_ref(0.0f, c - 0.004f);
     const float num = x*(6.2f*x + 0.5f);
     const float den = x*(6.2f*x + 1.7f) + 0.06f;       // Vec3(0.06): the double literal narrows to float in the ctor
-    return m_powf(num/den, 2.2f);
+    return num/den;
 }
+TN_D float tonemap_channel(float c) { return m_powf(filmic_channel(c), 2.2f); }
 
 __global__ __launch_bounds__(256) void k_present(const float4* __restrict__ accum, float4* __restrict__ out, int n,
                                                  float exposure, float limit)
 {
+    // powf's two tables (768 B) in LDS: six powf per pixel, each with two data-dependent table reads
+    __shared__ double s_log2[16][2];
+    __shared__ unsigned long long s_exp2[32];
+    if (threadIdx.x < 32)
+    {
+        s_log2[threadIdx.x >> 1][threadIdx.x & 1] = kPowfLog2Tab[threadIdx.x >> 1][threadIdx.x & 1];
+        s_exp2[threadIdx.x] = kPowfExp2Tab[threadIdx.x];
+    }
+    __syncthreads();
+
     const int i = blockIdx.x*256 + threadIdx.x;
     if (i >= n)
         return;
@@ -38,10 +49,10 @@ __global__ __launch_bounds__(256) void k_present(const float4* __restrict__ accu
     const float kInvGamma = 1.0f/2.2f;
     float4 r;
     // Color*s scales w too; ToneMap returns SrgbToLinear(Color(rgb, 0)): w = powf(0, 2.2) = 0; LinearToSrgb keeps w
-    r.x = m_powf(tonemap_channel(p.x*s), kInvGamma);
-    r.y = m_powf(tonemap_channel(p.y*s), kInvGamma);
-    r.z = m_powf(tonemap_channel(p.z*s), kInvGamma);
-    r.w = m_powf(0.0f, 2.2f);
+    r.x = m_powf_tab(m_powf_tab(filmic_channel(p.x*s), 2.2f, s_log2, s_exp2), kInvGamma, s_log2, s_exp2);
+    r.y = m_powf_tab(m_powf_tab(filmic_channel(p.y*s), 2.2f, s_log2, s_exp2), kInvGamma, s_log2, s_exp2);
+    r.z = m_powf_tab(m_powf_tab(filmic_channel(p.z*s), 2.2f, s_log2, s_exp2), kInvGamma, s_log2, s_exp2);
+    r.w = 0.0f;
     (void)limit;                                        // only the commented-out Reinhard operator used it
     out[i] = r;
 }

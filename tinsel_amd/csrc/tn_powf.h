@@ -51,7 +51,9 @@ TN_HD uint64_t powf_bits64(double d) { uint64_t u; memcpy(&u, &d, 8); return u; 
 TN_HD double powf_double(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 
 // x^y for the display stage's domain: any x (negative or NaN -> NaN), finite y > 0 that is not an integer.
-TN_HD float m_powf(float x, float y)
+// `log2tab` / `exp2tab`: the two tables above or copies of them (the display kernel keeps copies in LDS).
+template <class LogTab, class ExpTab>
+TN_HD float m_powf_tab(float x, float y, const LogTab& log2tab, const ExpTab& exp2tab)
 {
     uint32_t ix = powf_bits(x);
     if (x != x || ix >= 0x80000000u)
@@ -81,7 +83,7 @@ TN_HD float m_powf(float x, float y)
     const uint32_t top = tmp & 0xff800000u;
     const uint32_t iz = ix - top;
     const int k = (int32_t)top >> 23;
-    const double invc = kPowfLog2Tab[i][0], logc = kPowfLog2Tab[i][1];
+    const double invc = log2tab[i][0], logc = log2tab[i][1];
     const double z = (double)powf_float(iz);
 
     const double r = __builtin_fma(z, invc, -1.0);
@@ -111,7 +113,7 @@ TN_HD float m_powf(float x, float y)
     const uint64_t ki = powf_bits64(kd);
     kd -= 0x1.8p+47;
     const double rr = ylogx - kd;
-    uint64_t t = kPowfExp2Tab[ki & 31u];
+    uint64_t t = exp2tab[ki & 31u];
     t += ki << 47;
     const double s = powf_double(t);
     const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
@@ -120,5 +122,7 @@ TN_HD float m_powf(float x, float y)
     e = __builtin_fma(zz, rr2, e);
     return (float)(e*s);
 }
+
+TN_HD float m_powf(float x, float y) { return m_powf_tab(x, y, kPowfLog2Tab, kPowfExp2Tab); }
 
 } // namespace tn
