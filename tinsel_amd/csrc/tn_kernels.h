@@ -391,15 +391,17 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
                     int li = 0, sInLight = 0;
                     V3 sum = nee_sum(sc, [&](int k) -> V3 {
                         NeeRec r;
+                        // the 28-register material record is re-read per sample instead of living across the shadow trace
+                        const Mat matK = load_mat(sc.mats, prim);
                         if (sc.probe.valid && k == 0)
                         {
-                            nee_prepare_probe(sc, mat, h, p.rng, r);
+                            nee_prepare_probe(sc, matK, h, p.rng, r);
                         }
                         else
                         {
                             // NEE rays arrive in order: walk (light, sample) along with k
                             while (sInLight >= sc.mats[sc.lights[li]].lightSamples) { ++li; sInLight = 0; }
-                            nee_prepare_light(sc, mat, h, p.time, sc.lights[li], p.rng, r);
+                            nee_prepare_light(sc, matK, h, p.time, sc.lights[li], p.rng, r);
                             ++sInLight;
                         }
                         TN_TICK(2)
@@ -419,7 +421,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
                 // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
                 TN_TICK(2)
                 if (bounce + 1 < fp.maxDepth)
-                    alive = (bsdf_step(p, mat, h) == kContinue);
+                {
+                    // the material is read again rather than kept in 28 registers across the shadow traces
+                    const Mat matAgain = load_mat(sc.mats, prim);
+                    alive = (bsdf_step(p, matAgain, h) == kContinue);
+                }
             }
 
             TN_TICK(5)
