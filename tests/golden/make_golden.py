@@ -38,6 +38,10 @@ SCENES = {
     "emitter": ("data/emitter.tin", 48, 48, 2, None),
     "gloss": ("data/gloss.tin", 64, 64, 3, None),
     "features": (os.path.join(HERE, "scenes", "features.tin"), 96, 64, 4, None),
+    # 203 primitives: scene-level BVH walk instead of the flat scan, arena too large for LDS (HBM-resident scene)
+    "many_spheres": (os.path.join(HERE, "scenes", "many_spheres.tin"), 128, 96, 3, None),
+    # one primitive (root of the scene BVH is a leaf), 7x5 frame, maxDepth 1, emissive light hit directly
+    "one_sphere": (os.path.join(HERE, "scenes", "one_sphere.tin"), 7, 5, 5, None),
 }
 
 
@@ -48,10 +52,14 @@ def struct_bytes(s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("scenes", nargs="*", help="regenerate only these .tin-derived fixtures")
     args = ap.parse_args()
 
     R = RefOracle()
+    only = [a for a in sys.argv[1:] if not a.startswith("-") and a in SCENES]
     for name, (tin, W, H, passes, depth) in SCENES.items():
+        if only and name not in only:
+            continue
         path = tin if os.path.isabs(tin) else os.path.join(args.ref, tin)
         h = R.load_tin(path)
         if name == "features":
@@ -60,6 +68,9 @@ def main():
         R.write_pack(h, pack)
         make_outputs(R, h, name, W, H, passes, depth)
         R.free(h)
+
+    if only:
+        return
 
     # features + procedural probe: exercises ProbeSample/ProbePdf MIS (render.cpp:107-144,370-380)
     h = R.load_tin(os.path.join(HERE, "scenes", "features.tin"))

@@ -22,7 +22,7 @@ from tests.oracle_api import GOLDEN, image_l2
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell", "veach", "glass", "simple", "conservation", "furnace", "emitter", "gloss", "features",
-          "features_probe", "cornell_probe", "ajax_standin_96"]
+          "features_probe", "cornell_probe", "ajax_standin_96", "many_spheres", "one_sphere"]
 
 
 def _load(name):
@@ -141,7 +141,7 @@ def test_shards_sum_to_whole():
                     reason="oracle/_ref not built")
 @pytest.mark.parametrize("name,W,H,passes,depth", [("cornell", 256, 256, 16, 4), ("veach", 192, 192, 4, 4), ("glass", 160, 160, 4, 12),
                                                    ("features", 192, 128, 32, 6), ("features_probe", 192, 128, 32, 6),
-                                                   ("ajax_standin_96", 200, 200, 8, 4)])
+                                                   ("ajax_standin_96", 200, 200, 8, 4), ("many_spheres", 256, 192, 4, 5)])
 def test_against_reference_live(name, W, H, passes, depth):
     """BASELINE config-1-sized check against the reference's PathTrace run HERE on the host cores."""
     from tests.oracle_api import RefOracle
@@ -180,3 +180,30 @@ def test_filter_footprints(ftype, width, falloff, W, H):
     for pipeline in (abi.PIPELINE_WAVEFRONT, abi.PIPELINE_WAVEFRONT_SPLIT, abi.PIPELINE_MEGAKERNEL):
         out, _ = _render(scene, cam, opt, 3, pipeline)
         assert np.array_equal(out, ref), "pipeline %d" % pipeline
+
+
+def test_unsupported_inputs_fail_loudly():
+    """What the reference itself cannot handle (Scene::Build segfaults on an empty scene) or forbids (Render before
+    Init, a frame size that differs from Init) is refused with an error, never rendered wrongly."""
+    import ctypes as C
+    import tinsel_amd
+    from tinsel_amd.renderer import load_library
+    L = load_library()
+    L.tinsel_hip_create.restype = C.c_void_p
+    empty = abi.SceneDesc()
+    assert not L.tinsel_hip_create(C.byref(empty), 0)
+    assert b"empty scene" in L.tinsel_hip_last_error()
+
+    scene, cam, opt, g = _load("one_sphere")
+    r = tinsel_amd.create_gpu_renderer(scene)
+    with pytest.raises(tinsel_amd.TinselHipError):
+        r.render(cam, opt, passes=1)                    # before Init
+    r.init(opt.width, opt.height)
+    bad = opt.copy()
+    bad.width += 1
+    with pytest.raises(tinsel_amd.TinselHipError):
+        r.render(cam, bad, passes=1)                    # options do not match Init
+    with pytest.raises(tinsel_amd.TinselHipError):
+        r.render(cam, opt, passes=0)                    # the header promises passes >= 1
+    assert not r.read_accum().any()                     # and none of the refused calls touched the accumulator
+    r.close()
