@@ -43,7 +43,7 @@ def parse():
                     help="mesh BVHs: the reference's host-built trees (parity path) or rebuilt on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-core-seconds of oracle work")
-    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--tile", type=int, default=64, help="pixel-tile edge of the multi-GPU shard")
     return ap.parse_args()
 
 

@@ -207,3 +207,36 @@ def test_unsupported_inputs_fail_loudly():
         r.render(cam, opt, passes=0)                    # the header promises passes >= 1
     assert not r.read_accum().any()                     # and none of the refused calls touched the accumulator
     r.close()
+
+
+@pytest.mark.parametrize("pipeline", [abi.PIPELINE_WAVEFRONT, abi.PIPELINE_WAVEFRONT_SPLIT, abi.PIPELINE_MEGAKERNEL], ids=["wavefront", "split", "mega"])
+@pytest.mark.parametrize("world,tile,fwidth", [(4, 8, 1.0), (3, 20, 1.0), (8, 32, 0.75), (2, 32, 3.0), (5, 64, 1.0)])
+def test_every_shard_is_bit_identical_to_the_oracle_shard(pipeline, world, tile, fwidth):
+    """Each rank of a pixel-tile shard (only its own tiles are enumerated on the device; tiles that do not divide the
+    frame, more ranks than tile columns, a filter wide enough for the per-pixel accumulate) produces exactly the
+    accumulator the C oracle produces for that rank, and the ranks' sample counts add up to the frame's."""
+    import subprocess
+    from tests import oracle_api as oa
+    from tinsel_amd import create_gpu_renderer
+    if not oa.have_port():
+        subprocess.run(["make", "-C", os.path.join(oa.ROOT, "oracle"), "port"], check=True)
+    P = oa.PortOracle()
+    scene, cam, opt, g = _load("features")
+    opt.width, opt.height = 100, 70
+    opt.filter.width = fwidth
+    h = P.load_pack(os.path.join(GOLDEN, "features.pack"))
+    total = 0
+    for rank in range(world):
+        ref, nref = P.render_sharded(h, cam, opt, rank, world, tile=tile, passes=2)
+        r = create_gpu_renderer(scene)
+        r.set_pipeline(pipeline)
+        r.set_shard(rank, world, tile)
+        r.init(opt.width, opt.height)
+        out = r.render(cam, opt, passes=2)
+        n = r.stats()["samples"]
+        r.close()
+        assert n == nref
+        assert np.array_equal(out, ref), "rank %d of %d" % (rank, world)
+        total += n
+    P.free(h)
+    assert total == 2*opt.width*opt.height

@@ -262,6 +262,11 @@ struct tinsel_hip
     float4* accum = nullptr;
     bool accumOwned = true;
 
+    // sharded renders: accumulate tiles that have candidate paths of this shard (k_accumulate_tiled)
+    int* accTilesDev = nullptr;
+    int accTilesCount = 0;
+    int accTilesKey[6] = { 0, 0, 0, 0, 0, 0 };     // width, height, rank, world, shard tile, halo reach
+
     // display stage (tn_display.h): [0] filtered, [1] NLM means, [2] NLM output; sized width*height on first use
     float4* display[3] = { nullptr, nullptr, nullptr };
     size_t displayPixels = 0;
@@ -333,6 +338,9 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
         batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots) || batch_alloc(r, &r->queueNee, slots))
         return -1;
     ps.neePerPath = K;
+
+    // slots of other shards are never written (gen_slot): keep their radiance at zero for the test hook
+    HIP_TRY(hipMemset(ps.rad, 0, sizeof(float4)*slots));
 
     const size_t D = (size_t)maxDepth + 1;
     r->ctlWords = D*5;
@@ -517,12 +525,60 @@ void launch_shade(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, 
         hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), r->scene.arenaLdsBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth);
 }
 
+// Accumulate tiles (16x16 pixels + filter halo) that contain at least one pixel owned by this shard; cached per
+// (frame, shard, halo).  Ownership is a function of the pixel only (pixel_owned, tn_kernels.h).
+int accumulate_tile_list(tinsel_hip* r, const FrameParams& fp)
+{
+    const int reachLo = 1 + (int)floorf(fp.filterWidth), reachHi = (int)ceilf(fp.filterWidth);
+    const int key[6] = { fp.width, fp.height, fp.shardRank, fp.shardWorld, fp.shardTile, reachLo*16 + reachHi };
+    if (r->accTilesDev && memcmp(key, r->accTilesKey, sizeof(key)) == 0)
+        return 0;
+    const int tilesX = (fp.width + kAccTile - 1)/kAccTile, tilesY = (fp.height + kAccTile - 1)/kAccTile;
+    const int shardX = (fp.width + fp.shardTile - 1)/fp.shardTile;
+    std::vector<int> list;
+    for (int ty = 0; ty < tilesY; ++ty)
+    {
+        for (int tx = 0; tx < tilesX; ++tx)
+        {
+            // candidate paths of this tile are generated at pixels [x0, x1] x [y0, y1]
+            const int x0 = std::max(0, tx*kAccTile - reachLo), x1 = std::min(fp.width - 1, tx*kAccTile + kAccTile - 1 + reachHi);
+            const int y0 = std::max(0, ty*kAccTile - reachLo), y1 = std::min(fp.height - 1, ty*kAccTile + kAccTile - 1 + reachHi);
+            bool mine = false;
+            for (int sy = y0/fp.shardTile; sy <= y1/fp.shardTile && !mine; ++sy)
+                for (int sx = x0/fp.shardTile; sx <= x1/fp.shardTile && !mine; ++sx)
+                    mine = ((sy*shardX + sx) % fp.shardWorld) == fp.shardRank;
+            if (mine)
+                list.push_back(ty*tilesX + tx);
+        }
+    }
+    if (r->accTilesDev)
+    {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(r->accTilesDev);
+        r->accTilesDev = nullptr;
+    }
+    HIP_TRY(hipMalloc((void**)&r->accTilesDev, sizeof(int)*(list.empty() ? 1 : list.size())));
+    if (!list.empty())
+        HIP_TRY(hipMemcpy(r->accTilesDev, list.data(), sizeof(int)*list.size(), hipMemcpyHostToDevice));
+    r->accTilesCount = (int)list.size();
+    memcpy(r->accTilesKey, key, sizeof(key));
+    return 0;
+}
+
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp)
 {
     const size_t npix = (size_t)fp.width*fp.height;
     const size_t slots = npix*(size_t)fp.numPasses;
-    const int gridFlat = (int)((slots + kBlock - 1)/kBlock);
-    const int gridPersist = (int)std::min<size_t>((size_t)gridFlat, (size_t)r->numCUs*8);
+    // camera paths this shard enumerates per batch (gen_slot, tn_kernels.h)
+    fp.shardTilesX = (fp.width + fp.shardTile - 1)/fp.shardTile;
+    const int numTiles = fp.shardTilesX*((fp.height + fp.shardTile - 1)/fp.shardTile);
+    fp.shardOwnedTiles = fp.shardRank < numTiles ? (numTiles - fp.shardRank + fp.shardWorld - 1)/fp.shardWorld : 0;
+    const size_t gen = fp.shardWorld <= 1 ? slots : (size_t)fp.shardOwnedTiles*fp.shardTile*fp.shardTile*(size_t)fp.numPasses;
+    if (gen >= (size_t)0xffffffffu)
+        return fail("render: batch too large");
+    fp.genCount = (uint32_t)gen;
+    const int gridFlat = (int)((gen + kBlock - 1)/kBlock > 0 ? (gen + kBlock - 1)/kBlock : 1);
+    const int gridPersist = (int)std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*8);
     HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
     r->lastBatchSlots = slots;
 
@@ -574,8 +630,17 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         const int halo = 1 + (int)floorf(fp.filterWidth) + (int)ceilf(fp.filterWidth);
         if (halo <= kAccMaxHalo && fp.filterWidth >= 0.0f && fp.width < 65536 && fp.height < 65536)
         {
-            const int tiles = ((fp.width + kAccTile - 1)/kAccTile)*((fp.height + kAccTile - 1)/kAccTile);
-            hipLaunchKernelGGL(k_accumulate_tiled, dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, r->accum, r->passSeedsDev);
+            int tiles = ((fp.width + kAccTile - 1)/kAccTile)*((fp.height + kAccTile - 1)/kAccTile);
+            const int* tileList = nullptr;
+            if (fp.shardWorld > 1)
+            {
+                if (accumulate_tile_list(r, fp))
+                    return -1;
+                tileList = r->accTilesDev;
+                tiles = r->accTilesCount;
+            }
+            if (tiles > 0)
+                hipLaunchKernelGGL(k_accumulate_tiled, dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, r->accum, r->passSeedsDev, tileList);
         }
         else
         {
@@ -1124,6 +1189,7 @@ void tinsel_hip_destroy(tinsel_hip* r)
         if (d) (void)hipFree(d);
     for (void* p : r->lbvhAllocs)
         (void)hipFree(p);
+    if (r->accTilesDev) (void)hipFree(r->accTilesDev);
     if (r->passSeedsDev) (void)hipFree(r->passSeedsDev);
     if (r->statsDev) (void)hipFree(r->statsDev);
     for (TimedSpan& s : r->spans)
@@ -1355,6 +1421,12 @@ int tinsel_hip_set_shard(tinsel_hip* r, int rank, int world, int tile)
 {
     if (!r || world < 1 || rank < 0 || rank >= world || tile < 1)
         return fail("set_shard: bad arguments");
+    if (rank != r->shardRank || world != r->shardWorld || tile != r->shardTile)
+    {
+        HIP_TRY(hipSetDevice(r->device));
+        HIP_TRY(hipDeviceSynchronize());
+        free_batch(r);          // ownership changes: start from clean path buffers
+    }
     r->shardRank = rank;
     r->shardWorld = world;
     r->shardTile = tile;

@@ -76,6 +76,8 @@ struct FrameParams
     int numPasses;          // passes in this batch
     int maxDepth;
     int shardRank, shardWorld, shardTile;
+    int shardTilesX, shardOwnedTiles;   // tiles per frame row; tiles this shard owns (t % world == rank)
+    uint32_t genCount;                  // camera paths the generation kernels enumerate per batch (gen_slot)
     int filterType;
     float filterWidth, filterFalloff, filterOffset;
     float clampLen;
@@ -214,6 +216,33 @@ TN_D bool pixel_owned(const FrameParams& fp, int i, int j)
     return (t % fp.shardWorld) == fp.shardRank;
 }
 
+// The idx-th camera path this shard generates in a batch -> its slot (pass*W*H + j*W + i, the same numbering on every
+// shard).  One shard: slots in order.  Several: only the shard's OWN tiles are enumerated, tile after tile (lanes of
+// the generation kernels are all busy and slots of other shards are never touched); tiles that stick out of the
+// frame are padded to full size and the padding returns false.
+TN_D bool gen_slot(const FrameParams& fp, uint32_t idx, uint32_t& slot)
+{
+    if (fp.shardWorld <= 1)
+    {
+        slot = idx;
+        return true;
+    }
+    const uint32_t T = (uint32_t)fp.shardTile;
+    const uint32_t perPass = (uint32_t)fp.shardOwnedTiles*T*T;
+    const uint32_t s = idx/perPass;
+    const uint32_t o = idx - s*perPass;
+    const uint32_t k = o/(T*T);
+    const uint32_t within = o - k*T*T;
+    const uint32_t t = (uint32_t)fp.shardRank + k*(uint32_t)fp.shardWorld;
+    const uint32_t ty = t/(uint32_t)fp.shardTilesX, tx = t - ty*(uint32_t)fp.shardTilesX;
+    const uint32_t wy = within/T, wx = within - wy*T;
+    const uint32_t i = tx*T + wx, j = ty*T + wy;
+    if (i >= (uint32_t)fp.width || j >= (uint32_t)fp.height)
+        return false;
+    slot = s*(uint32_t)(fp.width*fp.height) + j*(uint32_t)fp.width + i;
+    return true;
+}
+
 // CameraSampler::GenerateRay (util.h:73-79) with TransformPoint(Mat44, Vec3) (maths.h:917-924)
 TN_D void generate_ray(const CameraParams& c, float rx, float ry, V3& o, V3& d)
 {
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
     SceneT<LDS> sc;
     stage_scene_lds(sc, scIn, s_scan + kScanWords);
 
-    const uint32_t count = FIRST ? (uint32_t)(fp.width*fp.height*fp.numPasses) : q.activeCount[bounce];
+    const uint32_t count = FIRST ? fp.genCount : q.activeCount[bounce];
     const uint32_t rounds = block_rounds(count);
     const uint32_t first = blockIdx.x*rounds*kBlock;       // this block's contiguous range
     uint32_t rays = 0, shadowRays = 0, samples = 0;
@@ -347,7 +376,14 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
             const uint32_t idx = base + g*kBlock + threadIdx.x;
             if (idx >= count)
                 continue;
-            const uint32_t slot = FIRST ? idx : queueIn[idx];
+            uint32_t slot;
+            if (FIRST)
+            {
+                if (!gen_slot(fp, idx, slot))
+                    continue;
+            }
+            else
+                slot = queueIn[idx];
 
             TN_TICK(4)
             PathRegs p;
@@ -444,7 +480,12 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
 
         block_append(keep, q.activeCount + bounce + 1, queueOut, s_scan, [&](int i) -> uint32_t {
             const uint32_t idx = base + (uint32_t)i*kBlock + threadIdx.x;
-            return FIRST ? idx : queueIn[idx];
+            uint32_t slot = 0;
+            if (FIRST)
+                (void)gen_slot(fp, idx, slot);
+            else
+                slot = queueIn[idx];
+            return slot;
         });
     }
 
@@ -474,7 +515,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q
                                                      const uint32_t* __restrict__ passSeeds)
 {
     __shared__ uint32_t s_scan[kScanWords];
-    const uint32_t count = (uint32_t)(fp.width*fp.height*fp.numPasses);
+    const uint32_t count = fp.genCount;
     const uint32_t rounds = block_rounds(count);
     const uint32_t first = blockIdx.x*rounds*kBlock;
     uint32_t samples = 0;
@@ -486,8 +527,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q
         uint32_t keep = 0;
         for (uint32_t g = 0; g < groups; ++g)
         {
-            const uint32_t slot = base + g*kBlock + threadIdx.x;
-            if (slot >= count)
+            const uint32_t idx = base + g*kBlock + threadIdx.x;
+            uint32_t slot;
+            if (idx >= count || !gen_slot(fp, idx, slot))
                 continue;
             PathRegs p;
             float rx, ry;
@@ -503,7 +545,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q
                 ps.rngRaster[slot] = make_float4(0.0f, 0.0f, -1e30f, -1e30f);
             }
         }
-        block_append(keep, q.activeCount + 0, queue0, s_scan, [&](int i) -> uint32_t { return base + (uint32_t)i*kBlock + threadIdx.x; });
+        block_append(keep, q.activeCount + 0, queue0, s_scan, [&](int i) -> uint32_t {
+            uint32_t slot = 0;
+            (void)gen_slot(fp, base + (uint32_t)i*kBlock + threadIdx.x, slot);
+            return slot;
+        });
     }
     wave_add_stat(q.stats, 1, samples);
 }
@@ -736,12 +782,14 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene scIn, 
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
     const int npix = fp.width*fp.height;
-    const int total = npix*fp.numPasses;
-    const int slot = blockIdx.x*kBlock + threadIdx.x;
+    const uint32_t idx = blockIdx.x*kBlock + threadIdx.x;
+    uint32_t uslot = 0;
+    const bool live = idx < fp.genCount && gen_slot(fp, idx, uslot);
+    const int slot = (int)uslot;
     uint32_t rays = 0, shadowRays = 0, samples = 0;
     TraceCounters ctr = { 0, 0, 0 };
 
-    if (slot < total)
+    if (live)
     {
         const int s = slot/npix;
         const int pix = slot - s*npix;
@@ -846,6 +894,12 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene scIn, 
 // adds the ones whose splat footprint [int(x-fw), int(x+fw)] x [int(y-fw), int(y+fw)] covers it --
 // exactly the adds, in exactly the order, the serial oracle performs on that pixel.
 
+template <class Tab>
+TN_D float filter_gauss_tab(float x, float falloff, float offset, const Tab& tab)     // same, expf table passed in
+{
+    return maxT(0.0f, float(m_expf_tab(-falloff*x*x, tab)) - offset);
+}
+
 TN_D float filter_gauss(float x, float falloff, float offset)      // Filter::Gaussian (render.h:29-32)
 {
     return maxT(0.0f, float(m_expf(-falloff*x*x)) - offset);
@@ -876,11 +930,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FramePar
         {
             for (int i = i0; i <= i1; ++i)
             {
+                if (!pixel_owned(fp, i, j))
+                    continue;       // path not generated by this shard (its slot was never written)
                 const size_t slot = passBase + (size_t)j*fp.width + i;
                 const float4 rr = ps.rngRaster[slot];
                 const float rx = rr.z, ry = rr.w;
-                if (rx < -1e29f)
-                    continue;       // path not generated by this shard
 
                 const int startX = maxI(0, int(rx - fw));
                 const int startY = maxI(0, int(ry - fw));
@@ -920,7 +974,7 @@ constexpr int kAccEntries = kAccSide*kAccSide;
 constexpr int kAccMaxFoot = 5;      // widest footprint (pixels per axis) for filter widths <= 2
 
 __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, FrameParams fp, float4* __restrict__ accum,
-                                                                const uint32_t* __restrict__ passSeeds)
+                                                                const uint32_t* __restrict__ passSeeds, const int* __restrict__ tileList)
 {
     // per candidate path of the tile: clamped sample, footprint [startX, startX+nX) x [startY, startY+nY)
     // and the separable Gaussian weights of its footprint columns / rows (each shared by up to 5 pixels)
@@ -928,9 +982,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
     __shared__ uint32_t s_y[kAccEntries];               // startY | nY << 16
     __shared__ float s_wx[kAccMaxFoot][kAccEntries];
     __shared__ float s_wy[kAccMaxFoot][kAccEntries];
+    __shared__ unsigned long long s_exp[32];            // expf's table: six data-dependent reads per staged path
+    if (threadIdx.x < 32)
+        s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __syncthreads();
 
+    // Sharded renders launch one block per tile that has candidate paths of THIS shard (tileList, built on the host:
+    // ownership depends on the pixel only); the other tiles have nothing to add in any pass, and with N shards they
+    // are most of the frame while the pass loop below is N x longer.
     const int tilesX = (fp.width + kAccTile - 1)/kAccTile;
-    const int tx = blockIdx.x % tilesX, ty = blockIdx.x/tilesX;
+    const int tile = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;
+    const int tx = tile % tilesX, ty = tile/tilesX;
     const int lx = threadIdx.x % kAccTile, ly = threadIdx.x/kAccTile;
     const int px = tx*kAccTile + lx, py = ty*kAccTile + ly;
     const bool inside = px < fp.width && py < fp.height;
@@ -951,17 +1013,40 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
     const int i0 = maxI(0, px - reachLo) - ox, i1 = minI(fp.width - 1, px + reachHi) - ox;
     const int j0 = maxI(0, py - reachLo) - oy, j1 = minI(fp.height - 1, py + reachHi) - oy;
 
+    // The (at most two) candidate entries this thread stages every pass: which path, where in LDS, whether the path
+    // is this shard's.  The radiance of the NEXT pass is requested before the current pass is processed.
+    int entLe[2], entGx[2], entGy[2];
+    bool entLive[2];
+    float4 nextRa[2];
+    for (int k = 0; k < 2; ++k)
+    {
+        const int e = threadIdx.x + k*kBlock;
+        const int ex = e % side, ey = e/side;
+        entGx[k] = ox + ex; entGy[k] = oy + ey;
+        entLe[k] = ey*kAccSide + ex;
+        entLive[k] = e < side*side && entGx[k] >= 0 && entGy[k] >= 0 && entGx[k] < fp.width && entGy[k] < fp.height &&
+                     pixel_owned(fp, entGx[k], entGy[k]);
+        nextRa[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (entLive[k] && fp.numPasses > 0)
+            nextRa[k] = ps.rad[(size_t)entGy[k]*fp.width + entGx[k]];
+    }
+
     for (int s = 0; s < fp.numPasses; ++s)
     {
-        const size_t passBase = (size_t)s*npix;
-        for (int e = threadIdx.x; e < side*side; e += kBlock)
+        float4 curRa[2] = { nextRa[0], nextRa[1] };
+        if (s + 1 < fp.numPasses)
+            for (int k = 0; k < 2; ++k)
+                if (entLive[k])
+                    nextRa[k] = ps.rad[(size_t)(s + 1)*npix + (size_t)entGy[k]*fp.width + entGx[k]];
+
+        for (int k = 0; k < 2; ++k)
         {
-            const int ex = e % side, ey = e/side;
-            const int gx = ox + ex, gy = oy + ey;
-            const int le = ey*kAccSide + ex;
+            if (threadIdx.x + k*kBlock >= side*side)
+                continue;
+            const int gx = entGx[k], gy = entGy[k], le = entLe[k];
             float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // nX == 0: covers nothing
             uint32_t ym = 0;
-            if (gx >= 0 && gy >= 0 && gx < fp.width && gy < fp.height && pixel_owned(fp, gx, gy))
+            if (entLive[k])
             {
                 // the raster position is the first two draws of the path's own stream (camera_sample):
                 // two LCG steps are cheaper than reading it back from the 16-B rngRaster record
@@ -969,7 +1054,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
                 const float x = rng.randf();
                 const float y = rng.randf();
                 const float rx = x + gx, ry = y + gy;
-                const float4 ra = ps.rad[passBase + (size_t)gy*fp.width + gx];
+                const float4 ra = curRa[k];
                 const V3 cl = clamp_length(V3(ra.x, ra.y, ra.z), fp.clampLen);
 
                 const int startX = maxI(0, int(rx - fw));
@@ -981,12 +1066,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
                 ym = (uint32_t)startY | (uint32_t)nY << 16;
                 if (gauss)
                 {
-                    for (int k = 0; k < kAccMaxFoot; ++k)
+                    for (int kk = 0; kk < kAccMaxFoot; ++kk)
                     {
-                        if (k < nX)
-                            s_wx[k][le] = filter_gauss((startX + k) - rx, fp.filterFalloff, fp.filterOffset);
-                        if (k < nY)
-                            s_wy[k][le] = filter_gauss((startY + k) - ry, fp.filterFalloff, fp.filterOffset);
+                        if (kk < nX)
+                            s_wx[kk][le] = filter_gauss_tab((startX + kk) - rx, fp.filterFalloff, fp.filterOffset, s_exp);
+                        if (kk < nY)
+                            s_wy[kk][le] = filter_gauss_tab((startY + kk) - ry, fp.filterFalloff, fp.filterOffset, s_exp);
                     }
                 }
             }

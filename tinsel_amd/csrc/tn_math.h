@@ -174,7 +174,9 @@ __device__ const unsigned long long kExp2fTab[32] = { 0x3ff0000000000000ULL, 0x3
 
 // glibc 2.35 expf, the __expf_fma ifunc variant an FMA-capable x86-64 host runs (e_expf.c, non-TOINT path: the
 // SHIFT trick; the compiler contracted InvLn2N*x + SHIFT and InvLn2N*x - kd into FMAs there, so they are FMAs here)
-TN_D float m_expf(float xf)
+// `tab`: kExp2fTab or a copy of it (kernels that call this in a tight loop keep one in LDS)
+template <class Tab>
+TN_D float m_expf_tab(float xf, const Tab& tab)
 {
     const uint32_t ix = __float_as_uint(xf);
     const uint32_t abstop = (ix >> 20) & 0x7ffu;
@@ -196,7 +198,7 @@ TN_D float m_expf(float xf)
     const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
     kd -= 0x1.8p+52;
     const double r = ::fma(0x1.71547652b82fep+5, x, -kd);
-    unsigned long long t = kExp2fTab[ki & 31u];
+    unsigned long long t = tab[ki & 31u];
     t += ki << (52 - 5);
     const double sc = __longlong_as_double((long long)t);
     const double z = ::fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
@@ -205,6 +207,7 @@ TN_D float m_expf(float xf)
     yv = ::fma(z, r2, yv);
     return (float)(yv*sc);
 }
+TN_D float m_expf(float xf) { return m_expf_tab(xf, kExp2fTab); }
 TN_D float m_logf(float x) { return (float)::log((double)x); }
 
 // glibc 2.35 __ieee754_acosf (sysdeps/ieee754/flt-32/e_acosf.c, the fdlibm fp32 routine; plain fp32 ops, no
