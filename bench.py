@@ -93,10 +93,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # TINSEL_BENCH_BACKEND=gloo + TINSEL_BENCH_ONE_DEVICE=1: run the N-rank code path on ONE GPU (validation of the
+    # launch / shard / reduce / reporting logic on a single-GPU box; not a measurement)
+    backend = os.environ.get("TINSEL_BENCH_BACKEND", "nccl")
+    if os.environ.get("TINSEL_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pack = os.path.join(ROOT, "tests", "golden", args.scene + ".pack")
     scene = tinsel_amd.Scene.load_pack(pack)
@@ -124,7 +132,14 @@ def main():
     def run(steps):
         r.render_async(cam, opt, passes=steps*passes_per_step, stream=stream)
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            if backend == "nccl":
+                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)         # RCCL over xGMI, on the render stream
+            else:
+                torch.cuda.synchronize()
+                host = accum.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    accum.copy_(host)
 
     def sync():
         if world > 1:
@@ -155,6 +170,7 @@ def main():
     r.reset_stats()
     r.enable_kernel_timing(True)
     sync()
+    first_timed_pass = r.get_pass_index()
     t0 = time.perf_counter()
     run(args.steps)
     sync()
@@ -166,10 +182,11 @@ def main():
 
     # max over ranks of the elapsed time; sums of the counters
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        small_dev = "cuda" if backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=small_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        cc = torch.tensor([st["rays"], st["samples"], st["shadow_rays"]], dtype=torch.float64, device="cuda")
+        cc = torch.tensor([st["rays"], st["samples"], st["shadow_rays"]], dtype=torch.float64, device=small_dev)
         dist.all_reduce(cc, op=dist.ReduceOp.SUM)
         tot_rays, tot_samples, tot_shadow = (float(x) for x in cc.tolist())
     else:
@@ -226,8 +243,24 @@ def main():
         "kernel_ms": {k: round(v[1], 3) for k, v in ktimes.items()},
     }
 
+    # validation mode only: the reduced image of the N-rank run must equal an unsharded render of the same passes
+    if os.environ.get("TINSEL_BENCH_ONE_DEVICE") and world > 1:
+        torch.cuda.synchronize()
+        chk = tinsel_amd.create_gpu_renderer(scene, local)
+        chk.init(opt.width, opt.height)
+        chk.set_pass_index(first_timed_pass)
+        want = chk.render(cam, opt, passes=args.steps*passes_per_step)
+        chk.close()
+        got = accum.cpu().numpy()
+        ok = np.allclose(got, want, rtol=1e-4, atol=1e-5)
+        print("validation: %d-rank reduced image vs unsharded render of passes [%d, %d): %s (max abs diff %.3e)" % (
+            world, first_timed_pass, first_timed_pass + args.steps*passes_per_step, "ok" if ok else "MISMATCH",
+            float(np.abs(got - want).max())), file=sys.stderr, flush=True)
+        if not ok:
+            raise SystemExit(3)
+
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
         try:
             cpu = cpu_baseline(args.scene, cam, opt, args.cpu_seconds)
         except Exception as e:      # a checker built for another box must not kill the bench line

@@ -1,0 +1,31 @@
+"""bench.py's N-rank code path, end to end, on ONE GPU: `python -m torch.distributed.run --nproc-per-node 2 bench.py
+--gpus 2` exactly as the driver launches it, with the two ranks sharing device 0 and `gloo` standing in for RCCL
+(TINSEL_BENCH_ONE_DEVICE / TINSEL_BENCH_BACKEND: validation switches, not a measurement).  Checks the launch, the
+pixel-tile shard, the reduce, the one-line JSON contract and -- inside bench.py -- that the reduced image equals an
+unsharded render of the same passes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_on_one_device():
+    env = dict(os.environ, TINSEL_BENCH_BACKEND="gloo", TINSEL_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "8", "--warmup", "1", "--width", "512", "--height", "384"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "validation: 2-rank reduced image vs unsharded render" in p.stderr and ": ok" in p.stderr, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout            # rank 0 prints ONE json line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["unit"] == "Msamples/s"
+    # weak scaling: 2 ranks x (8 steps x 2 passes) over half of the pixels each = 16 full-frame passes of samples
+    assert abs(d["value"]*d["ms_per_step"]*1e-3*8*1e6 - 16*512*384) < 1e-3*16*512*384
+    assert d["roofline"]["kernel"] and d["cpu_baseline"] is None

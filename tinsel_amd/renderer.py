@@ -215,6 +215,10 @@ class HipRenderer:
     def set_pipeline(self, pipeline):
         _check(self._L.tinsel_hip_set_pipeline(self._h, pipeline), "tinsel_hip_set_pipeline")
 
+    def get_pass_index(self):
+        """Index of the next pass (its seed is the (index+1)-th output of Random(1).Rand())."""
+        return int(self._L.tinsel_hip_get_pass_index(self._h))
+
     def set_pass_index(self, i):
         _check(self._L.tinsel_hip_set_pass_index(self._h, i), "tinsel_hip_set_pass_index")
 
