@@ -578,7 +578,10 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         return fail("render: batch too large");
     fp.genCount = (uint32_t)gen;
     const int gridFlat = (int)((gen + kBlock - 1)/kBlock > 0 ? (gen + kBlock - 1)/kBlock : 1);
-    const int gridPersist = (int)std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*8);
+    // blocks per CU of the streaming kernels' fixed grid.  Swept 4..256 on every config: 32 is best everywhere (finer
+    // static ranges even out the tail; beyond 64 the per-block staging and the shorter ranges cost more than they give)
+    static const int gridMult = getenv("TINSEL_HIP_GRID_MULT") ? atoi(getenv("TINSEL_HIP_GRID_MULT")) : 32;
+    const int gridPersist = (int)std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMult);
     HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
     r->lastBatchSlots = slots;
 

@@ -85,6 +85,11 @@ __global__ __launch_bounds__(256) void k_nlm_means(const float4* __restrict__ in
 __global__ __launch_bounds__(256) void k_nlm(const float4* __restrict__ in, const float4* __restrict__ means, float4* __restrict__ out,
                                              int width, int height, float falloff, int radius)
 {
+    __shared__ unsigned long long s_exp[32];            // expf's table: (2r+1)^2 data-dependent reads per pixel
+    if (threadIdx.x < 32)
+        s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __syncthreads();
+
     const int x = blockIdx.x*16 + (threadIdx.x & 15);
     const int y = blockIdx.y*16 + (threadIdx.x >> 4);
     if (x >= width || y >= height)
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void k_nlm(const float4* __restrict__ in, cons
             const float4 m = means[fy*width + fx];
             const float dx = mean.x - m.x, dy = mean.y - m.y, dz = mean.z - m.z, dw = mean.w - m.w;
             const float lsq = dx*dx + dy*dy + dz*dz + dw*dw;       // LengthSq(Vec4) (maths.h:331-332)
-            const float weight = m_expf(-falloff*lsq);
+            const float weight = m_expf_tab(-falloff*lsq, s_exp);
             const float4 c = in[fy*width + fx];
             sum.x += c.x*weight; sum.y += c.y*weight; sum.z += c.z*weight; sum.w += c.w*weight;
             totalWeight += weight;
