@@ -126,6 +126,7 @@ def main():
     accum = torch.zeros((opt.height, opt.width, 4), dtype=torch.float32, device="cuda")
     r.init(opt.width, opt.height, accum_tensor=accum)
     stream = torch.cuda.current_stream().cuda_stream
+    r.reserve(max(args.steps, args.warmup, 1)*world, opt.max_depth)      # no hipMalloc inside the timed region
 
     passes_per_step = world         # weak scaling: K*N passes over 1/N of the pixels each
 

@@ -279,7 +279,12 @@ int tinsel_hip_enable_kernel_timing(tinsel_hip* r, int enable);
 int tinsel_hip_stats_detail(tinsel_hip* r, unsigned long long* out8);
 int tinsel_hip_set_detail_counters(tinsel_hip* r, int enable);
 
-/* Upper bound on path slots resident per batch (default 4 Mi, or env TINSEL_HIP_BATCH_PATHS). */
+/* Allocates the per-batch path buffers a later render of `passes` passes at `max_depth` will need, so that the first
+ * such call does not pay for hipMalloc (tinsel_hip_render* allocate on demand otherwise). */
+int tinsel_hip_reserve(tinsel_hip* r, int passes, int max_depth);
+
+/* Upper bound on path slots resident per batch (default 8 Mi, 64 Mi for scenes with meshes in HBM; or env
+ * TINSEL_HIP_BATCH_PATHS). */
 int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths);
 
 /* Per-path radiance of the most recent batch (test hook): copies min(max_paths, paths in batch)

@@ -289,6 +289,7 @@ struct tinsel_hip
 
     size_t lastBatchSlots = 0;
     size_t maxBatchSlots = 8u << 20;
+    bool batchSlotsExplicit = false;     // set by TINSEL_HIP_BATCH_PATHS / tinsel_hip_set_batch_paths
     int pipeline = TINSEL_PIPELINE_AUTO;
     bool countDetail = false;
 
@@ -565,6 +566,17 @@ int accumulate_tile_list(tinsel_hip* r, const FrameParams& fp)
     return 0;
 }
 
+// Paths resident per batch.  Default 8 Mi (1 GB of state): best for scenes that live in LDS.  Scenes with meshes
+// in HBM run the split pipeline, whose trace launches end in a long tail (the slowest block of a deep traversal):
+// fewer, larger launches amortise it -- 524k-triangle config 765 / 941 / 992 Msamples/s at 8 / 32 / 64 Mi -- so
+// those default to 64 Mi (13 GB of 288).  An explicit setting always wins.
+size_t batch_slots(const tinsel_hip* r)
+{
+    if (!r->batchSlotsExplicit && !r->scene.allInArena && r->pipeline != TINSEL_PIPELINE_MEGAKERNEL)
+        return (size_t)64u << 20;
+    return r->maxBatchSlots;
+}
+
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp)
 {
     const size_t npix = (size_t)fp.width*fp.height;
@@ -727,7 +739,7 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
     // by the runtime, but do not rely on it)
     HIP_TRY(hipStreamSynchronize(st));
 
-    int perBatch = (int)std::max<size_t>(1, r->maxBatchSlots/npix);
+    int perBatch = (int)std::max<size_t>(1, batch_slots(r)/npix);
     if (perBatch > passes)
         perBatch = passes;
     if (ensure_batch(r, npix*(size_t)perBatch, fp.maxDepth))
@@ -870,7 +882,10 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
     {
         long long v = atoll(e);
         if (v >= 65536)
+        {
             r->maxBatchSlots = (size_t)v;
+            r->batchSlotsExplicit = true;
+        }
     }
 
     DevScene& sc = r->scene;
@@ -1547,11 +1562,24 @@ int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entr
     return n;
 }
 
+int tinsel_hip_reserve(tinsel_hip* r, int passes, int max_depth)
+{
+    if (!r || !r->accum || passes < 1 || max_depth < 1)
+        return fail("reserve: bad arguments (Init first)");
+    HIP_TRY(hipSetDevice(r->device));
+    const size_t npix = (size_t)r->width*r->height;
+    int perBatch = (int)std::max<size_t>(1, batch_slots(r)/npix);
+    if (perBatch > passes)
+        perBatch = passes;
+    return ensure_batch(r, npix*(size_t)perBatch, max_depth);
+}
+
 int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths)
 {
     if (!r || max_paths < 1024)
         return fail("set_batch_paths: bad arguments");
     r->maxBatchSlots = (size_t)max_paths;
+    r->batchSlotsExplicit = true;
     return 0;
 }
 
