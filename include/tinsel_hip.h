@@ -166,7 +166,7 @@ typedef struct tinsel_hip tinsel_hip;       /* opaque */
  * identical per-path arithmetic. */
 enum { TINSEL_PIPELINE_WAVEFRONT = 0, TINSEL_PIPELINE_MEGAKERNEL = 1, TINSEL_PIPELINE_WAVEFRONT_SPLIT = 2,
        /* default: WAVEFRONT (fused bounce kernel) when the whole scene is LDS-resident and a bounce casts at
-        * most one NEE ray, else WAVEFRONT_SPLIT, whose trace-only kernels run at twice the occupancy
+        * most two NEE rays, else WAVEFRONT_SPLIT, whose trace-only kernels run at twice the occupancy
         * (measured crossover: DESIGN.md section 5) */
        TINSEL_PIPELINE_AUTO = 3 };
 

@@ -599,7 +599,9 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
 
     int pipeline = r->pipeline;
     if (pipeline == TINSEL_PIPELINE_AUTO)
-        pipeline = (r->scene.allInArena && r->neePerPath <= 1) ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
+        // measured fused -> split, Msamples/s: 1 NEE ray per bounce cornell 2588 -> 1630; 2 rays cornell+probe 1840 -> 1375,
+        // env_loft 3008 -> 2443; 4 rays veach 1304 -> 1340; 9 rays features 540 -> 668
+        pipeline = (r->scene.allInArena && r->neePerPath <= 2) ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
 
     if (pipeline == TINSEL_PIPELINE_MEGAKERNEL)
     {
