@@ -1121,7 +1121,8 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         {
             sc.arena = arenaDev;
             sc.arenaBytes = (uint32_t)arena.bytes.size();
-            sc.arenaLdsBytes = (arena.bytes.size() <= kArenaLdsLimit && !getenv("TINSEL_HIP_NO_LDS_SCENE")) ? sc.arenaBytes : 0u;
+            const size_t ldsLimit = getenv("TINSEL_HIP_ARENA_LDS_LIMIT") ? (size_t)atoll(getenv("TINSEL_HIP_ARENA_LDS_LIMIT")) : kArenaLdsLimit;
+            sc.arenaLdsBytes = (arena.bytes.size() <= ldsLimit && !getenv("TINSEL_HIP_NO_LDS_SCENE")) ? sc.arenaBytes : 0u;
             sc.nodes = reinterpret_cast<const Node64*>(arenaDev + offNodes);
             sc.prims = reinterpret_cast<const Prim64*>(arenaDev + offPrims);
             sc.mats = reinterpret_cast<const Mat128*>(arenaDev + offMats);
