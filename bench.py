@@ -269,7 +269,8 @@ def main():
 
     msamples = tot_samples/elapsed/1e6
     line = {
-        "metric": "Msamples/s (cornell.tin 1024x1024 maxDepth=4 spp=256, wavefront path; Mrays/s alongside)",
+        "metric": "Msamples/s (%s.tin %dx%d maxDepth=%d spp=%d, wavefront path; Mrays/s alongside)" % (
+            args.scene, opt.width, opt.height, opt.max_depth, args.steps*passes_per_step),
         "value": msamples, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed*1e3/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

@@ -594,6 +594,8 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     // static ranges even out the tail; beyond 64 the per-block staging and the shorter ranges cost more than they give)
     static const int gridMult = getenv("TINSEL_HIP_GRID_MULT") ? atoi(getenv("TINSEL_HIP_GRID_MULT")) : 32;
     const int gridPersist = (int)std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMult);
+    static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : gridMult;
+    const int gridTrace = (int)std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMultTrace);
     HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
     r->lastBatchSlots = slots;
 
@@ -628,7 +630,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             uint32_t* qout = r->queues[(bounce + 1) & 1];
             {
                 ScopedTimer t(r, KN_EXTEND, st);
-                launch_extend(r, st, gridPersist, qin, bounce);
+                launch_extend(r, st, gridTrace, qin, bounce);
             }
             {
                 ScopedTimer t(r, KN_SHADE, st);
@@ -637,7 +639,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             if (r->neePerPath > 0)
             {
                 ScopedTimer t(r, KN_SHADOW, st);
-                launch_shadow(r, st, gridPersist, r->queueNee, bounce);
+                launch_shadow(r, st, gridTrace, r->queueNee, bounce);
             }
         }
     }
