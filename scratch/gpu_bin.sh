@@ -1,0 +1,16 @@
+#!/bin/bash
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_fuzz.py -m gpu -x -q 2>&1 | tail -3
+run() { timeout 600 python bench.py "$@" --no-cpu-baseline 2>/tmp/err.txt > /tmp/b.json || tail -3 /tmp/err.txt
+python - <<PY
+import json
+d=json.load(open('/tmp/b.json'))
+print('nobin=${TINSEL_HIP_NO_BIN:-0} %-34s Msamples/s %7.1f' % (d['config']['workload'][:34], d['value']), d['roofline']['kernel_ms'])
+PY
+}
+for rep in 1 2; do
+for nb in "" 1; do
+if [ -n "$nb" ]; then export TINSEL_HIP_NO_BIN=1; else unset TINSEL_HIP_NO_BIN; fi
+run --scene large/ajax_standin --width 1920 --height 1080 --steps 64 --warmup 2
+run --scene glass --width 1920 --height 1080 --maxdepth 12 --steps 32 --warmup 1
+done
+done

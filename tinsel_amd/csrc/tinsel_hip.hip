@@ -235,8 +235,8 @@ struct DeviceArena
 };
 
 const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals", "k_bounce",
-                               "k_present", "k_nlm_means", "k_nlm" };
-enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_COUNT };
+                               "k_present", "k_nlm_means", "k_nlm", "k_bin_rays" };
+enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_BIN, KN_COUNT };
 
 struct TimedSpan { int kernel; hipEvent_t start, stop; };
 
@@ -283,6 +283,9 @@ struct tinsel_hip
     size_t ctlWords = 0;
     uint32_t* queues[2] = { nullptr, nullptr };
     uint32_t* queueNee = nullptr;
+    uint32_t* queueBinned = nullptr;    // k_bin_rays output (split pipeline, scenes with meshes in HBM)
+    uint32_t* binCounters = nullptr;    // [4*(maxDepth+1)]: front/back cursors of the extension and the shadow bin per bounce
+    BinPrims binPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };
     uint32_t* passSeedsDev = nullptr;
     size_t passSeedsCap = 0;
     unsigned long long* statsDev = nullptr;
@@ -336,7 +339,8 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
         batch_alloc(r, &ps.rad, slots) || batch_alloc(r, &ps.absorb, slots) || batch_alloc(r, &ps.rngRaster, slots) ||
         batch_alloc(r, &ps.hit, slots) || batch_alloc(r, &ps.hitPrim, slots) ||
         batch_alloc(r, &ps.nee, slots*(size_t)K*4) || batch_alloc(r, &ps.neeThr, slots) ||
-        batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots) || batch_alloc(r, &r->queueNee, slots))
+        batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots) || batch_alloc(r, &r->queueNee, slots) ||
+        batch_alloc(r, &r->queueBinned, r->binPrims.count ? slots : 1) || batch_alloc(r, &r->binCounters, 4*((size_t)maxDepth + 1)))
         return -1;
     ps.neePerPath = K;
 
@@ -597,6 +601,8 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : gridMult;
     const int gridTrace = (int)std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMultTrace);
     HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(r->binCounters, 0, 4*((size_t)fp.maxDepth + 1)*sizeof(uint32_t), st));
+    static const bool noBin = getenv("TINSEL_HIP_NO_BIN") != nullptr;
     r->lastBatchSlots = slots;
 
     int pipeline = r->pipeline;
@@ -628,9 +634,18 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         {
             uint32_t* qin = r->queues[bounce & 1];
             uint32_t* qout = r->queues[(bounce + 1) & 1];
+            const uint32_t* qtrace = qin;
+            if (r->binPrims.count && !r->countDetail && !noBin)
+            {
+                // rays that enter a big mesh first, the rest last (k_bin_rays): same rays, same results
+                ScopedTimer t(r, KN_BIN, st);
+                hipLaunchKernelGGL(k_bin_rays<false>, dim3(gridPersist), dim3(kBlock), 0, st, r->scene.primBoxes, r->ps, r->ctl, qin, r->queueBinned, bounce,
+                                   r->binPrims, r->binCounters + 4*bounce);
+                qtrace = r->queueBinned;
+            }
             {
                 ScopedTimer t(r, KN_EXTEND, st);
-                launch_extend(r, st, gridTrace, qin, bounce);
+                launch_extend(r, st, gridTrace, qtrace, bounce);
             }
             {
                 ScopedTimer t(r, KN_SHADE, st);
@@ -638,8 +653,16 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             }
             if (r->neePerPath > 0)
             {
+                const uint32_t* qshadow = r->queueNee;
+                if (r->binPrims.count && !r->countDetail && !noBin)
+                {
+                    ScopedTimer t(r, KN_BIN, st);
+                    hipLaunchKernelGGL(k_bin_rays<true>, dim3(gridPersist), dim3(kBlock), 0, st, r->scene.primBoxes, r->ps, r->ctl, r->queueNee, r->queueBinned,
+                                       bounce, r->binPrims, r->binCounters + 4*bounce + 2);
+                    qshadow = r->queueBinned;
+                }
                 ScopedTimer t(r, KN_SHADOW, st);
-                launch_shadow(r, st, gridTrace, r->queueNee, bounce);
+                launch_shadow(r, st, gridTrace, qshadow, bounce);
             }
         }
     }
@@ -1139,6 +1162,12 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 if (mm.absorption[0] != 0.0f || mm.absorption[1] != 0.0f || mm.absorption[2] != 0.0f)
                     sc.hasMedia = 1;
             sc.flatScan = (everyPrimHasALeaf && P <= 64 && !getenv("TINSEL_HIP_NO_FLAT_SCAN")) ? 1 : 0;
+            // primitives whose mesh lives in HBM: their leaf-box test sorts the ray queues (k_bin_rays)
+            r->binPrims.count = 0;
+            if (sc.flatScan)
+                for (int k = 0; k < P && r->binPrims.count < 7; ++k)
+                    if (prims[(size_t)k].type == kPrimMesh && !meshes[prims[(size_t)k].mesh].inArena)
+                        r->binPrims.prim[r->binPrims.count++] = k;
             bool all = sc.arenaLdsBytes != 0;
             for (const DevMesh& dmesh : meshes)
                 all = all && dmesh.inArena;
