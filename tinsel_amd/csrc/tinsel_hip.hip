@@ -348,7 +348,7 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
     HIP_TRY(hipMemset(ps.rad, 0, sizeof(float4)*slots));
 
     const size_t D = (size_t)maxDepth + 1;
-    r->ctlWords = D*5;
+    r->ctlWords = D*6;
     if (batch_alloc(r, &r->ctlBase, r->ctlWords))
         return -1;
     r->ctl.activeCount = r->ctlBase;
@@ -356,6 +356,7 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
     r->ctl.cursorExtend = r->ctlBase + 2*D;
     r->ctl.cursorShade = r->ctlBase + 3*D;
     r->ctl.cursorShadow = r->ctlBase + 4*D;
+    r->ctl.activeBack = r->ctlBase + 5*D;
     r->ctl.stats = r->statsDev;
 
     r->batchSlots = slots;
@@ -593,6 +594,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     if (gen >= (size_t)0xffffffffu)
         return fail("render: batch too large");
     fp.genCount = (uint32_t)gen;
+    fp.queueCapacity = (uint32_t)r->batchSlots;
     const int gridFlat = (int)((gen + kBlock - 1)/kBlock > 0 ? (gen + kBlock - 1)/kBlock : 1);
     // blocks per CU of the streaming kernels' fixed grid.  Swept 4..256 on every config: 32 is best everywhere (finer
     // static ranges even out the tail; beyond 64 the per-block staging and the shorter ranges cost more than they give)
@@ -1162,6 +1164,16 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 if (mm.absorption[0] != 0.0f || mm.absorption[1] != 0.0f || mm.absorption[2] != 0.0f)
                     sc.hasMedia = 1;
             sc.flatScan = (everyPrimHasALeaf && P <= 64 && !getenv("TINSEL_HIP_NO_FLAT_SCAN")) ? 1 : 0;
+            // Fused kernel: sort the next bounce's queue by "meets the box of a bounded primitive" (tn_isect.h) when the
+            // scene is open.  Measured (cornell-sized frames, fused kernel): env_loft (1 plane) +16 %, gloss (1 plane) +4 %;
+            // the closed boxes cornell / cornell+probe (5 planes, every NEE ray aimed at the light mesh) -4 %: the test and
+            // the second append cost more than the plane-only waves save.
+            {
+                int planes = 0;
+                for (int k = 0; k < P; ++k)
+                    planes += boxes[(size_t)k].alwaysHit ? 1 : 0;
+                sc.sortQueues = (sc.flatScan && planes <= 2 && planes < P && !getenv("TINSEL_HIP_NO_SORT_QUEUES")) ? 1 : 0;
+            }
             // primitives whose mesh lives in HBM: their leaf-box test sorts the ray queues (k_bin_rays)
             r->binPrims.count = 0;
             if (sc.flatScan)

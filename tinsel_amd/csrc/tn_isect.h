@@ -360,6 +360,26 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
     return closest;
 }
 
+// Does this ray pass the leaf-box test of any primitive that is NOT an always-hit plane (flat-scan scenes)?  The
+// producer of a ray queue sorts by this bit: a wave of rays that can only hit the planes skips the sphere and mesh code
+// of trace_flat altogether, and the waves that do run it have their lanes on it.  The same box tests as trace_flat's.
+template <class SC>
+TN_D bool ray_meets_bounded_prim(const SC& sc, V3 o, V3 d)
+{
+    const V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    bool any = false;
+    for (int i = 0; i < sc.numPrims; ++i)
+    {
+        const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + i);
+        const float4 b0 = bp[0], b1 = bp[1];
+        if (__float_as_uint(b1.z) != 0u)
+            continue;
+        float tb;
+        any = any || ray_aabb(o, rcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tb);
+    }
+    return any;
+}
+
 // Trace (render.cpp:17-62) over QueryBVH (intersection.h:751-799).
 // Returns the primitive index or -1; outN is already FaceForward(n, -dir) (render.cpp:59).
 template <class SC, class Stack, bool COUNT>

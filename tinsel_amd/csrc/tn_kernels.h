@@ -54,7 +54,8 @@ struct PathState
 struct QueueCtl
 {
     // all indexed by bounce; zeroed once per batch
-    uint32_t* activeCount;  // [maxDepth+1]
+    uint32_t* activeCount;  // [maxDepth+1]   entries at the FRONT of queue[bounce]
+    uint32_t* activeBack;   // [maxDepth+1]   entries at the BACK (fused pipeline: rays that meet no bounded primitive)
     uint32_t* neeCount;     // [maxDepth]
     uint32_t* cursorExtend; // [maxDepth]
     uint32_t* cursorShade;  // [maxDepth]
@@ -78,6 +79,7 @@ struct FrameParams
     int shardRank, shardWorld, shardTile;
     int shardTilesX, shardOwnedTiles;   // tiles per frame row; tiles this shard owns (t % world == rank)
     uint32_t genCount;                  // camera paths the generation kernels enumerate per batch (gen_slot)
+    uint32_t queueCapacity;             // entries per ray queue (= path slots of the batch)
     int filterType;
     float filterWidth, filterFalloff, filterOffset;
     float clampLen;
@@ -147,6 +149,13 @@ TN_D void block_append(uint32_t bits, uint32_t* counter, uint32_t* __restrict__ 
         base += (uint32_t)__popcll(masks[i]);
     }
     __syncthreads();        // s_scan is reused by the next call
+}
+
+// A queue filled from both ends: entries [0, front) and [capacity - back, capacity).  Item `idx` of the front + back
+// items, front ones first.
+TN_D uint32_t two_ended(uint32_t idx, uint32_t front, uint32_t back, uint32_t capacity)
+{
+    return idx < front ? idx : capacity - back + (idx - front);
 }
 
 // statistics: wave reduction, then one atomic per wave into this block's shard (distinct addresses)
@@ -363,7 +372,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
     SceneT<LDS> sc;
     stage_scene_lds(sc, scIn, s_scan + kScanWords);
 
-    const uint32_t count = FIRST ? fp.genCount : q.activeCount[bounce];
+    const uint32_t frontCount = FIRST ? 0u : q.activeCount[bounce], backCount = FIRST ? 0u : q.activeBack[bounce];
+    const uint32_t count = FIRST ? fp.genCount : frontCount + backCount;
     const uint32_t rounds = block_rounds(count);
     const uint32_t first = blockIdx.x*rounds*kBlock;       // this block's contiguous range
     uint32_t rays = 0, shadowRays = 0, samples = 0;
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
         const uint32_t base = first + r0*kBlock;
         const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
 
-        uint32_t keep = 0;
+        uint32_t keep = 0, keepBack = 0;
         for (uint32_t g = 0; g < groups; ++g)
         {
             const uint32_t idx = base + g*kBlock + threadIdx.x;
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
                     continue;
             }
             else
-                slot = queueIn[idx];
+                slot = queueIn[two_ended(idx, frontCount, backCount, fp.queueCapacity)];
 
             TN_TICK(4)
             PathRegs p;
@@ -473,7 +483,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
             if (alive)
             {
                 store_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
-                keep |= 1u << g;
+                // next bounce's queue, sorted: rays that meet a bounded primitive's box in front, plane-only rays at the back
+                if (!sc.sortQueues || ray_meets_bounded_prim(sc, p.o, p.d))
+                    keep |= 1u << g;
+                else
+                    keepBack |= 1u << g;
             }
             else
             {
@@ -483,15 +497,18 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
             }
         }
 
-        block_append(keep, q.activeCount + bounce + 1, queueOut, s_scan, [&](int i) -> uint32_t {
+        auto slotOf = [&](int i) -> uint32_t {
             const uint32_t idx = base + (uint32_t)i*kBlock + threadIdx.x;
             uint32_t slot = 0;
             if (FIRST)
                 (void)gen_slot(fp, idx, slot);
             else
-                slot = queueIn[idx];
+                slot = queueIn[two_ended(idx, frontCount, backCount, fp.queueCapacity)];
             return slot;
-        });
+        };
+        block_append(keep, q.activeCount + bounce + 1, queueOut, s_scan, slotOf);
+        if (sc.sortQueues)
+            block_append(keepBack, q.activeBack + bounce + 1, queueOut, s_scan, slotOf, fp.queueCapacity - 1u);
     }
 
     wave_add_stat(q.stats, 0, rays);

@@ -153,6 +153,8 @@ struct DevScene
     const PrimBox* primBoxes;   // [numPrims], in the arena
     int32_t flatScan;           // 1: few primitives -> scene level is a wave-uniform scan (trace_flat)
     int32_t hasMedia;           // 0: no material absorbs, rayAbsorption stays 0 -> its 16-B state record is skipped
+    int32_t sortQueues;         // 1: the fused kernel sorts the next bounce's queue by ray_meets_bounded_prim (open scenes)
+    int32_t padScene;
 };
 
 // Compile-time view of where the scene lives.  SceneT<true>: the whole scene (arena incl. every mesh)
