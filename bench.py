@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--pipeline", choices=["auto", "wavefront", "mega", "split"], default="auto")
     ap.add_argument("--bvh", choices=["reference", "lbvh"], default="reference",
                     help="mesh BVHs: the reference's host-built trees (parity path) or rebuilt on the device")
+    ap.add_argument("--roulette", type=int, default=0, help="opt-in Russian roulette from this bounce on (0 = the reference's behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-core-seconds of oracle work")
     ap.add_argument("--tile", type=int, default=64, help="pixel-tile edge of the multi-GPU shard")
@@ -119,6 +120,8 @@ def main():
 
     r = tinsel_amd.create_gpu_renderer(scene, local)
     bvh_build_ms = r.set_mesh_bvh(abi.BVH_LBVH) if args.bvh == "lbvh" else None
+    if args.roulette > 0:
+        r.set_russian_roulette(args.roulette)
     r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
     if world > 1:
         r.set_shard(rank, world, args.tile)
@@ -279,7 +282,7 @@ def main():
             args.pipeline if args.pipeline != "auto" else "auto->" + ("wavefront(fused)" if "k_bounce" in ktimes else "wavefront(split)")),
             "scene_pack": os.path.relpath(pack, ROOT), "parallelism": "pixel-tile shard x%d + RCCL reduce" % world if world > 1 else "1 GPU",
             "filter": "gaussian w=%.2f" % fw, "rays_per_sample": tot_rays/max(1.0, tot_samples),
-            "mesh_bvh": args.bvh, "mesh_bvh_build_ms": bvh_build_ms},
+            "mesh_bvh": args.bvh, "mesh_bvh_build_ms": bvh_build_ms, "russian_roulette_from_bounce": args.roulette},
         "mrays_per_s": tot_rays/elapsed/1e6,
         "shadow_ray_fraction": tot_shadow/max(1.0, tot_rays),
         "gpu_kernel_ms_total": gpu_ms,

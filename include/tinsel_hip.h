@@ -217,6 +217,14 @@ int tinsel_hip_read_accum(tinsel_hip* r, float* out_rgba);
 enum { TINSEL_BVH_REFERENCE = 0, TINSEL_BVH_LBVH = 1 };
 int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms);
 
+/* Russian roulette, OPT-IN (start_bounce = 0, the default, is the reference's behaviour: render.cpp:250 runs every
+ * path to maxDepth and so does the parity path).  With start_bounce = b > 0, after every bounce i >= b - 1 that has a
+ * successor the path survives with probability q = min(1, max(throughput.rgb)) and its throughput is divided by q: the
+ * estimate stays unbiased, deep low-throughput paths (glass at maxDepth 12) stop early.  Draws one extra number from
+ * the path's stream when q < 1, so images differ from the reference's sample by sample; the same rule is restated in
+ * the C oracle (port_set_russian_roulette) and the two are compared bit for bit. */
+int tinsel_hip_set_russian_roulette(tinsel_hip* r, int start_bounce);
+
 /* Resume a progressive render: replaces the accumulator with a saved one (W*H*4 floats, as read_accum returned
  * it) and sets the index of the next pass, so that `read_accum after k passes` + `write_accum(.., k)` + more passes
  * gives the same image bit for bit as one uninterrupted render (pass seeds depend on the pass index only). */

@@ -858,6 +858,11 @@ static vec3 sample_lights(const scene_t* sc, const tinsel_primitive* surf, float
     return sum;
 }
 
+/* Russian roulette: NOT in the reference (render.cpp:250 runs every path to maxDepth) -- an opt-in of the HIP library
+ * (tinsel_hip_set_russian_roulette) restated here so that the mode has an oracle too.  0 = off = the reference. */
+static int g_rr_start = 0;
+void port_set_russian_roulette(int start_bounce) { g_rr_start = start_bounce; }
+
 static vec3 path_trace(const scene_t* sc, vec3 startOrigin, vec3 startDir, float time, int maxDepth, rng_t* rand, counters* ct)  /* :230-388 */
 {
     vec3 pathThroughput = v3(1.0f, 1.0f, 1.0f);
@@ -944,6 +949,20 @@ static vec3 path_trace(const scene_t* sc, vec3 startOrigin, vec3 startDir, float
             rayType = bsdfType;
             rayDir = bsdfDir;
             rayOrigin = vadd(p, vscale(face_forward(n, bsdfDir), kRayEpsilon));
+
+            if (g_rr_start > 0 && i + 1 >= g_rr_start && i + 1 < maxDepth)
+            {
+                float q = minT(1.0f, maxT(pathThroughput.x, maxT(pathThroughput.y, pathThroughput.z)));
+                if (!(q > 0.0f))
+                    break;
+                if (q < 1.0f)
+                {
+                    float u = rng_randf(rand);
+                    if (u >= q)
+                        break;
+                    pathThroughput = vscale(pathThroughput, 1.0f/q);
+                }
+            }
         }
         else
         {

@@ -256,6 +256,7 @@ struct tinsel_hip
     std::vector<DevMesh> meshesRef, meshesNow;
     int sceneStackNeed = 1;
     int bvhMode = TINSEL_BVH_REFERENCE;
+    int rrStart = 0;                    // > 0: Russian roulette from this bounce on (opt-in)
     std::vector<void*> lbvhAllocs;
 
     int width = 0, height = 0;
@@ -526,9 +527,9 @@ void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams&
 void launch_shade(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, int maxDepth)
 {
     if (r->scene.allInArena)
-        hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), r->scene.arenaBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth);
+        hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), r->scene.arenaBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth, r->rrStart);
     else
-        hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), r->scene.arenaLdsBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth);
+        hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), r->scene.arenaLdsBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth, r->rrStart);
 }
 
 // Accumulate tiles (16x16 pixels + filter halo) that contain at least one pixel owned by this shard; cached per
@@ -594,6 +595,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     if (gen >= (size_t)0xffffffffu)
         return fail("render: batch too large");
     fp.genCount = (uint32_t)gen;
+    fp.rrStart = r->rrStart;
     fp.queueCapacity = (uint32_t)r->batchSlots;
     const int gridFlat = (int)((gen + kBlock - 1)/kBlock > 0 ? (gen + kBlock - 1)/kBlock : 1);
     // blocks per CU of the streaming kernels' fixed grid.  Swept 4..256 on every config: 32 is best everywhere (finer
@@ -1467,6 +1469,14 @@ int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
             (void)hipFree(p);
         r->lbvhAllocs.clear();
     }
+    return 0;
+}
+
+int tinsel_hip_set_russian_roulette(tinsel_hip* r, int start_bounce)
+{
+    if (!r || start_bounce < 0)
+        return fail("set_russian_roulette: bad arguments");
+    r->rrStart = start_bounce;
     return 0;
 }
 

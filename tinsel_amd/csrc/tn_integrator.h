@@ -315,6 +315,25 @@ TN_D int bsdf_step(PathRegs& p, const Mat& mat, const HitCtx& h)
     return kContinue;
 }
 
+// Russian roulette (NOT in the reference: render.cpp:250 runs every path to maxDepth; opt-in through
+// tinsel_hip_set_russian_roulette, restated identically in oracle/tinsel_oracle.c).  Called after a bounce whose
+// successor will be traced: the path survives with probability q = min(1, max(throughput)) and is compensated by 1/q,
+// so the estimate stays unbiased.  One extra draw from the path's stream when q < 1.
+TN_D bool roulette_survives(PathRegs& p)
+{
+    const float q = minT(1.0f, maxT(p.thr.x, maxT(p.thr.y, p.thr.z)));
+    if (!(q > 0.0f))
+        return false;
+    if (q < 1.0f)
+    {
+        const float u = p.rng.randf();
+        if (u >= q)
+            return false;
+        p.thr = p.thr*(1.0f/q);
+    }
+    return true;
+}
+
 // render.cpp:365-383
 TN_D void on_miss(const DevScene& sc, PathRegs& p, int bounce)
 {

@@ -80,6 +80,7 @@ struct FrameParams
     int shardTilesX, shardOwnedTiles;   // tiles per frame row; tiles this shard owns (t % world == rank)
     uint32_t genCount;                  // camera paths the generation kernels enumerate per batch (gen_slot)
     uint32_t queueCapacity;             // entries per ray queue (= path slots of the batch)
+    int rrStart;                        // > 0: Russian roulette from this bounce on (opt-in, not the reference's behaviour)
     int filterType;
     float filterWidth, filterFalloff, filterOffset;
     float clampLen;
@@ -476,6 +477,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
                     // the material is read again rather than kept in 28 registers across the shadow traces
                     const Mat matAgain = load_mat(sc.mats, prim);
                     alive = (bsdf_step(p, matAgain, h) == kContinue);
+                    if (alive && fp.rrStart > 0 && bounce + 1 >= fp.rrStart)
+                        alive = roulette_survives(p);
                 }
             }
 
@@ -648,7 +651,7 @@ TN_D NeeRec load_nee(const PathState& ps, uint32_t slot, int k)
 
 template <bool LDS>
 __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue,
-                                                  uint32_t* __restrict__ queueNext, uint32_t* __restrict__ queueNee, int bounce, int maxDepth)
+                                                  uint32_t* __restrict__ queueNext, uint32_t* __restrict__ queueNee, int bounce, int maxDepth, int rrStart)
 {
     __shared__ uint32_t s_scan[kScanWords];
     extern __shared__ uint32_t s_arena[];
@@ -718,6 +721,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
             int res = kTerminate;
             if (bounce + 1 < maxDepth)
                 res = bsdf_step(p, mat, h);
+            if (res == kContinue && rrStart > 0 && bounce + 1 >= rrStart && !roulette_survives(p))
+                res = kTerminate;
 
             if (res == kContinue)
             {
@@ -956,6 +961,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene scIn, 
                 if (bounce + 1 >= fp.maxDepth)
                     break;
                 if (bsdf_step(p, mat, h) != kContinue)
+                    break;
+                if (fp.rrStart > 0 && bounce + 1 >= fp.rrStart && !roulette_survives(p))
                     break;
             }
 

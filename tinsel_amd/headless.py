@@ -1,7 +1,7 @@
 """Headless stand-in for the caller of the boundary -- the role src/main.cpp plays behind GLUT.
 
     python -m tinsel_amd.headless [-spp=N] [-width=W] [-height=H] [-exposure=E] [-maxdepth=D]
-                                  [-nlm=RADIUS[,FALLOFF]] [-out=image.png|image.pfm] [-save=state.npz] [-resume=state.npz]
+                                  [-nlm=RADIUS[,FALLOFF]] [-rr=BOUNCE] [-out=image.png|image.pfm] [-save=state.npz] [-resume=state.npz]
                                   scene.pack
 
 Conventions kept from main.cpp:
@@ -39,7 +39,7 @@ def parse_args(argv):
         if not a.startswith("-") or "=" not in a:
             raise SystemExit("unrecognised argument %r\n%s" % (a, __doc__))
         k, v = a[1:].split("=", 1)
-        if k in ("spp", "width", "height", "maxdepth"):
+        if k in ("spp", "width", "height", "maxdepth", "rr"):
             cfg["over"][k] = int(v)
         elif k == "exposure":
             cfg["over"][k] = float(v)
@@ -73,6 +73,8 @@ def main(argv=None):
     opt.exposure = over.get("exposure", opt.exposure)
 
     r = create_gpu_renderer(scene)
+    if over.get("rr", 0) > 0:
+        r.set_russian_roulette(over["rr"])       # opt-in; not the reference's behaviour (tinsel_hip.h)
     r.init(opt.width, opt.height)
     print("Created renderer in %fms" % ((time.perf_counter() - t0)*1000.0))
 

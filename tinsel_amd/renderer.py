@@ -77,6 +77,7 @@ def load_library():
     L.tinsel_hip_leaf.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, ci, C.POINTER(abi.Camera), ci, ci]
     L.tinsel_hip_write_accum.argtypes = [vp, vp, C.c_uint32]
     L.tinsel_hip_reserve.argtypes = [vp, ci, ci]
+    L.tinsel_hip_set_russian_roulette.argtypes = [vp, ci]
     L.tinsel_hip_set_mesh_bvh.argtypes = [vp, ci, C.POINTER(C.c_double)]
     L.tinsel_hip_present.argtypes = [vp, C.POINTER(abi.Options), ci, C.c_float, vp]
     L.tinsel_hip_present_async.argtypes = [vp, C.POINTER(abi.Options), ci, C.c_float, vp]
@@ -98,7 +99,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_reset_stats", "tinsel_hip_stats_detail", "tinsel_hip_set_detail_counters", "tinsel_hip_kernel_times",
     "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
     "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
-    "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
+    "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_russian_roulette", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
 ]
 
 
@@ -215,6 +216,10 @@ class HipRenderer:
 
     def set_pipeline(self, pipeline):
         _check(self._L.tinsel_hip_set_pipeline(self._h, pipeline), "tinsel_hip_set_pipeline")
+
+    def set_russian_roulette(self, start_bounce):
+        """0 (default) = none, as the reference; b > 0 = roulette from bounce b on (unbiased, not sample-identical)."""
+        _check(self._L.tinsel_hip_set_russian_roulette(self._h, int(start_bounce)), "tinsel_hip_set_russian_roulette")
 
     def reserve(self, passes, max_depth):
         """Pre-allocates the path buffers for renders of up to `passes` passes at `max_depth`."""
