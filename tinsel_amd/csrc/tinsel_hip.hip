@@ -235,8 +235,8 @@ struct DeviceArena
 };
 
 const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals", "k_bounce",
-                               "k_present", "k_nlm_means", "k_nlm", "k_bin_rays" };
-enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_BIN, KN_COUNT };
+                               "k_present", "k_nlm_means", "k_nlm" };
+enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_COUNT };
 
 struct TimedSpan { int kernel; hipEvent_t start, stop; };
 
@@ -284,8 +284,6 @@ struct tinsel_hip
     size_t ctlWords = 0;
     uint32_t* queues[2] = { nullptr, nullptr };
     uint32_t* queueNee = nullptr;
-    uint32_t* queueBinned = nullptr;    // k_bin_rays output (split pipeline, scenes with meshes in HBM)
-    uint32_t* binCounters = nullptr;    // [4*(maxDepth+1)]: front/back cursors of the extension and the shadow bin per bounce
     BinPrims binPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };
     uint32_t* passSeedsDev = nullptr;
     size_t passSeedsCap = 0;
@@ -340,8 +338,7 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
         batch_alloc(r, &ps.rad, slots) || batch_alloc(r, &ps.absorb, slots) || batch_alloc(r, &ps.rngRaster, slots) ||
         batch_alloc(r, &ps.hit, slots) || batch_alloc(r, &ps.hitPrim, slots) ||
         batch_alloc(r, &ps.nee, slots*(size_t)K*4) || batch_alloc(r, &ps.neeThr, slots) ||
-        batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots) || batch_alloc(r, &r->queueNee, slots) ||
-        batch_alloc(r, &r->queueBinned, r->binPrims.count ? slots : 1) || batch_alloc(r, &r->binCounters, 4*((size_t)maxDepth + 1)))
+        batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots) || batch_alloc(r, &r->queueNee, slots))
         return -1;
     ps.neePerPath = K;
 
@@ -349,7 +346,7 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
     HIP_TRY(hipMemset(ps.rad, 0, sizeof(float4)*slots));
 
     const size_t D = (size_t)maxDepth + 1;
-    r->ctlWords = D*6;
+    r->ctlWords = D*7;
     if (batch_alloc(r, &r->ctlBase, r->ctlWords))
         return -1;
     r->ctl.activeCount = r->ctlBase;
@@ -358,6 +355,7 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
     r->ctl.cursorShade = r->ctlBase + 3*D;
     r->ctl.cursorShadow = r->ctlBase + 4*D;
     r->ctl.activeBack = r->ctlBase + 5*D;
+    r->ctl.neeBack = r->ctlBase + 6*D;
     r->ctl.stats = r->statsDev;
 
     r->batchSlots = slots;
@@ -475,12 +473,12 @@ size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + 
 
 void launch_extend(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
 {
-    TN_DISPATCH2(k_extend, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
+    TN_DISPATCH2(k_extend, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed, (uint32_t)r->batchSlots);
 }
 
 void launch_shadow(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
 {
-    TN_DISPATCH2(k_shadow, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed);
+    TN_DISPATCH2(k_shadow, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed, (uint32_t)r->batchSlots);
 }
 
 void launch_mega(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
@@ -524,12 +522,18 @@ void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams&
         hipLaunchKernelGGL((k_normals<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum, r->stackNeed);
 }
 
+bool noBinPrims()
+{
+    static const bool off = getenv("TINSEL_HIP_NO_BIN") != nullptr;
+    return off;
+}
+
 void launch_shade(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, int maxDepth)
 {
     if (r->scene.allInArena)
-        hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), r->scene.arenaBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth, r->rrStart);
+        hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), r->scene.arenaBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth, r->rrStart, (uint32_t)r->batchSlots, noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims);
     else
-        hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), r->scene.arenaLdsBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth, r->rrStart);
+        hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), r->scene.arenaLdsBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth, r->rrStart, (uint32_t)r->batchSlots, noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims);
 }
 
 // Accumulate tiles (16x16 pixels + filter halo) that contain at least one pixel owned by this shard; cached per
@@ -605,8 +609,6 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : gridMult;
     const int gridTrace = (int)std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMultTrace);
     HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(r->binCounters, 0, 4*((size_t)fp.maxDepth + 1)*sizeof(uint32_t), st));
-    static const bool noBin = getenv("TINSEL_HIP_NO_BIN") != nullptr;
     r->lastBatchSlots = slots;
 
     int pipeline = r->pipeline;
@@ -639,14 +641,6 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             uint32_t* qin = r->queues[bounce & 1];
             uint32_t* qout = r->queues[(bounce + 1) & 1];
             const uint32_t* qtrace = qin;
-            if (r->binPrims.count && !r->countDetail && !noBin)
-            {
-                // rays that enter a big mesh first, the rest last (k_bin_rays): same rays, same results
-                ScopedTimer t(r, KN_BIN, st);
-                hipLaunchKernelGGL(k_bin_rays<false>, dim3(gridPersist), dim3(kBlock), 0, st, r->scene.primBoxes, r->ps, r->ctl, qin, r->queueBinned, bounce,
-                                   r->binPrims, r->binCounters + 4*bounce);
-                qtrace = r->queueBinned;
-            }
             {
                 ScopedTimer t(r, KN_EXTEND, st);
                 launch_extend(r, st, gridTrace, qtrace, bounce);
@@ -658,13 +652,6 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             if (r->neePerPath > 0)
             {
                 const uint32_t* qshadow = r->queueNee;
-                if (r->binPrims.count && !r->countDetail && !noBin)
-                {
-                    ScopedTimer t(r, KN_BIN, st);
-                    hipLaunchKernelGGL(k_bin_rays<true>, dim3(gridPersist), dim3(kBlock), 0, st, r->scene.primBoxes, r->ps, r->ctl, r->queueNee, r->queueBinned,
-                                       bounce, r->binPrims, r->binCounters + 4*bounce + 2);
-                    qshadow = r->queueBinned;
-                }
                 ScopedTimer t(r, KN_SHADOW, st);
                 launch_shadow(r, st, gridTrace, qshadow, bounce);
             }
@@ -1176,7 +1163,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                     planes += boxes[(size_t)k].alwaysHit ? 1 : 0;
                 sc.sortQueues = (sc.flatScan && planes <= 2 && planes < P && !getenv("TINSEL_HIP_NO_SORT_QUEUES")) ? 1 : 0;
             }
-            // primitives whose mesh lives in HBM: their leaf-box test sorts the ray queues (k_bin_rays)
+            // primitives whose mesh lives in HBM: their leaf-box test sorts the ray queues k_shade produces
             r->binPrims.count = 0;
             if (sc.flatScan)
                 for (int k = 0; k < P && r->binPrims.count < 7; ++k)

@@ -56,7 +56,8 @@ struct QueueCtl
     // all indexed by bounce; zeroed once per batch
     uint32_t* activeCount;  // [maxDepth+1]   entries at the FRONT of queue[bounce]
     uint32_t* activeBack;   // [maxDepth+1]   entries at the BACK (fused pipeline: rays that meet no bounded primitive)
-    uint32_t* neeCount;     // [maxDepth]
+    uint32_t* neeCount;     // [maxDepth]     front of the shadow queue of the bounce
+    uint32_t* neeBack;      // [maxDepth]     back of it
     uint32_t* cursorExtend; // [maxDepth]
     uint32_t* cursorShade;  // [maxDepth]
     uint32_t* cursorShadow; // [maxDepth]
@@ -99,7 +100,7 @@ struct FrameParams
 constexpr int kMaxItems = 8;
 constexpr int kStatShards = 2048;       // stats[kStatShards][8]
 constexpr int kStatWords = 8;
-constexpr int kScanWords = 8;           // LDS words behind the traversal stacks used by block_append
+constexpr int kScanWords = 16;           // LDS words behind the traversal stacks used by block_append
 
 TN_D int lane_id() { return (int)__lane_id(); }
 
@@ -157,6 +158,58 @@ TN_D void block_append(uint32_t bits, uint32_t* counter, uint32_t* __restrict__ 
 TN_D uint32_t two_ended(uint32_t idx, uint32_t front, uint32_t back, uint32_t capacity)
 {
     return idx < front ? idx : capacity - back + (idx - front);
+}
+
+// Both ends of a two-ended queue in one go (same synchronisation cost as one block_append): `front` bits are placed
+// upwards from counterFront's cursor, `back` bits downwards from `last`.  s_scan needs 10 words.
+template <class SlotFn>
+TN_D void block_append2(uint32_t front, uint32_t back, uint32_t* counterFront, uint32_t* counterBack, uint32_t* __restrict__ queue,
+                        uint32_t* s_scan, SlotFn slot, uint32_t last)
+{
+    const int lane = lane_id();
+    const int wave = (int)threadIdx.x/kWave;
+    unsigned long long mf[kMaxItems], mb[kMaxItems];
+    uint32_t totalF = 0, totalB = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxItems; ++i)
+    {
+        mf[i] = __ballot((front >> i) & 1u);
+        mb[i] = __ballot((back >> i) & 1u);
+        totalF += (uint32_t)__popcll(mf[i]);
+        totalB += (uint32_t)__popcll(mb[i]);
+    }
+    if (lane == 0)
+    {
+        s_scan[wave] = totalF;
+        s_scan[5 + wave] = totalB;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const uint32_t tf = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+        const uint32_t tb = s_scan[5] + s_scan[6] + s_scan[7] + s_scan[8];
+        s_scan[4] = tf ? atomicAdd(counterFront, tf) : 0u;
+        s_scan[9] = tb ? atomicAdd(counterBack, tb) : 0u;
+    }
+    __syncthreads();
+    uint32_t baseF = s_scan[4], baseB = s_scan[9];
+    for (int w = 0; w < wave; ++w)
+    {
+        baseF += s_scan[w];
+        baseB += s_scan[5 + w];
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < kMaxItems; ++i)
+    {
+        if ((front >> i) & 1u)
+            queue[baseF + (uint32_t)__popcll(mf[i] & below)] = slot(i);
+        if ((back >> i) & 1u)
+            queue[last - (baseB + (uint32_t)__popcll(mb[i] & below))] = slot(i);
+        baseF += (uint32_t)__popcll(mf[i]);
+        baseB += (uint32_t)__popcll(mb[i]);
+    }
+    __syncthreads();        // s_scan is reused by the next call
 }
 
 // statistics: wave reduction, then one atomic per wave into this block's shard (distinct addresses)
@@ -509,9 +562,10 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
                 slot = queueIn[two_ended(idx, frontCount, backCount, fp.queueCapacity)];
             return slot;
         };
-        block_append(keep, q.activeCount + bounce + 1, queueOut, s_scan, slotOf);
         if (sc.sortQueues)
-            block_append(keepBack, q.activeBack + bounce + 1, queueOut, s_scan, slotOf, fp.queueCapacity - 1u);
+            block_append2(keep, keepBack, q.activeCount + bounce + 1, q.activeBack + bounce + 1, queueOut, s_scan, slotOf, fp.queueCapacity - 1u);
+        else
+            block_append(keep, q.activeCount + bounce + 1, queueOut, s_scan, slotOf);
     }
 
     wave_add_stat(q.stats, 0, rays);
@@ -580,17 +634,51 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q
 }
 
 // ---------------------------------------------------------------------------
+// Queues sorted by "enters a big mesh" (split pipeline, scenes with a mesh in HBM).  k_shade, which produces the next
+// bounce's extension queue and this bounce's shadow queue, fills each from both ends: in front the rays whose leaf-box
+// test against one of the LARGE meshes succeeds, at the back all others.  trace() is unchanged and results do not
+// depend on queue order; what changes is that a wave of k_extend / k_shadow is either full of rays that walk the big
+// mesh's BVH or has none (measured on the 524k-triangle config: 60 % of the rays enter the mesh, and unsorted,
+// practically every wave paid for the walk with 23 % of its lanes active).
+struct BinPrims
+{
+    int count;
+    int prim[7];
+};
+
+TN_D bool ray_enters_big_mesh(const PrimBox* __restrict__ primBoxes, const BinPrims& bp, V3 o, V3 d)
+{
+    const V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    bool hit = false;
+    // fully unrolled with constant indices: bp lives in kernel-argument SGPRs, a dynamic index would spill it to scratch
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+    {
+        if (k < bp.count && !hit)
+        {
+            const float4* b = reinterpret_cast<const float4*>(primBoxes + bp.prim[k]);
+            const float4 b0 = b[0], b1 = b[1];
+            float tb;
+            hit = ray_aabb(o, rcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tb);
+        }
+    }
+    return hit;
+}
+
+// ---------------------------------------------------------------------------
 // k_extend: closest hit for every queued path
 
 template <bool COUNT, bool LDS>
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce, int stackEntries)
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce, int stackEntries,
+                                                                  uint32_t queueCapacity)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
     SceneT<LDS> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
-    const uint32_t count = q.activeCount[bounce];
+    const uint32_t frontCount = q.activeCount[bounce], backCount = q.activeBack[bounce];
+    const uint32_t count = frontCount + backCount;
     const uint32_t rounds = block_rounds(count);
     const uint32_t first = blockIdx.x*rounds*kBlock;
     uint32_t rays = 0;
@@ -602,7 +690,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene scIn
             const uint32_t idx = first + g*kBlock + threadIdx.x;
             if (idx >= count)
                 continue;
-            const uint32_t slot = queue[idx];
+            const uint32_t slot = queue[two_ended(idx, frontCount, backCount, queueCapacity)];
             const float4 ro = ps.rayO[slot];
             const float4 rd = ps.rayD[slot];
 
@@ -651,13 +739,15 @@ TN_D NeeRec load_nee(const PathState& ps, uint32_t slot, int k)
 
 template <bool LDS>
 __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue,
-                                                  uint32_t* __restrict__ queueNext, uint32_t* __restrict__ queueNee, int bounce, int maxDepth, int rrStart)
+                                                  uint32_t* __restrict__ queueNext, uint32_t* __restrict__ queueNee, int bounce, int maxDepth, int rrStart,
+                                                  uint32_t queueCapacity, BinPrims bp)
 {
     __shared__ uint32_t s_scan[kScanWords];
     extern __shared__ uint32_t s_arena[];
     SceneT<LDS> sc;
     stage_scene_lds(sc, scIn, s_arena);
-    const uint32_t count = q.activeCount[bounce];
+    const uint32_t frontCount = q.activeCount[bounce], backCount = q.activeBack[bounce];
+    const uint32_t count = frontCount + backCount;
     const uint32_t rounds = block_rounds(count);
     const uint32_t first = blockIdx.x*rounds*kBlock;
 
@@ -666,13 +756,13 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
         const uint32_t base = first + r0*kBlock;
         const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
 
-        uint32_t keepNee = 0, keepNext = 0;
+        uint32_t keepNee = 0, keepNext = 0, keepNeeBack = 0, keepNextBack = 0;
         for (uint32_t g = 0; g < groups; ++g)
         {
             const uint32_t idx = base + g*kBlock + threadIdx.x;
             if (idx >= count)
                 continue;
-            const uint32_t slot = queue[idx];
+            const uint32_t slot = queue[two_ended(idx, frontCount, backCount, queueCapacity)];
 
             PathRegs p;
             float rx, ry;
@@ -694,11 +784,13 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
 
             // SampleLights, part 1 (render.cpp:107-170): consume the RNG, emit shadow-ray records
             int k = 0;
+            bool neeInMesh = bp.count == 0;         // no big mesh: everything goes to the front
             if (sc.probe.valid)
             {
                 NeeRec r;
                 nee_prepare_probe(sc, mat, h, p.rng, r);
                 store_nee(ps, slot, k++, r);
+                neeInMesh = neeInMesh || ray_enters_big_mesh(sc.primBoxes, bp, r.o, r.wi);
             }
             for (int li = 0; li < sc.numLights; ++li)
             {
@@ -709,12 +801,13 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
                     NeeRec r;
                     nee_prepare_light(sc, mat, h, p.time, light, p.rng, r);
                     store_nee(ps, slot, k++, r);
+                    neeInMesh = neeInMesh || ray_enters_big_mesh(sc.primBoxes, bp, r.o, r.wi);
                 }
             }
             if (k > 0)
             {
                 ps.neeThr[slot] = make_float4(p.thr.x, p.thr.y, p.thr.z, 0.0f);
-                keepNee |= 1u << g;
+                if (neeInMesh) keepNee |= 1u << g; else keepNeeBack |= 1u << g;
             }
 
             // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
@@ -727,7 +820,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
             if (res == kContinue)
             {
                 store_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
-                keepNext |= 1u << g;
+                if (bp.count == 0 || ray_enters_big_mesh(sc.primBoxes, bp, p.o, p.d)) keepNext |= 1u << g; else keepNextBack |= 1u << g;
             }
             else
             {
@@ -735,9 +828,17 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
             }
         }
 
-        auto slotOf = [&](int i) -> uint32_t { return queue[base + (uint32_t)i*kBlock + threadIdx.x]; };
-        block_append(keepNee, q.neeCount + bounce, queueNee, s_scan, slotOf);
-        block_append(keepNext, q.activeCount + bounce + 1, queueNext, s_scan, slotOf);
+        auto slotOf = [&](int i) -> uint32_t { return queue[two_ended(base + (uint32_t)i*kBlock + threadIdx.x, frontCount, backCount, queueCapacity)]; };
+        if (bp.count)
+        {
+            block_append2(keepNee, keepNeeBack, q.neeCount + bounce, q.neeBack + bounce, queueNee, s_scan, slotOf, queueCapacity - 1u);
+            block_append2(keepNext, keepNextBack, q.activeCount + bounce + 1, q.activeBack + bounce + 1, queueNext, s_scan, slotOf, queueCapacity - 1u);
+        }
+        else
+        {
+            block_append(keepNee, q.neeCount + bounce, queueNee, s_scan, slotOf);
+            block_append(keepNext, q.activeCount + bounce + 1, queueNext, s_scan, slotOf);
+        }
     }
 }
 
@@ -745,80 +846,17 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
 // k_shadow: SampleLights, part 2 (render.cpp:118-139, 171-224): one thread per path resolves
 // its K shadow rays in the oracle's order, then totalRadiance += pathThroughput*sum (render.cpp:314)
 
-// k_bin_rays: reorders a bounce's ray queue so that the rays whose leaf-box test against one of the LARGE (HBM-resident)
-// meshes succeeds come first and all others last.  trace() is unchanged and results do not depend on queue order; what
-// changes is that a wave of k_extend is either full of rays that walk the big mesh's BVH or has none (measured on the
-// 524k-triangle config: 60 % of the rays enter the mesh, and unsorted, practically every wave paid for the walk with
-// 23 % of its lanes active).  Streaming: 32 B of ray in, 4 B of queue out per ray.
-struct BinPrims
-{
-    int count;
-    int prim[7];
-};
-
-// NEE = false: the extension rays of queue[bounce].  NEE = true: the shadow-ray queue of the bounce; a path goes first
-// when ANY of its NEE rays enters a big mesh.
-template <bool NEE>
-__global__ __launch_bounds__(kBlock, 4) void k_bin_rays(const PrimBox* __restrict__ primBoxes, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueIn,
-                                                     uint32_t* __restrict__ queueOut, int bounce, BinPrims bp, uint32_t* __restrict__ binCounters)
-{
-    __shared__ uint32_t s_scan[kScanWords];
-    const uint32_t count = NEE ? q.neeCount[bounce] : q.activeCount[bounce];
-    const uint32_t rounds = block_rounds(count);
-    const uint32_t first = blockIdx.x*rounds*kBlock;
-
-    for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
-    {
-        const uint32_t base = first + r0*kBlock;
-        const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
-        uint32_t inMesh = 0, other = 0;
-        for (uint32_t g = 0; g < groups; ++g)
-        {
-            const uint32_t idx = base + g*kBlock + threadIdx.x;
-            if (idx >= count)
-                continue;
-            const uint32_t slot = queueIn[idx];
-            bool hit = false;
-            const int numRays = NEE ? ps.neePerPath : 1;
-            for (int ray = 0; ray < numRays && !hit; ++ray)
-            {
-                float4 ro, rd;
-                if (NEE)
-                {
-                    const float4* src = ps.nee + ((size_t)slot*ps.neePerPath + ray)*4;
-                    ro = src[0]; rd = src[1];
-                }
-                else
-                {
-                    ro = ps.rayO[slot]; rd = ps.rayD[slot];
-                }
-                const V3 o(ro.x, ro.y, ro.z);
-                const V3 rcp(1.0f/rd.x, 1.0f/rd.y, 1.0f/rd.z);
-                for (int k = 0; k < bp.count; ++k)
-                {
-                    const float4* b = reinterpret_cast<const float4*>(primBoxes + bp.prim[k]);
-                    const float4 b0 = b[0], b1 = b[1];
-                    float tb;
-                    hit = hit || ray_aabb(o, rcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tb);
-                }
-            }
-            if (hit) inMesh |= 1u << g; else other |= 1u << g;
-        }
-        auto slotOf = [&](int i) -> uint32_t { return queueIn[base + (uint32_t)i*kBlock + threadIdx.x]; };
-        block_append(inMesh, binCounters + 0, queueOut, s_scan, slotOf);
-        block_append(other, binCounters + 1, queueOut, s_scan, slotOf, count - 1u);
-    }
-}
-
 template <bool COUNT, bool LDS>
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce, int stackEntries)
+__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce, int stackEntries,
+                                                                  uint32_t queueCapacity)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
     SceneT<LDS> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
-    const uint32_t count = q.neeCount[bounce];
+    const uint32_t frontCount = q.neeCount[bounce], backCount = q.neeBack[bounce];
+    const uint32_t count = frontCount + backCount;
     const uint32_t rounds = block_rounds(count);
     const uint32_t first = blockIdx.x*rounds*kBlock;
     uint32_t rays = 0;
@@ -830,7 +868,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene scIn
             const uint32_t idx = first + g*kBlock + threadIdx.x;
             if (idx >= count)
                 continue;
-            const uint32_t slot = queueNee[idx];
+            const uint32_t slot = queueNee[two_ended(idx, frontCount, backCount, queueCapacity)];
             const float time = ps.rayO[slot].w;     // rayTime never changes along a path
 
             V3 sum = nee_sum(sc, [&](int k) -> V3 {
