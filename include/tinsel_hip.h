@@ -311,6 +311,9 @@ int tinsel_hip_leaf(tinsel_hip* r, int op, int index, int n, const float* in, in
 /* Introspection: LDS traversal-stack entries per lane chosen for this scene, NEE rays per bounce. */
 int tinsel_hip_stack_entries(tinsel_hip* r);
 int tinsel_hip_nee_per_path(tinsel_hip* r);
+/* Primitives whose mesh BVH is walked by the dedicated k_walk kernel ahead of the scan kernels (large meshes in HBM,
+ * split pipeline; tn_walk.h).  0: every mesh is walked inline, as IntersectRayMesh is called in the reference. */
+int tinsel_hip_walked_prims(tinsel_hip* r);
 
 const char* tinsel_hip_last_error(void);
 

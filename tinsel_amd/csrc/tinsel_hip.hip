@@ -58,48 +58,96 @@ struct ConvertedBvh
     std::vector<Node64> nodes;
     uint32_t root = 0;
     int maxLeafDepth = 0;
+    int topCount = 0;           // nodes [0, topCount) are numbered breadth-first
 };
 
 inline bool ref_is_leaf(const tinsel_bvh_node& n) { return (n.right_index_leaf >> 31) != 0; }
 inline uint32_t ref_right(const tinsel_bvh_node& n) { return n.right_index_leaf & 0x7fffffffu; }
 
-bool convert_bvh(const tinsel_bvh_node* ref, int numNodes, ConvertedBvh& out)
+// `numItems`: what a leaf may index (primitives / triangles); `topBudget`: how many internal nodes to number
+// breadth-first from the root (the part of a tree in HBM that k_walk stages into LDS, tn_walk.h) before the rest is
+// numbered depth-first (a node's left subtree follows it immediately: the builder's locality).  Node numbers are labels
+// only: boxes, children and the visit order of a traversal do not depend on them.
+// Refuses malformed input: child / item indices out of range, a node reachable twice (a cycle or a DAG).
+bool convert_bvh(const tinsel_bvh_node* ref, int numNodes, int numItems, int topBudget, ConvertedBvh& out)
 {
     out.nodes.clear();
     out.maxLeafDepth = 0;
+    out.topCount = 0;
     if (numNodes <= 0 || !ref)
         return false;
 
     if (ref_is_leaf(ref[0]))
     {
+        if (ref[0].left_index >= (uint32_t)numItems)
+            return false;
         out.root = kLeafBit | ref[0].left_index;
         return true;
     }
 
-    // DFS pre-order numbering of internal nodes (keeps the builder's locality: a node's left
-    // subtree follows it immediately)
     std::vector<uint32_t> internalIndex((size_t)numNodes, kNoNode);
     struct Item { uint32_t node; int depth; };
-    std::vector<Item> stack;
     std::vector<uint32_t> order;
-    stack.push_back({ 0u, 0 });
-    while (!stack.empty())
-    {
-        Item it = stack.back();
-        stack.pop_back();
+    order.reserve((size_t)numNodes/2 + 1);
+
+    // takes one node off a work list: leaves only report their depth, internal nodes get the next number
+    auto visit = [&](const Item& it, uint32_t& left, uint32_t& right) -> int {      // 0 leaf, 1 internal, -1 malformed
         const tinsel_bvh_node& n = ref[it.node];
         if (ref_is_leaf(n))
         {
+            if (n.left_index >= (uint32_t)numItems)
+                return -1;
             if (it.depth > out.maxLeafDepth)
                 out.maxLeafDepth = it.depth;
-            continue;
+            return 0;
         }
-        if (n.left_index >= (uint32_t)numNodes || ref_right(n) >= (uint32_t)numNodes)
-            return false;
+        if (n.left_index >= (uint32_t)numNodes || ref_right(n) >= (uint32_t)numNodes || internalIndex[it.node] != kNoNode)
+            return -1;
         internalIndex[it.node] = (uint32_t)order.size();
         order.push_back(it.node);
-        stack.push_back({ ref_right(n), it.depth + 1 });
-        stack.push_back({ n.left_index, it.depth + 1 });
+        left = n.left_index;
+        right = ref_right(n);
+        return 1;
+    };
+
+    // breadth-first part
+    std::vector<Item> frontier;
+    frontier.push_back({ 0u, 0 });
+    size_t head = 0;
+    while (head < frontier.size() && (int)order.size() < topBudget)
+    {
+        const Item it = frontier[head++];
+        uint32_t l = 0, r = 0;
+        const int kind = visit(it, l, r);
+        if (kind < 0)
+            return false;
+        if (kind == 1)
+        {
+            frontier.push_back({ l, it.depth + 1 });
+            frontier.push_back({ r, it.depth + 1 });
+        }
+    }
+    out.topCount = (int)order.size();
+
+    // depth-first pre-order below the frontier
+    std::vector<Item> stack;
+    for (; head < frontier.size(); ++head)
+    {
+        stack.push_back(frontier[head]);
+        while (!stack.empty())
+        {
+            const Item it = stack.back();
+            stack.pop_back();
+            uint32_t l = 0, r = 0;
+            const int kind = visit(it, l, r);
+            if (kind < 0)
+                return false;
+            if (kind == 1)
+            {
+                stack.push_back({ r, it.depth + 1 });
+                stack.push_back({ l, it.depth + 1 });
+            }
+        }
     }
 
     out.nodes.resize(order.size());
@@ -206,6 +254,7 @@ struct ArenaBuilder
 };
 
 constexpr size_t kSmallMeshBytes = 4096;        // meshes up to this size ride inside the arena
+constexpr int kWalkTopNodes = 2048;             // internal nodes of a mesh in HBM numbered breadth-first (128 KB: more than LDS can take)
 constexpr size_t kArenaLdsLimit = 32768;        // arenas up to this size are staged into LDS by the kernels
 
 struct DeviceArena
@@ -235,8 +284,8 @@ struct DeviceArena
 };
 
 const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals", "k_bounce",
-                               "k_present", "k_nlm_means", "k_nlm" };
-enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_COUNT };
+                               "k_present", "k_nlm_means", "k_nlm", "k_walk" };
+enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_WALK, KN_COUNT };
 
 struct TimedSpan { int kernel; hipEvent_t start, stop; };
 
@@ -285,6 +334,12 @@ struct tinsel_hip
     uint32_t* queues[2] = { nullptr, nullptr };
     uint32_t* queueNee = nullptr;
     BinPrims binPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };
+    BinPrims walkPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };   // the subset of binPrims whose closest hits k_walk computes (large trees)
+    int walkPrimMesh[7] = { 0, 0, 0, 0, 0, 0, 0 };         // DevScene::meshes index of each walked primitive
+    float4* walkRec = nullptr;                          // k_walk's closest-hit records (tn_walk.h); batch-sized
+    bool walkEnabled = true;                            // TINSEL_HIP_NO_WALK: walk meshes inline in k_extend / k_shadow (A/B)
+    unsigned long long* walkProf = nullptr;             // developer-only (-DTN_WALK_PROF builds): section counters of k_walk
+    int sharedMemLimit = 65536;
     uint32_t* passSeedsDev = nullptr;
     size_t passSeedsCap = 0;
     unsigned long long* statsDev = nullptr;
@@ -311,6 +366,7 @@ void free_batch(tinsel_hip* r)
     for (void* p : r->batchAllocs)
         (void)hipFree(p);
     r->batchAllocs.clear();
+    r->walkRec = nullptr;
     r->batchSlots = 0;
     r->batchNee = -1;
     r->batchDepth = -1;
@@ -341,6 +397,11 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
         batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots) || batch_alloc(r, &r->queueNee, slots))
         return -1;
     ps.neePerPath = K;
+    // k_walk records: one 32-B closest hit per (queued ray, walked primitive); extension and shadow rays share the buffer
+    r->walkRec = nullptr;
+    if (r->walkPrims.count > 0 && r->walkEnabled && (double)slots*(K > 1 ? K : 1)*r->walkPrims.count < 2147483648.0)
+        if (batch_alloc(r, &r->walkRec, slots*(size_t)(K > 1 ? K : 1)*(size_t)r->walkPrims.count*2))
+            return -1;
 
     // slots of other shards are never written (gen_slot): keep their radiance at zero for the test hook
     HIP_TRY(hipMemset(ps.rad, 0, sizeof(float4)*slots));
@@ -471,14 +532,86 @@ size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + 
                       else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); }             \
     } while (0)
 
+// k_walk's records are used by the scan kernels unless the detail counters are on (those count the inline walk)
+const float4* walk_records(const tinsel_hip* r) { return r->countDetail ? nullptr : r->walkRec; }
+
 void launch_extend(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
 {
-    TN_DISPATCH2(k_extend, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed, (uint32_t)r->batchSlots);
+    TN_DISPATCH2(k_extend, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed, (uint32_t)r->batchSlots,
+                 walk_records(r), (uint32_t)r->walkPrims.count);
 }
 
 void launch_shadow(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
 {
-    TN_DISPATCH2(k_shadow, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed, (uint32_t)r->batchSlots);
+    TN_DISPATCH2(k_shadow, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed, (uint32_t)r->batchSlots,
+                 walk_records(r), (uint32_t)r->walkPrims.count);
+}
+
+// k_walk (tn_walk.h): closest hits of the front rays of `queue` against the meshes in HBM, ahead of the scan kernel.
+// One 1024-thread workgroup per CU whose LDS holds the traversal stacks and, in what is left of the 160 KB, the top of
+// the walked trees; trees too deep for that (a device-built LBVH of 524k triangles: 48 entries per lane) run 256-thread
+// workgroups without a staged top.
+void launch_walk(tinsel_hip* r, hipStream_t st, const uint32_t* queue, const uint32_t* frontCount, bool shadowRays)
+{
+    static const int gridMult = getenv("TINSEL_HIP_WALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_WALK_GRID_MULT")) : 1;
+    static const int refillMin = getenv("TINSEL_HIP_WALK_REFILL") ? atoi(getenv("TINSEL_HIP_WALK_REFILL")) : 16;
+    static const int leafMin = getenv("TINSEL_HIP_WALK_LEAFMIN") ? atoi(getenv("TINSEL_HIP_WALK_LEAFMIN")) : 8;
+    static const int topLimit = getenv("TINSEL_HIP_WALK_TOP") ? atoi(getenv("TINSEL_HIP_WALK_TOP")) : 1 << 20;      // nodes; 0: no staged top (A/B)
+    static const int forceBlock = getenv("TINSEL_HIP_WALK_BLOCK") ? atoi(getenv("TINSEL_HIP_WALK_BLOCK")) : 0;
+    static bool attrSet = false;
+    if (!attrSet)
+    {
+        (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, r->sharedMemLimit);
+        (void)hipFuncSetAttribute((const void*)k_walk<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, r->sharedMemLimit);
+        attrSet = true;
+    }
+    WalkJob job;
+    job.queue = queue;
+    job.frontCount = frontCount;
+    job.rayO = r->ps.rayO;
+    job.rayD = r->ps.rayD;
+    job.nee = r->ps.nee;
+    job.rec = r->walkRec;
+    job.neePerPath = shadowRays ? r->neePerPath : 0;
+    job.numPrims = r->walkPrims.count;
+    int entries = 1;
+    for (int k = 0; k < kWalkMaxPrims; ++k)
+    {
+        job.prim[k] = k < r->walkPrims.count ? r->walkPrims.prim[k] : 0;
+        job.topCount[k] = 0;
+        if (k < r->walkPrims.count)
+            entries = std::max(entries, r->meshesNow[(size_t)r->walkPrimMesh[k]].stackNeed);
+    }
+    job.stackEntries = entries;
+    job.prof = r->walkProf;
+    job.refillMin = std::min(64, std::max(1, refillMin));
+    job.leafMin = std::min(64, std::max(1, leafMin));
+
+    const size_t ctl = kWalkCtlWords*sizeof(uint32_t);
+    const size_t stackBig = (size_t)entries*1024*sizeof(uint32_t);
+    const bool big = forceBlock ? forceBlock == 1024 : stackBig + ctl + 16384 <= (size_t)r->sharedMemLimit;
+    const int block = big ? 1024 : 256;
+    size_t lds = (size_t)entries*block*sizeof(uint32_t) + ctl;
+    if (big)
+    {
+        // what is left of the CU's LDS goes to the tree tops, in primitive order
+        size_t room = ((size_t)r->sharedMemLimit - lds)/sizeof(Node64);
+        room = std::min<size_t>(room, (size_t)std::max(0, topLimit));
+        for (int k = 0; k < r->walkPrims.count && room > 0; ++k)
+        {
+            const int n = (int)std::min<size_t>(room, (size_t)r->meshesNow[(size_t)r->walkPrimMesh[k]].topCount);
+            job.topCount[k] = n;
+            room -= (size_t)n;
+            lds += (size_t)n*sizeof(Node64);
+        }
+    }
+    const size_t items = r->batchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1)*(size_t)r->walkPrims.count;
+    const int perCU = big ? gridMult : gridMult*4;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
+    if (big)
+        hipLaunchKernelGGL((k_walk<1024, 4>), dim3(grid), dim3(1024), lds, st, r->scene, job);
+    else
+        hipLaunchKernelGGL((k_walk<256, 5>), dim3(grid), dim3(256), lds, st, r->scene, job);
 }
 
 void launch_mega(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
@@ -587,27 +720,38 @@ size_t batch_slots(const tinsel_hip* r)
     return r->maxBatchSlots;
 }
 
+// Path slots one pass of this renderer's shard occupies: W*H for one shard, else its own tiles padded to full size.
+size_t slots_per_pass(const tinsel_hip* r, int width, int height, int* tilesXOut = nullptr, int* ownedOut = nullptr)
+{
+    const int tilesX = (width + r->shardTile - 1)/r->shardTile;
+    const int numTiles = tilesX*((height + r->shardTile - 1)/r->shardTile);
+    const int owned = r->shardRank < numTiles ? (numTiles - r->shardRank + r->shardWorld - 1)/r->shardWorld : 0;
+    if (tilesXOut) *tilesXOut = tilesX;
+    if (ownedOut) *ownedOut = owned;
+    if (r->shardWorld <= 1)
+        return (size_t)width*height;
+    return std::max<size_t>(1, (size_t)owned*r->shardTile*r->shardTile);
+}
+
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp)
 {
     const size_t npix = (size_t)fp.width*fp.height;
-    const size_t slots = npix*(size_t)fp.numPasses;
-    // camera paths this shard enumerates per batch (gen_slot, tn_kernels.h)
-    fp.shardTilesX = (fp.width + fp.shardTile - 1)/fp.shardTile;
-    const int numTiles = fp.shardTilesX*((fp.height + fp.shardTile - 1)/fp.shardTile);
-    fp.shardOwnedTiles = fp.shardRank < numTiles ? (numTiles - fp.shardRank + fp.shardWorld - 1)/fp.shardWorld : 0;
-    const size_t gen = fp.shardWorld <= 1 ? slots : (size_t)fp.shardOwnedTiles*fp.shardTile*fp.shardTile*(size_t)fp.numPasses;
-    if (gen >= (size_t)0xffffffffu)
+    // path slots of this shard per pass and per batch (slot_pixel / slot_of, tn_kernels.h): rank-local numbering
+    const size_t perPass = slots_per_pass(r, fp.width, fp.height, &fp.shardTilesX, &fp.shardOwnedTiles);
+    const size_t slots = perPass*(size_t)fp.numPasses;
+    if (slots >= (size_t)0xffffffffu)
         return fail("render: batch too large");
-    fp.genCount = (uint32_t)gen;
+    fp.shardPerPass = (uint32_t)perPass;
+    fp.genCount = (uint32_t)slots;
     fp.rrStart = r->rrStart;
     fp.queueCapacity = (uint32_t)r->batchSlots;
-    const int gridFlat = (int)((gen + kBlock - 1)/kBlock > 0 ? (gen + kBlock - 1)/kBlock : 1);
+    const int gridFlat = (int)std::max<size_t>(1, (slots + kBlock - 1)/kBlock);
     // blocks per CU of the streaming kernels' fixed grid.  Swept 4..256 on every config: 32 is best everywhere (finer
     // static ranges even out the tail; beyond 64 the per-block staging and the shorter ranges cost more than they give)
     static const int gridMult = getenv("TINSEL_HIP_GRID_MULT") ? atoi(getenv("TINSEL_HIP_GRID_MULT")) : 32;
-    const int gridPersist = (int)std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMult);
+    const int gridPersist = (int)std::max<size_t>(1, std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMult));
     static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : gridMult;
-    const int gridTrace = (int)std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMultTrace);
+    const int gridTrace = (int)std::max<size_t>(1, std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMultTrace));
     HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
     r->lastBatchSlots = slots;
 
@@ -632,15 +776,22 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     }
     else
     {
+        const BinPrims bins = noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims;
+        const bool walk = walk_records(r) != nullptr;
         {
             ScopedTimer t(r, KN_GENERATE, st);
-            hipLaunchKernelGGL(k_generate, dim3(gridPersist), dim3(kBlock), 0, st, r->ps, r->ctl, r->queues[0], cam, fp, r->passSeedsDev);
+            hipLaunchKernelGGL(k_generate, dim3(gridPersist), dim3(kBlock), 0, st, r->ps, r->ctl, r->queues[0], cam, fp, r->passSeedsDev, r->scene.primBoxes, bins);
         }
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
             uint32_t* qin = r->queues[bounce & 1];
             uint32_t* qout = r->queues[(bounce + 1) & 1];
             const uint32_t* qtrace = qin;
+            if (walk)
+            {
+                ScopedTimer t(r, KN_WALK, st);
+                launch_walk(r, st, qtrace, r->ctl.activeCount + bounce, false);
+            }
             {
                 ScopedTimer t(r, KN_EXTEND, st);
                 launch_extend(r, st, gridTrace, qtrace, bounce);
@@ -652,6 +803,11 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             if (r->neePerPath > 0)
             {
                 const uint32_t* qshadow = r->queueNee;
+                if (walk)
+                {
+                    ScopedTimer t(r, KN_WALK, st);
+                    launch_walk(r, st, qshadow, r->ctl.neeCount + bounce, true);
+                }
                 ScopedTimer t(r, KN_SHADOW, st);
                 launch_shadow(r, st, gridTrace, qshadow, bounce);
             }
@@ -757,10 +913,11 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
     // by the runtime, but do not rely on it)
     HIP_TRY(hipStreamSynchronize(st));
 
-    int perBatch = (int)std::max<size_t>(1, batch_slots(r)/npix);
+    const size_t perPass = slots_per_pass(r, fp.width, fp.height);
+    int perBatch = (int)std::max<size_t>(1, batch_slots(r)/perPass);
     if (perBatch > passes)
         perBatch = passes;
-    if (ensure_batch(r, npix*(size_t)perBatch, fp.maxDepth))
+    if (ensure_batch(r, perPass*(size_t)perBatch, fp.maxDepth))
         return -1;
 
     for (int done = 0; done < passes; done += perBatch)
@@ -855,6 +1012,7 @@ int build_lbvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out)
         out.nodes = nodes;
         out.root = 0;
         out.stackNeed = rootHeight + 1;
+        out.topCount = 0;               // Karras numbering: no breadth-first prefix to stage
     } while (false);
     if (rc)
         (void)hipFree(nodes);
@@ -894,7 +1052,10 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
     r->device = device_index;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_index) == hipSuccess)
+    {
         r->numCUs = prop.multiProcessorCount;
+        r->sharedMemLimit = (int)prop.sharedMemPerBlock;
+    }
 
     if (const char* e = getenv("TINSEL_HIP_BATCH_PATHS"))
     {
@@ -992,7 +1153,9 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                     break;
                 }
                 ConvertedBvh cb;
-                if (!convert_bvh(g.nodes, g.num_nodes, cb))
+                const size_t roughBytes = (size_t)g.num_nodes*32 + (size_t)numTris*48 + (size_t)g.num_vertices*12 + (size_t)numTris*4;
+                // meshes that will live in HBM: the upper levels breadth-first (k_walk's LDS-resident top, tn_walk.h)
+                if (!convert_bvh(g.nodes, g.num_nodes, numTris, roughBytes > kSmallMeshBytes ? kWalkTopNodes : 0, cb))
                 {
                     fail("create: malformed mesh BVH");
                     ok = false;
@@ -1021,8 +1184,11 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 dm.root = cb.root;
                 dm.numTris = numTris;
                 dm.stackNeed = cb.maxLeafDepth + 1;
+                dm.topCount = cb.topCount;
                 const size_t meshBytes = cb.nodes.size()*sizeof(Node64) + tris.size()*sizeof(Tri48) + (size_t)g.num_vertices*12 + (size_t)numTris*4;
-                if (meshBytes <= kSmallMeshBytes)
+                // TINSEL_HIP_SMALL_MESH_BYTES: test / A-B knob (0 = every mesh lives in HBM, so the queue sort and k_walk see them all)
+                const size_t smallLimit = getenv("TINSEL_HIP_SMALL_MESH_BYTES") ? (size_t)atoll(getenv("TINSEL_HIP_SMALL_MESH_BYTES")) : kSmallMeshBytes;
+                if (meshBytes <= smallLimit)
                 {
                     // offsets for now; turned into pointers once the arena has its device address
                     dm.inArena = 1;
@@ -1059,7 +1225,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
     }
 
     ConvertedBvh sceneBvh;
-    if (ok && !convert_bvh(desc->bvh_nodes, desc->num_bvh_nodes, sceneBvh))
+    if (ok && !convert_bvh(desc->bvh_nodes, desc->num_bvh_nodes, P, 0, sceneBvh))
     {
         fail("create: malformed scene BVH");
         ok = false;
@@ -1078,14 +1244,6 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
 
     if (ok)
     {
-        // one contiguous arena: scene BVH, Prim64, Mat128, moving poses, lights, mesh table (+ small meshes, added above)
-        const size_t offNodes = arena.add(sceneBvh.nodes.data(), sceneBvh.nodes.size());
-        const size_t offPrims = arena.add(prims.data(), prims.size());
-        const size_t offMats = arena.add(mats.data(), mats.size());
-        const size_t offMoving = arena.add(moving.data(), moving.size());
-        const size_t offLights = arena.add(lights.data(), lights.size());
-        const size_t offMeshes = arena.add(meshes.data(), meshes.size());
-
         // leaf boxes of the scene BVH, by primitive index (flat scene-level scan)
         std::vector<PrimBox> boxes((size_t)P);
         std::vector<char> seen((size_t)P, 0);
@@ -1105,6 +1263,41 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         bool everyPrimHasALeaf = true;
         for (int k = 0; k < P; ++k)
             everyPrimHasALeaf = everyPrimHasALeaf && seen[(size_t)k];
+        const bool flatScan = everyPrimHasALeaf && P <= 64 && !getenv("TINSEL_HIP_NO_FLAT_SCAN");
+
+        // primitives whose mesh lives in HBM (flat-scan scenes, the first 7): their leaf-box test sorts the ray queues
+        // (k_generate, k_shade).  Of those, the ones with a LARGE tree are walked by k_walk ahead of the scan kernels
+        // (tn_walk.h); a small tree (glass.tin's 1280-triangle sphere: 80 KB of nodes) is L1/L2-resident and cheaper to walk
+        // inline than to hand over (measured: 732 inline vs 657-690 Msamples/s through k_walk).
+        const int walkMinTris = getenv("TINSEL_HIP_WALK_MIN_TRIS") ? atoi(getenv("TINSEL_HIP_WALK_MIN_TRIS")) : 16384;
+        r->binPrims.count = 0;
+        r->walkPrims.count = 0;
+        if (flatScan)
+            for (int k = 0; k < P && r->binPrims.count < 7; ++k)
+                if (prims[(size_t)k].type == kPrimMesh && !meshes[prims[(size_t)k].mesh].inArena)
+                {
+                    r->binPrims.prim[r->binPrims.count++] = k;
+                    if (meshes[prims[(size_t)k].mesh].numTris >= walkMinTris)
+                    {
+                        prims[(size_t)k].flags |= kPrimWalked | ((uint32_t)r->walkPrims.count << kPrimWalkLaneShift);
+                        r->walkPrimMesh[r->walkPrims.count] = (int)prims[(size_t)k].mesh;
+                        r->walkPrims.prim[r->walkPrims.count++] = k;
+                    }
+                }
+        r->walkEnabled = !getenv("TINSEL_HIP_NO_WALK");
+#ifdef TN_WALK_PROF
+        if (hipMalloc((void**)&r->walkProf, 16*sizeof(unsigned long long)) == hipSuccess)
+            (void)hipMemset(r->walkProf, 0, 16*sizeof(unsigned long long));
+#endif
+
+        // one contiguous arena: scene BVH, Prim64, Mat128, moving poses, lights, mesh table (+ small meshes, added above)
+        const size_t offNodes = arena.add(sceneBvh.nodes.data(), sceneBvh.nodes.size());
+        const size_t offPrims = arena.add(prims.data(), prims.size());
+        const size_t offMats = arena.add(mats.data(), mats.size());
+        const size_t offMoving = arena.add(moving.data(), moving.size());
+        const size_t offLights = arena.add(lights.data(), lights.size());
+        const size_t offMeshes = arena.add(meshes.data(), meshes.size());
+
         const size_t offBoxes = arena.add(boxes.data(), boxes.size());
         arena.bytes.resize((arena.bytes.size() + 127) & ~size_t(127), 0);
 
@@ -1152,7 +1345,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             for (const Mat128& mm : mats)
                 if (mm.absorption[0] != 0.0f || mm.absorption[1] != 0.0f || mm.absorption[2] != 0.0f)
                     sc.hasMedia = 1;
-            sc.flatScan = (everyPrimHasALeaf && P <= 64 && !getenv("TINSEL_HIP_NO_FLAT_SCAN")) ? 1 : 0;
+            sc.flatScan = flatScan ? 1 : 0;
             // Fused kernel: sort the next bounce's queue by "meets the box of a bounded primitive" (tn_isect.h) when the
             // scene is open.  Measured (cornell-sized frames, fused kernel): env_loft (1 plane) +16 %, gloss (1 plane) +4 %;
             // the closed boxes cornell / cornell+probe (5 planes, every NEE ray aimed at the light mesh) -4 %: the test and
@@ -1163,12 +1356,6 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                     planes += boxes[(size_t)k].alwaysHit ? 1 : 0;
                 sc.sortQueues = (sc.flatScan && planes <= 2 && planes < P && !getenv("TINSEL_HIP_NO_SORT_QUEUES")) ? 1 : 0;
             }
-            // primitives whose mesh lives in HBM: their leaf-box test sorts the ray queues k_shade produces
-            r->binPrims.count = 0;
-            if (sc.flatScan)
-                for (int k = 0; k < P && r->binPrims.count < 7; ++k)
-                    if (prims[(size_t)k].type == kPrimMesh && !meshes[prims[(size_t)k].mesh].inArena)
-                        r->binPrims.prim[r->binPrims.count++] = k;
             bool all = sc.arenaLdsBytes != 0;
             for (const DevMesh& dmesh : meshes)
                 all = all && dmesh.inArena;
@@ -1235,6 +1422,19 @@ void tinsel_hip_destroy(tinsel_hip* r)
         return;
     (void)hipSetDevice(r->device);
     (void)hipDeviceSynchronize();
+    if (r->walkProf)
+    {
+        unsigned long long wp[16] = { 0 };
+        (void)hipMemcpy(wp, r->walkProf, sizeof(wp), hipMemcpyDeviceToHost);
+        const double tot = (double)(wp[0] + wp[1] + wp[2] + wp[3] + wp[4]);
+        fprintf(stderr, "k_walk profile: cycles refill %.1f%% node %.1f%% tri %.1f%% pop %.1f%% loop %.1f%% | iterations %llu refills %llu node-phases %llu tri-phases %llu | "
+                "lanes/node-phase %.1f lanes/tri-phase %.1f lanes/refill %.1f | waves %llu cycles/wave %.0f cycles/iteration %.0f cycles/refill %.0f cycles/node-phase %.0f cycles/tri-phase %.0f\n",
+                100.0*wp[0]/tot, 100.0*wp[1]/tot, 100.0*wp[2]/tot, 100.0*wp[3]/tot, 100.0*wp[4]/tot, wp[5], wp[6], wp[7], wp[8],
+                (double)wp[9]/std::max(1ull, wp[7]), (double)wp[10]/std::max(1ull, wp[8]), (double)wp[11]/std::max(1ull, wp[6]),
+                wp[12], (double)wp[13]/std::max(1ull, wp[12]), tot/std::max(1ull, wp[5]), (double)wp[0]/std::max(1ull, wp[6]),
+                (double)wp[1]/std::max(1ull, wp[7]), (double)wp[2]/std::max(1ull, wp[8]));
+        (void)hipFree(r->walkProf);
+    }
     free_batch(r);
     r->sceneMem.release();
     if (r->accum && r->accumOwned) (void)hipFree(r->accum);
@@ -1610,11 +1810,11 @@ int tinsel_hip_reserve(tinsel_hip* r, int passes, int max_depth)
     if (!r || !r->accum || passes < 1 || max_depth < 1)
         return fail("reserve: bad arguments (Init first)");
     HIP_TRY(hipSetDevice(r->device));
-    const size_t npix = (size_t)r->width*r->height;
-    int perBatch = (int)std::max<size_t>(1, batch_slots(r)/npix);
+    const size_t perPass = slots_per_pass(r, r->width, r->height);
+    int perBatch = (int)std::max<size_t>(1, batch_slots(r)/perPass);
     if (perBatch > passes)
         perBatch = passes;
-    return ensure_batch(r, npix*(size_t)perBatch, max_depth);
+    return ensure_batch(r, perPass*(size_t)perBatch, max_depth);
 }
 
 int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths)
@@ -1679,6 +1879,7 @@ int tinsel_hip_leaf(tinsel_hip* r, int op, int index, int n, const float* in, in
 }
 
 int tinsel_hip_stack_entries(tinsel_hip* r) { return r ? r->stackNeed : 0; }
+int tinsel_hip_walked_prims(tinsel_hip* r) { return (r && r->walkEnabled) ? r->walkPrims.count : 0; }
 int tinsel_hip_nee_per_path(tinsel_hip* r) { return r ? r->neePerPath : 0; }
 
 // ---------------------------------------------------------------------------

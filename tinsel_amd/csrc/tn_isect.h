@@ -279,7 +279,20 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
     const DevMesh m = sc.meshes[p.mesh];
     const Tri48* mtris = mesh_tris(sc, m);
     MeshHit h;
-    if (!ray_mesh<Stack, COUNT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, h, ctr))
+    if (!COUNT && sc.walkRec != nullptr && (p.flags & kPrimWalked))
+    {
+        // the mesh-space closest hit of this (ray, primitive) was computed by k_walk with the same ray_mesh arithmetic
+        // on the same lo / ld (tn_walk.h); t == FLT_MAX marks "no hit" (ray_mesh's own `closestT < FLT_MAX`)
+        const float4* rp = sc.walkRec + (size_t)(sc.walkItem + ((p.flags >> kPrimWalkLaneShift) & 7u))*2;
+        const float4 ra = rp[0];
+        if (!(ra.x < kFltMax))
+            return false;
+        const float4 rb = rp[1];
+        h.t = ra.x; h.u = ra.y; h.v = ra.z; h.w = ra.w;
+        h.n = V3(rb.x, rb.y, rb.z);
+        h.tri = __float_as_int(rb.w);
+    }
+    else if (!ray_mesh<Stack, COUNT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, h, ctr))
         return false;
 
     // interpolate vertex normals (intersection.h:996-1012)
@@ -380,6 +393,10 @@ TN_D bool ray_meets_bounded_prim(const SC& sc, V3 o, V3 d)
     return any;
 }
 
+// Rays the flat scan handles; the others take the scene BVH walk (which does not box-test a root leaf), so the queue
+// sort and k_walk (tn_walk.h) treat them as entering every walked mesh.
+TN_D bool ray_sane(V3 o) { return fabsf(o.x) < 1e6f && fabsf(o.y) < 1e6f && fabsf(o.z) < 1e6f; }
+
 // Trace (render.cpp:17-62) over QueryBVH (intersection.h:751-799).
 // Returns the primitive index or -1; outN is already FaceForward(n, -dir) (render.cpp:59).
 template <class SC, class Stack, bool COUNT>
@@ -396,7 +413,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
     if (!COUNT && sc.flatScan)
     {
         // "sane" rays only: the always-hit shortcut for infinite boxes assumes |origin| << 1e8
-        const bool sane = fabsf(o.x) < 1e6f && fabsf(o.y) < 1e6f && fabsf(o.z) < 1e6f;
+        const bool sane = ray_sane(o);
         bool tie = false;
         int prim = -1;
         if (sane)

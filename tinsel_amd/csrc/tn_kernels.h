@@ -18,6 +18,7 @@
 
 #include "tn_integrator.h"
 #include "tn_display.h"
+#include "tn_walk.h"
 
 namespace tn {
 
@@ -79,6 +80,7 @@ struct FrameParams
     int maxDepth;
     int shardRank, shardWorld, shardTile;
     int shardTilesX, shardOwnedTiles;   // tiles per frame row; tiles this shard owns (t % world == rank)
+    uint32_t shardPerPass;              // path slots per pass of this shard (owned tiles x tile^2; W*H for one shard)
     uint32_t genCount;                  // camera paths the generation kernels enumerate per batch (gen_slot)
     uint32_t queueCapacity;             // entries per ray queue (= path slots of the batch)
     int rrStart;                        // > 0: Russian roulette from this bounce on (opt-in, not the reference's behaviour)
@@ -236,6 +238,8 @@ TN_D void stage_scene_lds(SceneT<LDS>& sc, const DevScene& in, uint32_t* ldsWord
     static_cast<DevScene&>(sc) = in;
     unsigned char* lds = reinterpret_cast<unsigned char*>(ldsWords);
     sc.ldsBase = lds;
+    sc.walkRec = nullptr;
+    sc.walkItem = 0u;
     if (!LDS && in.arenaLdsBytes == 0)
         return;
 
@@ -284,31 +288,53 @@ TN_D bool pixel_owned(const FrameParams& fp, int i, int j)
     return (t % fp.shardWorld) == fp.shardRank;
 }
 
-// The idx-th camera path this shard generates in a batch -> its slot (pass*W*H + j*W + i, the same numbering on every
-// shard).  One shard: slots in order.  Several: only the shard's OWN tiles are enumerated, tile after tile (lanes of
-// the generation kernels are all busy and slots of other shards are never touched); tiles that stick out of the
-// frame are padded to full size and the padding returns false.
-TN_D bool gen_slot(const FrameParams& fp, uint32_t idx, uint32_t& slot)
+// Path slots.  One shard: slot = pass*W*H + j*W + i.  Several: slots are RANK-LOCAL -- the shard's own tiles one after
+// the other, pass by pass (slot = pass*perPass + k*T*T + (j%T)*T + i%T for the shard's k-th tile) -- so a rank's state
+// arrays hold exactly the paths it traces whatever the number of ranks, the generation kernels' lanes are all busy and
+// consecutive slots are consecutive pixels of a tile.  Tiles that stick out of the frame are padded to full size; the
+// padding slots are never generated, written or read.
+TN_D bool slot_pixel(const FrameParams& fp, uint32_t slot, int& s, int& i, int& j)
 {
     if (fp.shardWorld <= 1)
     {
-        slot = idx;
+        const uint32_t npix = (uint32_t)(fp.width*fp.height);
+        const uint32_t ss = slot/npix;
+        const uint32_t pix = slot - ss*npix;
+        const uint32_t jj = pix/(uint32_t)fp.width;
+        s = (int)ss; j = (int)jj; i = (int)(pix - jj*(uint32_t)fp.width);
         return true;
     }
     const uint32_t T = (uint32_t)fp.shardTile;
-    const uint32_t perPass = (uint32_t)fp.shardOwnedTiles*T*T;
-    const uint32_t s = idx/perPass;
-    const uint32_t o = idx - s*perPass;
+    const uint32_t ss = slot/fp.shardPerPass;
+    const uint32_t o = slot - ss*fp.shardPerPass;
     const uint32_t k = o/(T*T);
     const uint32_t within = o - k*T*T;
     const uint32_t t = (uint32_t)fp.shardRank + k*(uint32_t)fp.shardWorld;
     const uint32_t ty = t/(uint32_t)fp.shardTilesX, tx = t - ty*(uint32_t)fp.shardTilesX;
     const uint32_t wy = within/T, wx = within - wy*T;
-    const uint32_t i = tx*T + wx, j = ty*T + wy;
-    if (i >= (uint32_t)fp.width || j >= (uint32_t)fp.height)
-        return false;
-    slot = s*(uint32_t)(fp.width*fp.height) + j*(uint32_t)fp.width + i;
-    return true;
+    s = (int)ss; i = (int)(tx*T + wx); j = (int)(ty*T + wy);
+    return i < fp.width && j < fp.height;
+}
+
+// slot of the path of pass `s` (in the batch) generated at pixel (i, j); several shards: the pixel must be owned
+TN_D uint32_t slot_of(const FrameParams& fp, int s, int i, int j)
+{
+    if (fp.shardWorld <= 1)
+        return (uint32_t)s*(uint32_t)(fp.width*fp.height) + (uint32_t)j*(uint32_t)fp.width + (uint32_t)i;
+    const uint32_t T = (uint32_t)fp.shardTile;
+    const uint32_t ty = (uint32_t)j/T, tx = (uint32_t)i/T;
+    const uint32_t k = (ty*(uint32_t)fp.shardTilesX + tx)/(uint32_t)fp.shardWorld;
+    return (uint32_t)s*fp.shardPerPass + k*T*T + ((uint32_t)j - ty*T)*T + ((uint32_t)i - tx*T);
+}
+
+// The idx-th camera path this shard generates in a batch -> its slot (= idx); false for tile padding.
+TN_D bool gen_slot(const FrameParams& fp, uint32_t idx, uint32_t& slot)
+{
+    slot = idx;
+    if (fp.shardWorld <= 1)
+        return true;
+    int s, i, j;
+    return slot_pixel(fp, idx, s, i, j);
 }
 
 // CameraSampler::GenerateRay (util.h:73-79) with TransformPoint(Mat44, Vec3) (maths.h:917-924)
@@ -365,16 +391,12 @@ TN_D void store_path(const PathState& ps, uint32_t slot, const PathRegs& p, floa
     ps.rngRaster[slot] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), rasterX, rasterY);
 }
 
-// Slot -> (pass, pixel); generates the camera sample.  Returns false for pixels of other shards.
+// Slot -> (pass, pixel); generates the camera sample.  Returns false for tile padding.
 TN_D bool begin_path(const CameraParams& cam, const FrameParams& fp, const uint32_t* __restrict__ passSeeds, uint32_t slot,
                      PathRegs& p, float& rx, float& ry)
 {
-    const int npix = fp.width*fp.height;
-    const int s = (int)slot/npix;
-    const int pix = (int)slot - s*npix;
-    const int j = pix/fp.width;
-    const int i = pix - j*fp.width;
-    if (!pixel_owned(fp, i, j))
+    int s, i, j;
+    if (!slot_pixel(fp, slot, s, i, j))
         return false;
     Rng rng;
     float time;
@@ -588,52 +610,6 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn
 // ~3x the state traffic for smaller kernels (k_extend/k_shadow 132-136 VGPRs vs k_bounce's).
 
 // ---------------------------------------------------------------------------
-// k_generate
-
-__global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q, uint32_t* queue0, CameraParams cam, FrameParams fp,
-                                                     const uint32_t* __restrict__ passSeeds)
-{
-    __shared__ uint32_t s_scan[kScanWords];
-    const uint32_t count = fp.genCount;
-    const uint32_t rounds = block_rounds(count);
-    const uint32_t first = blockIdx.x*rounds*kBlock;
-    uint32_t samples = 0;
-
-    for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
-    {
-        const uint32_t base = first + r0*kBlock;
-        const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
-        uint32_t keep = 0;
-        for (uint32_t g = 0; g < groups; ++g)
-        {
-            const uint32_t idx = base + g*kBlock + threadIdx.x;
-            uint32_t slot;
-            if (idx >= count || !gen_slot(fp, idx, slot))
-                continue;
-            PathRegs p;
-            float rx, ry;
-            if (begin_path(cam, fp, passSeeds, slot, p, rx, ry))
-            {
-                store_path(ps, slot, p, rx, ry, true);
-                keep |= 1u << g;
-                samples++;
-            }
-            else
-            {
-                ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                ps.rngRaster[slot] = make_float4(0.0f, 0.0f, -1e30f, -1e30f);
-            }
-        }
-        block_append(keep, q.activeCount + 0, queue0, s_scan, [&](int i) -> uint32_t {
-            uint32_t slot = 0;
-            (void)gen_slot(fp, base + (uint32_t)i*kBlock + threadIdx.x, slot);
-            return slot;
-        });
-    }
-    wave_add_stat(q.stats, 1, samples);
-}
-
-// ---------------------------------------------------------------------------
 // Queues sorted by "enters a big mesh" (split pipeline, scenes with a mesh in HBM).  k_shade, which produces the next
 // bounce's extension queue and this bounce's shadow queue, fills each from both ends: in front the rays whose leaf-box
 // test against one of the LARGE meshes succeeds, at the back all others.  trace() is unchanged and results do not
@@ -649,7 +625,7 @@ struct BinPrims
 TN_D bool ray_enters_big_mesh(const PrimBox* __restrict__ primBoxes, const BinPrims& bp, V3 o, V3 d)
 {
     const V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
-    bool hit = false;
+    bool hit = !ray_sane(o);        // rays the flat scan refuses reach the mesh without a box test (trace, tn_isect.h)
     // fully unrolled with constant indices: bp lives in kernel-argument SGPRs, a dynamic index would spill it to scratch
 #pragma unroll
     for (int k = 0; k < 7; ++k)
@@ -666,11 +642,62 @@ TN_D bool ray_enters_big_mesh(const PrimBox* __restrict__ primBoxes, const BinPr
 }
 
 // ---------------------------------------------------------------------------
+// k_generate
+
+__global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q, uint32_t* queue0, CameraParams cam, FrameParams fp,
+                                                     const uint32_t* __restrict__ passSeeds, const PrimBox* __restrict__ primBoxes, BinPrims bp)
+{
+    __shared__ uint32_t s_scan[kScanWords];
+    const uint32_t count = fp.genCount;
+    const uint32_t rounds = block_rounds(count);
+    const uint32_t first = blockIdx.x*rounds*kBlock;
+    uint32_t samples = 0;
+
+    for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
+    {
+        const uint32_t base = first + r0*kBlock;
+        const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
+        uint32_t keep = 0, keepBack = 0;
+        for (uint32_t g = 0; g < groups; ++g)
+        {
+            const uint32_t idx = base + g*kBlock + threadIdx.x;
+            uint32_t slot;
+            if (idx >= count || !gen_slot(fp, idx, slot))
+                continue;
+            PathRegs p;
+            float rx, ry;
+            if (begin_path(cam, fp, passSeeds, slot, p, rx, ry))
+            {
+                store_path(ps, slot, p, rx, ry, true);
+                // sorted like every later queue: camera rays that enter a mesh in HBM in front (k_walk takes those)
+                if (bp.count == 0 || ray_enters_big_mesh(primBoxes, bp, p.o, p.d)) keep |= 1u << g; else keepBack |= 1u << g;
+                samples++;
+            }
+            else
+            {
+                ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                ps.rngRaster[slot] = make_float4(0.0f, 0.0f, -1e30f, -1e30f);
+            }
+        }
+        auto slotOf = [&](int i) -> uint32_t {
+            uint32_t slot = 0;
+            (void)gen_slot(fp, base + (uint32_t)i*kBlock + threadIdx.x, slot);
+            return slot;
+        };
+        if (bp.count)
+            block_append2(keep, keepBack, q.activeCount + 0, q.activeBack + 0, queue0, s_scan, slotOf, fp.queueCapacity - 1u);
+        else
+            block_append(keep, q.activeCount + 0, queue0, s_scan, slotOf);
+    }
+    wave_add_stat(q.stats, 1, samples);
+}
+
+// ---------------------------------------------------------------------------
 // k_extend: closest hit for every queued path
 
 template <bool COUNT, bool LDS>
 __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce, int stackEntries,
-                                                                  uint32_t queueCapacity)
+                                                                  uint32_t queueCapacity, const float4* __restrict__ walkRec, uint32_t walkPrims)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
@@ -683,6 +710,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene scIn
     const uint32_t first = blockIdx.x*rounds*kBlock;
     uint32_t rays = 0;
     TraceCounters ctr = { 0, 0, 0 };
+    sc.walkRec = walkRec;           // k_walk's records of the front rays (null: meshes are walked inline)
 
     {
         for (uint32_t g = 0; g < rounds; ++g)
@@ -693,6 +721,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene scIn
             const uint32_t slot = queue[two_ended(idx, frontCount, backCount, queueCapacity)];
             const float4 ro = ps.rayO[slot];
             const float4 rd = ps.rayD[slot];
+            sc.walkItem = idx*walkPrims;        // only front rays (idx < frontCount) ever reach a walked primitive
 
             float t;
             V3 n;
@@ -848,7 +877,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn,
 
 template <bool COUNT, bool LDS>
 __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce, int stackEntries,
-                                                                  uint32_t queueCapacity)
+                                                                  uint32_t queueCapacity, const float4* __restrict__ walkRec, uint32_t walkPrims)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
@@ -861,6 +890,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene scIn
     const uint32_t first = blockIdx.x*rounds*kBlock;
     uint32_t rays = 0;
     TraceCounters ctr = { 0, 0, 0 };
+    sc.walkRec = walkRec;
 
     {
         for (uint32_t g = 0; g < rounds; ++g)
@@ -875,6 +905,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene scIn
                 const NeeRec r = load_nee(ps, slot, k);
                 float t;
                 V3 n;
+                sc.walkItem = (idx*(uint32_t)ps.neePerPath + (uint32_t)k)*walkPrims;
                 const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, time, t, n, ctr);
                 rays++;
                 if (r.dist < 0.0f)
@@ -911,27 +942,15 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene scIn, 
     SceneT<LDS> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
-    const int npix = fp.width*fp.height;
     const uint32_t idx = blockIdx.x*kBlock + threadIdx.x;
-    uint32_t uslot = 0;
-    const bool live = idx < fp.genCount && gen_slot(fp, idx, uslot);
-    const int slot = (int)uslot;
+    const uint32_t slot = idx;
+    int s = 0, i = 0, j = 0;
+    const bool live = idx < fp.genCount && slot_pixel(fp, slot, s, i, j);
     uint32_t rays = 0, shadowRays = 0, samples = 0;
     TraceCounters ctr = { 0, 0, 0 };
 
     if (live)
     {
-        const int s = slot/npix;
-        const int pix = slot - s*npix;
-        const int j = pix/fp.width;
-        const int i = pix - j*fp.width;
-
-        if (!pixel_owned(fp, i, j))
-        {
-            ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            ps.rngRaster[slot] = make_float4(0.0f, 0.0f, -1e30f, -1e30f);
-        }
-        else
         {
             Rng rng;
             float rx, ry, time;
@@ -1057,14 +1076,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FramePar
 
     for (int s = 0; s < fp.numPasses; ++s)
     {
-        const size_t passBase = (size_t)s*npix;
         for (int j = j0; j <= j1; ++j)
         {
             for (int i = i0; i <= i1; ++i)
             {
                 if (!pixel_owned(fp, i, j))
-                    continue;       // path not generated by this shard (its slot was never written)
-                const size_t slot = passBase + (size_t)j*fp.width + i;
+                    continue;       // path not generated by this shard
+                const size_t slot = slot_of(fp, s, i, j);
                 const float4 rr = ps.rngRaster[slot];
                 const float rx = rr.z, ry = rr.w;
 
@@ -1160,7 +1178,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
                      pixel_owned(fp, entGx[k], entGy[k]);
         nextRa[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (entLive[k] && fp.numPasses > 0)
-            nextRa[k] = ps.rad[(size_t)entGy[k]*fp.width + entGx[k]];
+            nextRa[k] = ps.rad[slot_of(fp, 0, entGx[k], entGy[k])];
     }
 
     for (int s = 0; s < fp.numPasses; ++s)
@@ -1169,7 +1187,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
         if (s + 1 < fp.numPasses)
             for (int k = 0; k < 2; ++k)
                 if (entLive[k])
-                    nextRa[k] = ps.rad[(size_t)(s + 1)*npix + (size_t)entGy[k]*fp.width + entGx[k]];
+                    nextRa[k] = ps.rad[slot_of(fp, s + 1, entGx[k], entGy[k])];
 
         for (int k = 0; k < 2; ++k)
         {

@@ -53,6 +53,8 @@ enum : uint32_t
 enum : uint32_t
 {
     kPrimMoving = 1u,           // startTransform != endTransform: interpolate per ray
+    kPrimWalked = 2u,           // mesh in HBM whose closest hit k_walk (tn_walk.h) computes ahead of the scan kernels
+    kPrimWalkLaneShift = 8,     // bits 8..10: which of the (up to 7) walked primitives this is = its record lane
 };
 
 struct alignas(64) Prim64
@@ -113,6 +115,8 @@ struct DevMesh
     int32_t stackNeed;          // worst-case traversal stack entries for this tree
     int32_t inArena;            // 1: nodes/tris/normals/cdf live inside DevScene::arena (and follow it into LDS)
     uint32_t offNodes, offTris, offNormals, offCdf;     // byte offsets inside the arena (inArena only)
+    int32_t topCount;           // nodes [0, topCount) are the top of the tree in breadth-first order (k_walk stages a prefix into LDS)
+    int32_t padMesh;
 };
 
 struct DevProbe
@@ -165,6 +169,10 @@ struct SceneT : DevScene
 {
     static constexpr bool kLds = LDS;
     const unsigned char* ldsBase;
+    // closest-hit records of the walked primitives for the ray being traced (tn_walk.h): record lane kb of the ray
+    // lives at walkRec[(walkItem + kb)*2 .. +1]; null = walk the mesh inline (ray_mesh)
+    const float4* walkRec;
+    uint32_t walkItem;
 };
 
 template <class SC> TN_D const Node64* mesh_nodes(const SC& sc, const DevMesh& m)

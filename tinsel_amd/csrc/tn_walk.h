@@ -1,0 +1,401 @@
+// tn_walk.h -- k_walk: the closest-hit walk of meshes that live in HBM, as its own lean streaming kernel.
+//
+// Why a kernel of its own.  The scan kernels (k_extend / k_shadow, tn_kernels.h) carry the whole scene-level
+// state of Trace() (render.cpp:17-62) around the mesh walk of IntersectRayMesh (intersection.h:661-749): 128
+// VGPRs, a wave as slow as its slowest ray (34 % of the VALU lanes active on the 524,288-triangle config,
+// profiles/r01_f_ajax_kernel_stats.md).  k_walk runs ONLY that walk, for the rays whose leaf-box test against such
+// a mesh succeeds (the front part of the sorted queues), and parks the mesh-space closest hit (32 B) in HBM; the
+// scan kernels then read the record where they would have called ray_mesh.
+//
+// What bounds the walk on gfx950 (measured, scratch/ubench/gather_bench.hip + the -DTN_WALK_PROF section timers):
+// a CU's vector-memory front end retires ~0.35 random 64-B records per clock whatever the load shape (4 x dwordx4
+// per lane, quad-cooperative, LDS-DMA: all 205 G records/s chip-wide from L1/L2, 67 G/s once the set spills to the
+// Infinity Cache), and the first version of this kernel sat at that rate with the VALUs 37 % busy.  So the design
+// spends LDS, which reads 64 B per lane an order of magnitude faster, on the part of the tree every ray visits:
+//   * TOP OF THE TREE IN LDS: the host numbers the upper levels of a walked tree breadth-first (convert_bvh,
+//     tinsel_hip.hip), one 1024-thread workgroup per CU stages the first `topCount` Node64 records (as many as fit
+//     beside the stacks, ~60 KB) and every visit to them is four ds_read_b128 instead of four global loads;
+//   * RAY REPLACEMENT: a workgroup owns a contiguous range of work items and an LDS cursor into it; a lane whose ray
+//     is finished takes the next item, so lanes stay busy until the range is exhausted (no global atomics: ranges
+//     are static, the dispatcher balances workgroups);
+//   * the near child stays in a register (only the far child of a both-hit node goes to the LDS stack);
+//   * v_min/v_max box tests when no 0*inf can occur in the wave (the reference's `a < b ? a : b` ternaries and the
+//     hardware min/max differ only on NaN and on the sign of zero, neither of which can reach a decision).
+// Same boxes, same triangles, same visit order per ray as ray_mesh (tn_isect.h): results are bit-identical
+// (asserted against the inline walk of the other pipelines in tests/test_gpu_parity.py).
+// Tried and measured, not kept: XCD-aware range mapping (each XCD a contiguous eighth of the queue so that its L2 holds
+// one patch of the tree: 24.1 -> 29.4 ms; the interleaved ranges already share their working set in TIME), 8 waves per
+// SIMD at 64 VGPRs (spills: 24.8 -> 38.6 ms).
+#pragma once
+
+#include "tn_isect.h"
+
+namespace tn {
+
+constexpr int kWalkMaxPrims = 7;
+
+struct WalkJob
+{
+    const uint32_t* queue;          // ray queue; the FRONT part [0, *frontCount) holds the slots to walk
+    const uint32_t* frontCount;
+    const float4* rayO;             // extension rays: origin|time, dir|- by slot
+    const float4* rayD;
+    const float4* nee;              // shadow rays: NEE records [(slot*K + k)*4 + {0: o|dist, 1: wi|nl}]
+    float4* rec;                    // out: [item][2] = {t,u,v,w} {n.xyz, tri};  t == FLT_MAX: no hit
+    int neePerPath;                 // 0: extension rays; K > 0: the K shadow rays of every queued slot
+    int numPrims;                   // walked primitives (1..7)
+    int prim[kWalkMaxPrims];
+    int topCount[kWalkMaxPrims];    // Node64 records of each walked primitive's tree staged into LDS (a prefix: breadth-first order)
+    int stackEntries;               // LDS stack entries per lane (deepest walked tree)
+    int refillMin;                  // idle lanes that trigger a refill from the workgroup's range
+    int leafMin;                    // lanes waiting at a triangle that trigger the triangle phase
+    unsigned long long* prof;       // developer-only (-DTN_WALK_PROF): per-section wave cycles and event counts
+};
+
+// Developer-only section timer of k_walk (never in the shipped library): s_memtime deltas per wave, summed into job.prof
+//   [0] refill cycles [1] node-phase cycles [2] triangle-phase cycles [3] pop/finish cycles [4] loop overhead cycles
+//   [5] iterations [6] refills [7] node-phase runs [8] triangle-phase runs [9] lanes in node phases [10] lanes in triangle
+//   phases [11] lanes refilled [12] waves [13] total wave cycles [14] node visits served from LDS
+#ifdef TN_WALK_PROF
+#define TN_WP_DECL unsigned long long wp[15] = { 0 }; long long wpT = clock64(); const long long wpT0 = wpT;
+#define TN_WP_TICK(k) { __builtin_amdgcn_sched_barrier(0); const long long _t = clock64(); wp[k] += (unsigned long long)(_t - wpT); wpT = _t; __builtin_amdgcn_sched_barrier(0); }
+#define TN_WP_COUNT(k, v) { wp[k] += (unsigned long long)(v); }
+#define TN_WP_FLUSH { wp[12] = 1; wp[13] = (unsigned long long)(clock64() - wpT0); if (lane == 0 && job.prof) for (int k = 0; k < 15; ++k) atomicAdd(job.prof + k, wp[k]); }
+#else
+#define TN_WP_DECL
+#define TN_WP_TICK(k)
+#define TN_WP_COUNT(k, v)
+#define TN_WP_FLUSH
+#endif
+
+// IntersectRayAABBFast (intersection.h:373-397) with hardware min/max.  Only for rays whose 1/d is finite in
+// all three components: then every product below is finite or +-inf, never NaN, and v_min/v_max return what the
+// reference's ternaries return up to the sign of a zero, which no comparison below or in the caller can see.
+TN_D bool ray_aabb_minmax(V3 pos, V3 rcp, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t)
+{
+    float l1 = (minx - pos.x)*rcp.x;
+    float l2 = (maxx - pos.x)*rcp.x;
+    float lmin = fminf(l1, l2);
+    float lmax = fmaxf(l1, l2);
+
+    l1 = (miny - pos.y)*rcp.y;
+    l2 = (maxy - pos.y)*rcp.y;
+    lmin = fmaxf(fminf(l1, l2), lmin);
+    lmax = fminf(fmaxf(l1, l2), lmax);
+
+    l1 = (minz - pos.z)*rcp.z;
+    l2 = (maxz - pos.z)*rcp.z;
+    lmin = fmaxf(fminf(l1, l2), lmin);
+    lmax = fminf(fmaxf(l1, l2), lmax);
+
+    t = lmin;
+    return (lmax >= 0.f) & (lmax >= lmin);
+}
+
+TN_D bool finite_bits(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
+
+// The walked meshes live in HBM by definition: say so to the compiler (a pointer read out of the mesh table is a
+// generic one to it, and generic loads are flat_load + a wait on both counters).
+typedef float WalkF4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) WalkF4* GlobalF4;
+TN_D GlobalF4 as_global(const void* p) { return (GlobalF4)(uintptr_t)p; }
+
+template <class Ptr>
+TN_D Node64 load_node_from(Ptr nodes, uint32_t idx)
+{
+    Ptr p = nodes + (size_t)idx*4;
+    const WalkF4 a = p[0], b = p[1], c = p[2], d = p[3];
+    Node64 n;
+    n.lminx = a.x; n.lminy = a.y; n.lminz = a.z; n.lmaxx = a.w;
+    n.lmaxy = b.x; n.lmaxz = b.y; n.rminx = b.z; n.rminy = b.w;
+    n.rminz = c.x; n.rmaxx = c.y; n.rmaxy = c.z; n.rmaxz = c.w;
+    n.left = __float_as_uint(d.x);
+    n.right = __float_as_uint(d.y);
+    return n;
+}
+
+// LDS of one workgroup: [stackEntries][BLOCK] stack words, then 16 control words, then the staged tree tops.
+constexpr int kWalkCtlWords = 16;
+
+template <int BLOCK, int WAVES>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_walk[];
+    uint32_t* const stack = s_walk + threadIdx.x;               // this lane's column: entry i at stack[i*BLOCK]
+    uint32_t* const s_ctl = s_walk + job.stackEntries*BLOCK;    // [0] the workgroup's cursor
+    WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_ctl + kWalkCtlWords);
+
+    const int lane = (int)__lane_id();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t Kx = job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
+    const uint32_t Kb = (uint32_t)job.numPrims;
+    const uint32_t per = Kx*Kb;                                 // work items per queued slot
+    const uint32_t total = (*job.frontCount)*per;
+
+    // static ranges: workgroup b -> the b-th contiguous piece of the items; its waves share it through an LDS cursor
+    const uint32_t chunk = (total + gridDim.x - 1u)/gridDim.x;
+    const uint32_t bbeg = blockIdx.x*chunk < total ? blockIdx.x*chunk : total;
+    const uint32_t end = (bbeg + chunk) < total ? (bbeg + chunk) : total;
+    if (threadIdx.x == 0)
+        s_ctl[0] = bbeg;
+
+    // stage the tops of the walked trees (a workgroup with nothing to do skips it)
+    if (bbeg < end)
+    {
+        uint32_t base = 0;
+#pragma unroll 1
+        for (int kb = 0; kb < job.numPrims; ++kb)
+        {
+            int primIndex = job.prim[0], n = job.topCount[0];
+#pragma unroll
+            for (int q = 1; q < kWalkMaxPrims; ++q)
+                if (q == kb) { primIndex = job.prim[q]; n = job.topCount[q]; }
+            if (n > 0)
+            {
+                const Prim64 p = load_prim(sc.prims, primIndex);
+                GlobalF4 src = as_global(sc.meshes[p.mesh].nodes);
+                WalkF4* dst = s_top + (size_t)base*4;
+                for (uint32_t i = threadIdx.x; i < (uint32_t)n*4u; i += BLOCK)
+                    dst[i] = src[i];
+                base += (uint32_t)n;
+            }
+        }
+    }
+    __syncthreads();
+
+    // per-lane walk state
+    bool active = false;
+    uint32_t item = 0, ref = 0;
+    int sp = 0;
+    V3 o, d, rcp;
+    float closestT = kFltMax;
+    float hu = 0.0f, hv = 0.0f, hw = 0.0f;
+    int htri = -1;
+    V3 hn;
+    GlobalF4 mnodes = nullptr;
+    GlobalF4 mtris = nullptr;
+    uint32_t topBase = 0, topN = 0;     // this lane's tree: refs < topN are staged at s_top[(topBase + ref)*4 ..]
+    bool pending = false;               // a finished ray's record is still in this lane's registers (see the refill)
+    bool finiteAll = true;              // wave-uniform: every active lane's 1/d is finite
+    bool exhausted = bbeg >= end;       // wave-uniform: the workgroup's range has been handed out
+    TN_WP_DECL
+
+    for (;;)
+    {
+        TN_WP_TICK(4)
+        TN_WP_COUNT(5, 1)
+        // ---- refill: idle lanes take the next items of the workgroup's range ---------------------------------
+        const unsigned long long idleMask = __ballot(!active);
+        const int nIdle = __popcll(idleMask);
+        if (!exhausted && nIdle >= job.refillMin)
+        {
+            TN_WP_COUNT(6, 1)
+            TN_WP_COUNT(11, nIdle)
+            uint32_t cur = 0;
+            if (lane == 0)
+                cur = atomicAdd(&s_ctl[0], (uint32_t)nIdle);        // LDS atomic: one per refill
+            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+            exhausted = cur + (uint32_t)nIdle >= end;
+            if (!active)
+            {
+                // A finished ray's record is written HERE, next to the loads of the lane's next ray, not where the ray
+                // ends: stores count against vmcnt like loads on gfx950, so a 32-B record on its way to HBM would sit in
+                // front of every node fetch the wave waits for (measured: node phases of 1900-2800 cycles, 780 when
+                // nothing but LDS reads was outstanding).
+                if (pending)
+                {
+                    float4* out = job.rec + (size_t)item*2;
+                    out[0] = make_float4(closestT, hu, hv, hw);
+                    if (closestT < kFltMax)
+                        out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
+                    pending = false;
+                }
+                const uint32_t my = cur + (uint32_t)__popcll(idleMask & below);
+                if (my < end)
+                {
+                    const uint32_t qi = my/per;
+                    const uint32_t rem = my - qi*per;
+                    const uint32_t k = rem/Kb;
+                    const uint32_t kb = rem - k*Kb;
+                    const uint32_t slot = job.queue[qi];
+
+                    float4 ro, rd;
+                    float time;
+                    if (job.neePerPath > 0)
+                    {
+                        const float4* np = job.nee + ((size_t)slot*Kx + k)*4;
+                        ro = np[0]; rd = np[1];
+                        time = job.rayO[slot].w;        // rayTime never changes along a path
+                    }
+                    else
+                    {
+                        ro = job.rayO[slot]; rd = job.rayD[slot];
+                        time = ro.w;
+                    }
+                    const V3 wo(ro.x, ro.y, ro.z), wd(rd.x, rd.y, rd.z);
+
+                    int index = job.prim[0];
+                    uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
+#pragma unroll
+                    for (int q = 1; q < kWalkMaxPrims; ++q)
+                    {
+                        if ((uint32_t)q == kb)
+                        {
+                            index = job.prim[q];
+                            tb = run;
+                            tn = (uint32_t)job.topCount[q];
+                        }
+                        run += (uint32_t)job.topCount[q];
+                    }
+
+                    // the leaf-box test of the scan (trace_flat / the scene BVH walk): same function, same operands
+                    const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + index);
+                    const float4 b0 = bp[0], b1 = bp[1];
+                    const V3 wrcp(1.0f/wd.x, 1.0f/wd.y, 1.0f/wd.z);
+                    float tbox;
+                    bool enters = true;         // rays the scan does not box-test (ray_sane) are walked unconditionally
+                    if (__float_as_uint(b1.z) == 0u && ray_sane(wo))
+                        enters = ray_aabb(wo, wrcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tbox);
+
+                    if (!enters)
+                    {
+                        job.rec[(size_t)my*2] = make_float4(kFltMax, 0.0f, 0.0f, 0.0f);
+                    }
+                    else
+                    {
+                        // PrimitiveIntersect's mesh branch up to IntersectRayMesh (intersection.h:977-990)
+                        const Prim64 p = load_prim(sc.prims, index);
+                        const Xform x = prim_pose(sc, p, time);
+                        o = inv_xform_point(x, wo);
+                        d = inv_xform_vector(x, wd);
+                        rcp = V3(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+                        const DevMesh* m = sc.meshes + p.mesh;
+                        mnodes = as_global(m->nodes);
+                        mtris = as_global(m->tris);
+                        topBase = tb;
+                        topN = tn;
+                        ref = m->root;
+                        sp = 0;
+                        closestT = kFltMax;
+                        htri = -1;
+                        item = my;
+                        active = true;
+                    }
+                }
+            }
+            finiteAll = __all(!active || (finite_bits(rcp.x) && finite_bits(rcp.y) && finite_bits(rcp.z) &&
+                                          finite_bits(o.x) && finite_bits(o.y) && finite_bits(o.z)));
+            TN_WP_TICK(0)
+        }
+
+        if (__ballot(active) == 0ull)
+        {
+            if (exhausted)
+                break;
+            continue;
+        }
+
+        bool pop = false;
+#ifdef TN_WALK_PROF
+        { const unsigned long long nm = __ballot(active && !(ref & kLeafBit)); if (nm) { TN_WP_COUNT(7, 1) TN_WP_COUNT(9, __popcll(nm)) }
+          TN_WP_COUNT(14, __popcll(__ballot(active && !(ref & kLeafBit) && ref < topN))) }
+        TN_WP_TICK(4)
+#endif
+
+        // ---- node phase: lanes at an internal node -------------------------------------------------------------
+        if (active && !(ref & kLeafBit))
+        {
+            Node64 nd;
+            if (ref < topN)
+                nd = load_node_from((const WalkF4*)s_top, topBase + ref);   // 4 x ds_read_b128
+            else
+                nd = load_node_from(mnodes, ref);                           // 4 x global_load_dwordx4
+            float tL, tR;
+            bool hL, hR;
+            if (finiteAll)
+            {
+                hL = ray_aabb_minmax(o, rcp, nd.lminx, nd.lminy, nd.lminz, nd.lmaxx, nd.lmaxy, nd.lmaxz, tL);
+                hR = ray_aabb_minmax(o, rcp, nd.rminx, nd.rminy, nd.rminz, nd.rmaxx, nd.rmaxy, nd.rmaxz, tR);
+            }
+            else
+            {
+                tL = tR = 0.0f;
+                hL = ray_aabb(o, rcp, nd.lminx, nd.lminy, nd.lminz, nd.lmaxx, nd.lmaxy, nd.lmaxz, tL);
+                hR = ray_aabb(o, rcp, nd.rminx, nd.rminy, nd.rminz, nd.rmaxx, nd.rmaxy, nd.rmaxz, tR);
+            }
+            hL = hL && tL < closestT;       // `tLeft < tmax`, tmax == closestT after every leaf (intersection.h:701-702)
+            hR = hR && tR < closestT;
+
+            if (hL && hR)
+            {
+                // the reference pushes far then near and pops near: the near child continues in a register
+                const bool leftNear = tL < tR;
+                stack[sp*BLOCK] = leftNear ? nd.right : nd.left;
+                ++sp;
+                ref = leftNear ? nd.left : nd.right;
+            }
+            else if (hL)
+                ref = nd.left;
+            else if (hR)
+                ref = nd.right;
+            else
+                pop = true;
+        }
+
+        TN_WP_TICK(1)
+        // ---- triangle phase: once enough lanes wait at a leaf (or nobody has a node to visit) -----------------
+        const bool atLeaf = active && !pop && (ref & kLeafBit);
+        const unsigned long long leafMask = __ballot(atLeaf);
+        if (leafMask != 0ull && (__popcll(leafMask) >= job.leafMin || __ballot(active && !pop && !atLeaf) == 0ull))
+        {
+            TN_WP_COUNT(8, 1)
+            TN_WP_COUNT(10, __popcll(leafMask))
+            if (atLeaf)
+            {
+                const int i = (int)(ref & ~kLeafBit);
+                GlobalF4 tp = mtris + (size_t)i*3;
+                const WalkF4 ta = tp[0], tb = tp[1], tc = tp[2];
+                float t, u, v, w, sign;
+                V3 n;
+                if (ray_tri(o, d, V3(ta.x, ta.y, ta.z), V3(tb.x, tb.y, tb.z), V3(tc.x, tc.y, tc.z), t, u, v, w, sign, n))
+                {
+                    if (t > 0.0f && t < closestT)
+                    {
+                        closestT = t;
+                        hu = u; hv = v; hw = w;
+                        htri = i;
+                        hn = n*sign;
+                    }
+                }
+                pop = true;
+            }
+        }
+
+        TN_WP_TICK(2)
+        // ---- next entry, or the ray is done ---------------------------------------------------------------------
+        if (pop)
+        {
+            if (sp > 0)
+            {
+                --sp;
+                ref = stack[sp*BLOCK];
+            }
+            else
+            {
+                active = false;
+                pending = true;         // the record stays in registers until the lane's next refill
+            }
+        }
+        TN_WP_TICK(3)
+    }
+    if (pending)
+    {
+        float4* out = job.rec + (size_t)item*2;
+        out[0] = make_float4(closestT, hu, hv, hw);
+        if (closestT < kFltMax)
+            out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
+    }
+    TN_WP_FLUSH
+}
+
+} // namespace tn

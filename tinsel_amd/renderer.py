@@ -86,6 +86,7 @@ def load_library():
     L.tinsel_image_quantize_rgb8.argtypes = [vp, ci, ci, vp]
     L.tinsel_hip_stack_entries.argtypes = [vp]
     L.tinsel_hip_nee_per_path.argtypes = [vp]
+    L.tinsel_hip_walked_prims.argtypes = [vp]
     L.tinsel_hip_last_error.restype = C.c_char_p
     L.tinsel_pack_open.argtypes = [vp, C.c_size_t, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.Options)]
     _lib = L
@@ -100,6 +101,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
     "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
     "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_russian_roulette", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
+    "tinsel_hip_walked_prims",
 ]
 
 
@@ -288,6 +290,11 @@ class HipRenderer:
     @property
     def nee_per_path(self):
         return self._L.tinsel_hip_nee_per_path(self._h)
+
+    @property
+    def walked_prims(self):
+        """Primitives whose mesh BVH the dedicated k_walk kernel traverses (0: all meshes are walked inline)."""
+        return self._L.tinsel_hip_walked_prims(self._h)
 
     def close(self):
         if self._h:
