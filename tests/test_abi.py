@@ -87,6 +87,40 @@ def test_pack_open_rejects_garbage():
         tinsel_amd.Scene(good[:300])
 
 
+def test_pack_open_rejects_offsets_and_counts_that_wrap(golden_dir):
+    """A hostile pack must not get pointers outside the blob: offsets near 2^64 (off + bytes wraps), negative counts."""
+    import struct
+    good = bytearray(open(os.path.join(golden_dir, "cornell.pack"), "rb").read())
+    # header: magic 8, version 4, num_primitives 4, num_bvh_nodes 4, num_meshes 4, total_bytes 8, off_primitives 8, off_bvh_nodes 8
+    bad = bytearray(good)
+    struct.pack_into("<Q", bad, 32, 0xFFFFFFFFFFFFFF00)            # off_primitives: off + bytes wraps past zero
+    with pytest.raises(tinsel_amd.TinselHipError):
+        tinsel_amd.Scene(bytes(bad))
+    bad = bytearray(good)
+    struct.pack_into("<I", bad, 12, 0xFFFFFFF0)                    # num_primitives * 272 overflows 32 bits, not 64: out of range
+    with pytest.raises(tinsel_amd.TinselHipError):
+        tinsel_amd.Scene(bytes(bad))
+    # a mesh primitive with negative counts / an offset that wraps
+    off_prims = struct.unpack_from("<Q", good, 32)[0]
+    nprims = struct.unpack_from("<I", good, 12)[0]
+    mesh_at = None
+    for i in range(nprims):
+        base = off_prims + i*272
+        if struct.unpack_from("<i", good, base + 64)[0] == abi.GEOM_MESH:
+            mesh_at = base + 72
+            break
+    assert mesh_at is not None
+    bad = bytearray(good)
+    struct.pack_into("<i", bad, mesh_at + 40, -5)                  # num_vertices
+    with pytest.raises(tinsel_amd.TinselHipError):
+        tinsel_amd.Scene(bytes(bad))
+    bad = bytearray(good)
+    struct.pack_into("<Q", bad, mesh_at + 0, 0xFFFFFFFFFFFFFFF8)   # positions offset
+    with pytest.raises(tinsel_amd.TinselHipError):
+        tinsel_amd.Scene(bytes(bad))
+    tinsel_amd.Scene(bytes(good))                                  # the untouched pack still opens
+
+
 def test_no_cpu_fallback(golden_dir):
     """Without a visible GPU the constructor must raise; nothing renders on the host."""
     import torch

@@ -209,6 +209,33 @@ def test_unsupported_inputs_fail_loudly():
     r.close()
 
 
+def test_malformed_bvhs_are_refused():
+    """tinsel_hip_create walks the trees it is handed: a leaf that indexes past the items, a child past the nodes and a
+    cycle must be refused with a message, not walked (host out-of-bounds reads, an endless DFS, device OOB reads)."""
+    import ctypes as C
+    import struct
+    import tinsel_amd
+    good = open(os.path.join(GOLDEN, "cornell.pack"), "rb").read()
+    off_bvh = struct.unpack_from("<Q", good, 40)[0]
+    nnodes = struct.unpack_from("<I", good, 16)[0]
+    nprims = struct.unpack_from("<I", good, 12)[0]
+
+    def node(blob, k):
+        return struct.unpack_from("<II", blob, off_bvh + 32*k + 24)
+
+    # find one leaf and one internal node of the scene BVH
+    leaf = next(k for k in range(nnodes) if node(good, k)[1] >> 31)
+    internal = next(k for k in range(1, nnodes) if not node(good, k)[1] >> 31)
+    cases = []
+    b = bytearray(good); struct.pack_into("<I", b, off_bvh + 32*leaf + 24, nprims + 3); cases.append(("leaf item out of range", b))
+    b = bytearray(good); struct.pack_into("<I", b, off_bvh + 32*internal + 24, nnodes + 7); cases.append(("child out of range", b))
+    b = bytearray(good); struct.pack_into("<I", b, off_bvh + 32*internal + 24, 0); cases.append(("cycle through the root", b))
+    for what, blob in cases:
+        scene = tinsel_amd.Scene(bytes(blob))
+        with pytest.raises(tinsel_amd.TinselHipError, match="malformed"):
+            tinsel_amd.create_gpu_renderer(scene)
+
+
 @pytest.mark.parametrize("pipeline", [abi.PIPELINE_WAVEFRONT, abi.PIPELINE_WAVEFRONT_SPLIT, abi.PIPELINE_MEGAKERNEL], ids=["wavefront", "split", "mega"])
 @pytest.mark.parametrize("world,tile,fwidth", [(4, 8, 1.0), (3, 20, 1.0), (8, 32, 0.75), (2, 32, 3.0), (5, 64, 1.0)])
 def test_every_shard_is_bit_identical_to_the_oracle_shard(pipeline, world, tile, fwidth):

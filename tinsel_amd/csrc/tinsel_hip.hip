@@ -351,6 +351,8 @@ struct tinsel_hip
     bool countDetail = false;
 
     uint32_t passIndex = 0;
+    Rng seedRng = Rng::seeded(1u);      // Random(1) advanced seedRngIndex times: the generator of the pass seeds
+    uint32_t seedRngIndex = 0;
     int shardRank = 0, shardWorld = 1, shardTile = 32;
 
     bool timing = false;
@@ -892,26 +894,29 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
     if (fp.maxDepth < 1)
         return 0;
 
-    // pass seeds for this call: passSeed[s] = (s+1)-th output of Random(1).Rand()
-    std::vector<uint32_t> seeds((size_t)passes);
+    // pass seeds for this call: passSeed[s] = (passIndex+s+1)-th output of Random(1).Rand().  The host only keeps the
+    // generator's state at passIndex; the seeds themselves are produced on the device, in stream order (k_pass_seeds).
+    if (r->seedRngIndex > r->passIndex)
     {
-        Rng sr = Rng::seeded(1u);
-        for (uint32_t i = 0; i < r->passIndex; ++i)
-            (void)sr.rand();
-        for (int i = 0; i < passes; ++i)
-            seeds[(size_t)i] = sr.rand();
+        r->seedRng = Rng::seeded(1u);
+        r->seedRngIndex = 0;
     }
+    for (; r->seedRngIndex < r->passIndex; ++r->seedRngIndex)
+        (void)r->seedRng.rand();
     if (r->passSeedsCap < (size_t)passes)
     {
         if (r->passSeedsDev)
+        {
+            HIP_TRY(hipDeviceSynchronize());        // growth only: earlier launches may still read the old array
             (void)hipFree(r->passSeedsDev);
-        HIP_TRY(hipMalloc((void**)&r->passSeedsDev, sizeof(uint32_t)*(size_t)passes));
-        r->passSeedsCap = (size_t)passes;
+            r->passSeedsDev = nullptr;
+            r->passSeedsCap = 0;
+        }
+        const size_t cap = std::max<size_t>((size_t)passes, 64);
+        HIP_TRY(hipMalloc((void**)&r->passSeedsDev, sizeof(uint32_t)*cap));
+        r->passSeedsCap = cap;
     }
-    HIP_TRY(hipMemcpyAsync(r->passSeedsDev, seeds.data(), sizeof(uint32_t)*(size_t)passes, hipMemcpyHostToDevice, st));
-    // the host vector dies at return: make the copy complete first (pageable memcpy is staged synchronously
-    // by the runtime, but do not rely on it)
-    HIP_TRY(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_pass_seeds, dim3(1), dim3(1), 0, st, r->seedRng.s1, r->seedRng.s2, passes, r->passSeedsDev);
 
     const size_t perPass = slots_per_pass(r, fp.width, fp.height);
     int perBatch = (int)std::max<size_t>(1, batch_slots(r)/perPass);
@@ -1407,9 +1412,23 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         }
     }
 
+    // the traversal stacks (+ the staged arena) must fit a workgroup's LDS: give the arena up first, then refuse
+    if (ok && stack_bytes(r) > (size_t)r->sharedMemLimit && r->scene.arenaLdsBytes)
+    {
+        r->scene.arenaLdsBytes = 0;
+        r->scene.allInArena = 0;
+    }
+    if (ok && stack_bytes(r) > (size_t)r->sharedMemLimit)
+    {
+        fail("create: the traversal stacks of this scene need " + std::to_string(stack_bytes(r)) + " B of LDS per workgroup, the device offers " + std::to_string(r->sharedMemLimit));
+        ok = false;
+    }
+
     if (!ok)
     {
         r->sceneMem.release();
+        if (r->statsDev) (void)hipFree(r->statsDev);
+        if (r->walkProf) (void)hipFree(r->walkProf);
         delete r;
         return nullptr;
     }
@@ -1616,6 +1635,7 @@ int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
         *build_ms = 0.0;
 
     std::vector<DevMesh> next = r->meshesRef;
+    const size_t prevAllocs = r->lbvhAllocs.size();
     if (mode == TINSEL_BVH_LBVH)
     {
         hipEvent_t e0, e1;
@@ -1643,19 +1663,24 @@ int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
         if (dm.stackNeed > maxMeshNeed)
             maxMeshNeed = dm.stackNeed;
     const int stack = pick_stack(r->sceneStackNeed + maxMeshNeed);
-    if (stack < 0)
-        return fail("set_mesh_bvh: tree too deep for the 156-entry LDS traversal stack (reference trees kept)");
+    const size_t ldsNeed = stack < 0 ? 0 : ((size_t)stack*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes;
+    if (stack < 0 || ldsNeed > (size_t)r->sharedMemLimit)
+    {
+        // keep what was there: drop the trees just built
+        for (size_t k = prevAllocs; k < r->lbvhAllocs.size(); ++k)
+            (void)hipFree(r->lbvhAllocs[k]);
+        r->lbvhAllocs.resize(prevAllocs);
+        return fail("set_mesh_bvh: tree too deep for the LDS traversal stack (previous trees kept)");
+    }
     if (!next.empty())
         HIP_TRY(hipMemcpy((void*)r->scene.meshes, next.data(), sizeof(DevMesh)*next.size(), hipMemcpyHostToDevice));
     r->meshesNow = next;
     r->stackNeed = stack;
     r->bvhMode = mode;
-    if (mode == TINSEL_BVH_REFERENCE)
-    {
-        for (void* p : r->lbvhAllocs)
-            (void)hipFree(p);
-        r->lbvhAllocs.clear();
-    }
+    // the previous generation of device-built trees is unreachable now (a per-frame rebuild must not grow)
+    for (size_t k = 0; k < prevAllocs; ++k)
+        (void)hipFree(r->lbvhAllocs[k]);
+    r->lbvhAllocs.erase(r->lbvhAllocs.begin(), r->lbvhAllocs.begin() + (long)prevAllocs);
     return 0;
 }
 
@@ -1896,8 +1921,11 @@ int tinsel_pack_open(void* blob, size_t size, tinsel_scene_desc* out_scene, tins
         return fail("pack_open: not a TINPACK1 blob");
     if (hdr.total_bytes > size)
         return fail("pack_open: truncated blob");
+    if (hdr.probe_width < 0 || hdr.probe_height < 0)
+        return fail("pack_open: negative probe size");
 
-    auto in_range = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(hdr) && off + bytes <= hdr.total_bytes; };
+    // written so that nothing can wrap: bytes <= total first, then off <= total - bytes
+    auto in_range = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(hdr) && bytes <= hdr.total_bytes && off <= hdr.total_bytes - bytes; };
 
     if (!in_range(hdr.off_primitives, (uint64_t)hdr.num_primitives*sizeof(tinsel_primitive)) ||
         !in_range(hdr.off_bvh_nodes, (uint64_t)hdr.num_bvh_nodes*sizeof(tinsel_bvh_node)))
@@ -1910,6 +1938,8 @@ int tinsel_pack_open(void* blob, size_t size, tinsel_scene_desc* out_scene, tins
         if (p.type != TINSEL_GEOM_MESH)
             continue;
         tinsel_mesh_geometry& g = p.geo.mesh;
+        if (g.num_vertices < 0 || g.num_indices < 0 || g.num_nodes < 0)
+            return fail("pack_open: negative mesh counts");
         // offsets -> pointers, exactly once (a resolved pointer is far above total_bytes)
         const uint64_t offs[5] = { (uint64_t)(uintptr_t)g.positions, (uint64_t)(uintptr_t)g.normals, (uint64_t)(uintptr_t)g.indices,
                                    (uint64_t)(uintptr_t)g.nodes, (uint64_t)(uintptr_t)g.cdf };

@@ -1262,6 +1262,20 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
 }
 
 // ---------------------------------------------------------------------------
+// k_pass_seeds: passSeed[s] = the (first + s + 1)-th output of Random(1).Rand() (render.cu:1050-1052, 1099), continued on
+// the device from the generator state the host keeps for the next pass: one thread, a few thousand integer steps at
+// most, and the call that needs the seeds neither copies from host memory nor waits for anything.
+__global__ void k_pass_seeds(uint32_t s1, uint32_t s2, int n, uint32_t* __restrict__ out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    Rng r;
+    r.s1 = s1; r.s2 = s2;
+    for (int i = 0; i < n; ++i)
+        out[i] = r.rand();
+}
+
+// ---------------------------------------------------------------------------
 // k_normals: eNormals mode of the CPU renderer (render.cpp:494-515): x=i, y=j, time 1, overwrite.
 
 template <bool LDS>
