@@ -318,6 +318,39 @@ int tinsel_hip_walked_prims(tinsel_hip* r);
 const char* tinsel_hip_last_error(void);
 
 /* ------------------------------------------------------------------------- */
+/* All GPUs of one node behind ONE Renderer (tinsel_hip_create(scene, num_gpus); north_star: pixel   */
+/* tiles sharded over the 8 GPUs with an RCCL reduce of the float4 accumulation buffer).                            */
+/*                                                                                                                   */
+/* The reference's caller is one single-threaded C++ loop (main.cpp:207 creates the renderer, :246-250 calls         */
+/* Render): a group gives that caller N devices with no second process and no Python.  One host thread per device    */
+/* drives a full tinsel_hip renderer of its own (scene uploaded to every device, rank-local path slots: set_shard);  */
+/* every member traces the paths of ITS pixel tiles for every pass of a call, seeds depend on (pixel, pass) only, so  */
+/* the sum over members of the accumulators is the single-GPU image up to float summation order.  That sum is ONE    */
+/* ncclReduce(SUM, float, 4*W*H) over xGMI into a buffer on member 0 per read-back (the members' own accumulators    */
+/* are never modified by it, so repeated calls cannot double-count), followed by the D2H copy.  RCCL is loaded with  */
+/* dlopen on first use (librccl.so.1): a single-GPU user of this library needs no RCCL at all.                       */
+
+typedef struct tinsel_hip_group tinsel_hip_group;      /* opaque */
+
+/* Replaces `new GpuRenderer(scene)` for `num_gpus` devices (0 = every visible device), devices 0..num_gpus-1, pixel
+ * tiles of `tile` x `tile` (0 = 64) dealt round-robin.  num_gpus == 1 is exactly one tinsel_hip (no RCCL, no threads'
+ * worth of difference in the image).  Fails (NULL + tinsel_hip_last_error) when fewer devices are visible -- except
+ * under TINSEL_HIP_GROUP_ONE_DEVICE=1, a VALIDATION switch for single-GPU boxes: all members share device 0 and the
+ * reduce is a device-local sum in rank order instead of the RCCL call (threads, shards, slots and read-back as real). */
+tinsel_hip_group* tinsel_hip_group_create(const tinsel_scene_desc* scene, int num_gpus, int tile);
+void tinsel_hip_group_destroy(tinsel_hip_group* g);
+/* Renderer::Init on every member (+ the reduce target on member 0). */
+int tinsel_hip_group_init(tinsel_hip_group* g, int width, int height);
+/* Renderer::Render: `passes` more samples per pixel of the WHOLE frame (each member its tiles), then -- when out_rgba
+ * is not NULL -- reduce + copy the running sum of everything since Init to out_rgba (W*H*4 floats, host). */
+int tinsel_hip_group_render(tinsel_hip_group* g, const tinsel_camera* camera, const tinsel_options* options, float* out_rgba, int passes);
+/* The display stage (tinsel_hip_present) on the reduced accumulator, run on member 0. */
+int tinsel_hip_group_present(tinsel_hip_group* g, const tinsel_options* options, int nlm_width, float nlm_falloff, float* out_rgba);
+int tinsel_hip_group_size(tinsel_hip_group* g);
+/* Member `rank`'s renderer, for the introspection / statistics entry points (do not render or init through it). */
+tinsel_hip* tinsel_hip_group_member(tinsel_hip_group* g, int rank);
+
+/* ------------------------------------------------------------------------- */
 /* Scene packs: a relocatable single-blob serialisation of tinsel_scene_desc   */
 /* (+ the scene's camera/options) so that scenes travel to machines without    */
 /* the reference's loader.  See DESIGN.md "Scene pack".                         */

@@ -13,6 +13,7 @@
 #include "../include/tinsel_hip.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 static_assert(sizeof(Primitive) == sizeof(tinsel_primitive), "Primitive layout");
 static_assert(sizeof(BVHNode) == sizeof(tinsel_bvh_node), "BVHNode layout");
@@ -22,9 +23,12 @@ static_assert(sizeof(Color) == 4*sizeof(float), "Color layout");
 
 struct HipRenderer : public Renderer
 {
-    tinsel_hip* handle;
+    // Every visible GPU of the node behind the one Renderer the caller asked for (TINSEL_HIP_NUM_GPUS limits it): pixel
+    // tiles sharded over the devices, one RCCL reduce of the accumulation buffer per Render (include/tinsel_hip.h,
+    // tinsel_hip_group_*).  With one device this is exactly one tinsel_hip.
+    tinsel_hip_group* group;
 
-    HipRenderer(const Scene* s) : handle(NULL)
+    HipRenderer(const Scene* s) : group(NULL)
     {
         tinsel_scene_desc d = {};
         d.primitives = (const tinsel_primitive*)&s->primitives[0];
@@ -45,17 +49,20 @@ struct HipRenderer : public Renderer
             d.probe_pdf_y = p.pdfValuesY;
             d.probe_cdf_y = p.cdfValuesY;
         }
-        handle = tinsel_hip_create(&d, 0);
-        if (!handle)
+        const char* n = getenv("TINSEL_HIP_NUM_GPUS");
+        group = tinsel_hip_group_create(&d, n ? atoi(n) : 0, 64);
+        if (!group)
             fprintf(stderr, "CreateGpuRenderer: %s\n", tinsel_hip_last_error());
+        else if (tinsel_hip_group_size(group) > 1)
+            fprintf(stderr, "CreateGpuRenderer: %d GPUs\n", tinsel_hip_group_size(group));
     }
 
-    virtual ~HipRenderer() { tinsel_hip_destroy(handle); }
+    virtual ~HipRenderer() { tinsel_hip_group_destroy(group); }
 
-    // Renderer::Init (render.h:70): allocate + zero the accumulator (render.cu:1070-1075)
+    // Renderer::Init (render.h:70): allocate + zero the accumulators (render.cu:1070-1075)
     virtual void Init(int width, int height)
     {
-        if (handle && tinsel_hip_init(handle, width, height))
+        if (group && tinsel_hip_group_init(group, width, height))
             fprintf(stderr, "HipRenderer::Init: %s\n", tinsel_hip_last_error());
     }
 
@@ -64,7 +71,7 @@ struct HipRenderer : public Renderer
     // reports no errors either; the message is on stderr and in tinsel_hip_last_error()).
     virtual void Render(const Camera& camera, const Options& options, Color* output)
     {
-        if (handle && tinsel_hip_render(handle, (const tinsel_camera*)&camera, (const tinsel_options*)&options, (float*)output, 1))
+        if (group && tinsel_hip_group_render(group, (const tinsel_camera*)&camera, (const tinsel_options*)&options, (float*)output, 1))
             fprintf(stderr, "HipRenderer::Render: %s\n", tinsel_hip_last_error());
     }
 };
@@ -79,7 +86,7 @@ Renderer* CreateGpuRenderer(const Scene* s)
 extern "C" int HipRendererRenderPasses(Renderer* r, const Camera& camera, const Options& options, Color* output, int passes)
 {
     HipRenderer* h = static_cast<HipRenderer*>(r);
-    return h->handle ? tinsel_hip_render(h->handle, (const tinsel_camera*)&camera, (const tinsel_options*)&options, (float*)output, passes) : -1;
+    return h->group ? tinsel_hip_group_render(h->group, (const tinsel_camera*)&camera, (const tinsel_options*)&options, (float*)output, passes) : -1;
 }
 
 // The display stage of main.cpp:258-282 on the device accumulator: `filtered` receives what main.cpp calls
@@ -87,5 +94,11 @@ extern "C" int HipRendererRenderPasses(Renderer* r, const Camera& camera, const 
 extern "C" int HipRendererPresent(Renderer* r, const Options& options, Color* filtered, int nlmWidth, float nlmFalloff)
 {
     HipRenderer* h = static_cast<HipRenderer*>(r);
-    return h->handle ? tinsel_hip_present(h->handle, (const tinsel_options*)&options, nlmWidth, nlmFalloff, (float*)filtered) : -1;
+    return h->group ? tinsel_hip_group_present(h->group, (const tinsel_options*)&options, nlmWidth, nlmFalloff, (float*)filtered) : -1;
+}
+
+extern "C" int HipRendererNumGpus(Renderer* r)
+{
+    HipRenderer* h = static_cast<HipRenderer*>(r);
+    return h->group ? tinsel_hip_group_size(h->group) : 0;
 }

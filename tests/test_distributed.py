@@ -39,11 +39,17 @@ def _worker(rank, world, port, tmp):
         mask = distributed.owned_mask(opt.width, opt.height, rank, world, 8)
         assert nsamples == 2*int(mask.sum())          # the oracle's shard rule == the host's owned_mask
         t = torch.from_numpy(acc)
-        distributed.reduce_accum(t, dst=0)
+        mine = t.clone()
+        total = distributed.reduce_accum(t, dst=0)
+        assert torch.equal(t, mine)                   # the rank's own accumulator is untouched by the reduce ...
+        again = distributed.reduce_accum(t, dst=0)    # ... so reducing twice gives the same frame (no double counting)
         if rank == 0:
+            assert torch.equal(total, again)
             whole, _, _ = P.render_seeded(h, cam, opt, 0, 2, threads=2)
-            np.save(os.path.join(tmp, "reduced.npy"), t.numpy())
+            np.save(os.path.join(tmp, "reduced.npy"), total.numpy())
             np.save(os.path.join(tmp, "whole.npy"), whole)
+        else:
+            assert total is None and again is None
         P.free(h)
         dist.barrier()
     finally:

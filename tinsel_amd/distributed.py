@@ -11,7 +11,9 @@ the accumulation buffer, a commutative float sum (render.cpp:439).  So
   * ONE `reduce(SUM)` to rank 0 per read-back re-assembles the frame (RCCL over xGMI with the
     "nccl" backend; "gloo" in the CPU tests).  4K: 132.7 MB, once per thousands of passes.
 
-One process per GPU; launched by torch.distributed.run.
+One process per GPU; launched by torch.distributed.run (bench.py --gpus N).  The same shard + reduce inside ONE process,
+for the reference's single-threaded C++ caller, is the C-ABI's tinsel_hip_group (include/tinsel_hip.h;
+tinsel_amd.HipRendererGroup).
 """
 import numpy as np
 
@@ -27,33 +29,14 @@ def owned_mask(width, height, rank, world, tile=32):
 
 
 def reduce_accum(accum, dst=0, group=None):
-    """Sum the per-rank accumulators into rank `dst` (in place on `dst`).  `accum`: torch tensor [H,W,4]."""
+    """The one collective of the path: the sum over ranks of the per-rank accumulators [H,W,4], returned on rank `dst`
+    (None elsewhere).  `accum` itself is left untouched on every rank -- it keeps the rank's OWN partial sums since
+    Init, so a later render + reduce_accum cannot count earlier samples twice (an in-place reduce would leave rank
+    dst holding everyone's samples, and the gloo backend also overwrites the non-dst inputs).  The price is one
+    accumulator-sized scratch tensor per call."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return accum
-    dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    return accum
-
-
-class ShardedRenderer:
-    """Renderer-shaped wrapper: `init` / `render` on this rank's shard, `gather()` = the reduce.
-
-    `renderer` is anything with set_shard / init / render_async (the HipRenderer); `make_accum(h, w)`
-    returns the torch tensor that backs the accumulator on this rank's device."""
-
-    def __init__(self, renderer, rank, world, tile=32):
-        self.renderer = renderer
-        self.rank, self.world, self.tile = rank, world, tile
-        renderer.set_shard(rank, world, tile)
-        self.accum = None
-
-    def init(self, width, height, accum):
-        self.accum = accum
-        self.renderer.init(width, height, accum_tensor=accum)
-
-    def render(self, camera, options, passes=1, stream=None):
-        self.renderer.render_async(camera, options, passes=passes, stream=stream)
-
-    def gather(self, dst=0):
-        """The one collective of the path: framebuffer sum-reduce to `dst`."""
-        return reduce_accum(self.accum, dst=dst)
+    total = accum.clone()
+    dist.reduce(total, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return total if dist.get_rank(group) == dst else None

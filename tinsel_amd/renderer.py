@@ -87,6 +87,16 @@ def load_library():
     L.tinsel_hip_stack_entries.argtypes = [vp]
     L.tinsel_hip_nee_per_path.argtypes = [vp]
     L.tinsel_hip_walked_prims.argtypes = [vp]
+    L.tinsel_hip_group_create.restype = vp
+    L.tinsel_hip_group_create.argtypes = [C.POINTER(abi.SceneDesc), ci, ci]
+    L.tinsel_hip_group_destroy.restype = None
+    L.tinsel_hip_group_destroy.argtypes = [vp]
+    L.tinsel_hip_group_init.argtypes = [vp, ci, ci]
+    L.tinsel_hip_group_render.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.Options), vp, ci]
+    L.tinsel_hip_group_present.argtypes = [vp, C.POINTER(abi.Options), ci, C.c_float, vp]
+    L.tinsel_hip_group_size.argtypes = [vp]
+    L.tinsel_hip_group_member.restype = vp
+    L.tinsel_hip_group_member.argtypes = [vp, ci]
     L.tinsel_hip_last_error.restype = C.c_char_p
     L.tinsel_pack_open.argtypes = [vp, C.c_size_t, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.Options)]
     _lib = L
@@ -102,6 +112,8 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
     "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_russian_roulette", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
     "tinsel_hip_walked_prims",
+    "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
+    "tinsel_hip_group_size", "tinsel_hip_group_member",
 ]
 
 
@@ -299,6 +311,62 @@ class HipRenderer:
     def close(self):
         if self._h:
             self._L.tinsel_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipRendererGroup:
+    """`Renderer` (render.h:66-73) over several GPUs of one node: the C-ABI's tinsel_hip_group (one host thread per
+    device inside the library, pixel-tile shards, ONE RCCL reduce of the accumulator per read-back)."""
+
+    def __init__(self, scene: Scene, num_gpus: int = 0, tile: int = 64):
+        L = load_library()
+        self._L = L
+        self._h = L.tinsel_hip_group_create(C.byref(scene.desc), num_gpus, tile)
+        if not self._h:
+            msg = L.tinsel_hip_last_error()
+            raise TinselHipError("tinsel_hip_group_create failed: %s" % (msg.decode() if msg else "?"))
+        self.width = self.height = 0
+
+    @property
+    def num_gpus(self):
+        return self._L.tinsel_hip_group_size(self._h)
+
+    def init(self, width, height):
+        _check(self._L.tinsel_hip_group_init(self._h, width, height), "tinsel_hip_group_init")
+        self.width, self.height = width, height
+
+    def render(self, camera, options, output=None, passes=1, readback=True):
+        if output is None and readback:
+            output = np.empty((options.height, options.width, 4), np.float32)
+        ptr = output.ctypes.data_as(C.c_void_p) if (readback and output is not None) else None
+        _check(self._L.tinsel_hip_group_render(self._h, C.byref(camera), C.byref(options), ptr, passes), "tinsel_hip_group_render")
+        return output
+
+    Init = init
+    Render = render
+
+    def present(self, options, nlm_width=0, nlm_falloff=200.0):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        _check(self._L.tinsel_hip_group_present(self._h, C.byref(options), int(nlm_width), float(nlm_falloff), out.ctypes.data_as(C.c_void_p)),
+               "tinsel_hip_group_present")
+        return out
+
+    def member_stats(self, rank):
+        """rays / samples counters of member `rank` (tinsel_hip_stats_detail on its renderer)."""
+        m = self._L.tinsel_hip_group_member(self._h, rank)
+        out = np.zeros(8, np.uint64)
+        _check(self._L.tinsel_hip_stats_detail(m, out.ctypes.data_as(C.c_void_p)), "tinsel_hip_stats_detail")
+        return {"rays": int(out[0]), "samples": int(out[1]), "shadow_rays": int(out[5])}
+
+    def close(self):
+        if self._h:
+            self._L.tinsel_hip_group_destroy(self._h)
             self._h = None
 
     def __del__(self):
