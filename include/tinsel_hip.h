@@ -195,6 +195,16 @@ int tinsel_hip_init_external(tinsel_hip* r, int width, int height, float* device
 int tinsel_hip_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options,
                       float* out_rgba, int passes);
 
+/* Look-ahead for callers that use tinsel_hip_render the way the reference's main loop does (main.cpp:246-250: one pass and
+ * the full-frame running sum to the host per call, 16 calls per displayed frame).  With it on, a tinsel_hip_render call
+ * returns as soon as ITS running sum has been copied out, and meanwhile the passes the next call will most probably ask
+ * for (same camera, options and pass count) are traced into a second accumulator; a matching next call only swaps
+ * buffers and copies, anything else drops the speculation.  Images are bit-identical to the plain path; the statistics
+ * counters and tinsel_hip_read_batch_radiance see one call ahead (every other entry point drops the speculation first).
+ * The caller's output array is page-locked in place (hipHostRegister) on first use.  Off by default; the C++ shim
+ * turns it on. */
+int tinsel_hip_set_lookahead(tinsel_hip* r, int enable);
+
 /* Same, but never touches host memory: enqueues `passes` passes on `stream`
  * (a hipStream_t, may be NULL for the default stream) and returns without
  * synchronising.  Used by bench.py / multi-GPU hosts that own the stream. */

@@ -55,6 +55,9 @@ struct HipRenderer : public Renderer
             fprintf(stderr, "CreateGpuRenderer: %s\n", tinsel_hip_last_error());
         else if (tinsel_hip_group_size(group) > 1)
             fprintf(stderr, "CreateGpuRenderer: %d GPUs\n", tinsel_hip_group_size(group));
+        else if (!getenv("TINSEL_HIP_NO_LOOKAHEAD"))
+            // main.cpp:246-250 calls Render() once per pass with a full-frame read-back: trace the next pass while this one is copied
+            tinsel_hip_set_lookahead(tinsel_hip_group_member(group, 0), 1);
     }
 
     virtual ~HipRenderer() { tinsel_hip_group_destroy(group); }

@@ -67,6 +67,23 @@ def test_group_of_one_is_one_renderer_bit_for_bit():
     assert np.array_equal(out, g["accum"])
 
 
+def test_one_rank_rccl_reduce_executes(monkeypatch):
+    """The RCCL arm itself on a single-GPU box: dlopen(librccl.so.1), ncclCommInitAll over one device and a 1-rank
+    ncclReduce of the accumulator into the separate `total` on the member's stream, from the member's thread
+    (TINSEL_HIP_GROUP_FORCE_RCCL: the calls a multi-GPU group makes, with one participant)."""
+    from tinsel_amd import HipRendererGroup
+    monkeypatch.delenv("TINSEL_HIP_GROUP_ONE_DEVICE", raising=False)
+    monkeypatch.setenv("TINSEL_HIP_GROUP_FORCE_RCCL", "1")
+    scene, cam, opt, g = _load("cornell")
+    grp = HipRendererGroup(scene, 1)
+    grp.init(opt.width, opt.height)
+    half = int(g["passes"])//2
+    grp.render(cam, opt, passes=half)
+    out = grp.render(cam, opt, passes=int(g["passes"]) - half)
+    grp.close()
+    assert np.array_equal(out, g["accum"])          # a sum over one rank is a copy: still bit-identical to the reference
+
+
 def test_group_refuses_more_gpus_than_visible(monkeypatch):
     import torch
     import tinsel_amd

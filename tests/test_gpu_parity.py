@@ -209,6 +209,35 @@ def test_unsupported_inputs_fail_loudly():
     r.close()
 
 
+def test_lookahead_changes_no_bit():
+    """tinsel_hip_set_lookahead: the reference's call pattern (Render = 1 pass + full read-back) with the next pass traced
+    while the image is copied out.  Every returned image must equal the plain path's, through speculation hits, a miss
+    (options change mid-stream), interleaved read-backs and an Init."""
+    from tinsel_amd import create_gpu_renderer
+    scene, cam, opt, g = _load("features")
+    plain = create_gpu_renderer(scene); plain.init(opt.width, opt.height)
+    ahead = create_gpu_renderer(scene); ahead.init(opt.width, opt.height)
+    ahead.set_lookahead(True)
+    out = np.empty((opt.height, opt.width, 4), np.float32)
+    deeper = opt.copy(); deeper.max_depth = opt.max_depth + 2
+    script = [opt, opt, opt, deeper, deeper, opt, opt]          # hits, a miss, hits, a miss, a hit
+    for k, o in enumerate(script):
+        want = plain.render(cam, o, passes=1)
+        got = ahead.render(cam, o, output=out, passes=1)
+        assert np.array_equal(got, want), "call %d" % k
+        if k == 2:
+            assert np.array_equal(ahead.read_accum(), want)     # a read-back in between sees the committed sum only
+    assert ahead.get_pass_index() == plain.get_pass_index() == len(script)
+    # two passes per call, then a new frame
+    for _ in range(3):
+        want = plain.render(cam, opt, passes=2)
+        got = ahead.render(cam, opt, output=out, passes=2)
+        assert np.array_equal(got, want)
+    plain.init(opt.width, opt.height); ahead.init(opt.width, opt.height)
+    assert np.array_equal(ahead.render(cam, opt, output=out, passes=1), plain.render(cam, opt, passes=1))
+    plain.close(); ahead.close()
+
+
 def test_malformed_bvhs_are_refused():
     """tinsel_hip_create walks the trees it is handed: a leaf that indexes past the items, a child past the nodes and a
     cycle must be refused with a message, not walked (host out-of-bounds reads, an endless DFS, device OOB reads)."""

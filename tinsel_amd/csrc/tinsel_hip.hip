@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <cstdio>
@@ -360,6 +361,22 @@ struct tinsel_hip
     Rng seedRng = Rng::seeded(1u);      // Random(1) advanced seedRngIndex times: the generator of the pass seeds
     uint32_t seedRngIndex = 0;
     int shardRank = 0, shardWorld = 1, shardTile = 32;
+
+    // look-ahead (tinsel_hip_set_lookahead): the NEXT call's passes are traced speculatively into accumSpec while this
+    // call's running sum travels to the host
+    bool lookahead = false;
+    FrameParams lastFp;                 // of the most recent batch (its paths' radiance is still in ps.rad)
+    struct SpecShot { float4* buf; hipEvent_t ready; };
+    std::vector<float4*> specFree;      // accumulator-sized buffers not in use
+    std::deque<SpecShot> specQueue;     // specQueue[j] = accum + the passes of the next j+1 calls, in flight or finished on workStream
+    uint32_t specNextPass = 0;          // pass index the next speculated call starts at
+    tinsel_camera specCamera;
+    tinsel_options specOptions;
+    int specPasses = 0;
+    int lookaheadDepth = 0;             // calls per speculated batch; 0 = chosen from the batch capacity (TINSEL_HIP_LOOKAHEAD_DEPTH)
+    hipStream_t workStream = nullptr, copyStream = nullptr;
+    void* pinnedPtr = nullptr;          // caller's output buffer, page-locked in place (hipHostRegister) for the D2H DMA
+    size_t pinnedBytes = 0;
 
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -741,7 +758,36 @@ size_t slots_per_pass(const tinsel_hip* r, int width, int height, int* tilesXOut
     return std::max<size_t>(1, (size_t)owned*r->shardTile*r->shardTile);
 }
 
-int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp)
+// The accumulate stage of a traced batch: adds the batch passes [fp.accBegin, fp.accEnd) to `target`.
+int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, float4* target)
+{
+    const size_t npix = (size_t)fp.width*fp.height;
+    ScopedTimer t(r, KN_ACCUMULATE, st);
+    const int halo = 1 + (int)floorf(fp.filterWidth) + (int)ceilf(fp.filterWidth);
+    if (halo <= kAccMaxHalo && fp.filterWidth >= 0.0f && fp.width < 65536 && fp.height < 65536)
+    {
+        int tiles = ((fp.width + kAccTile - 1)/kAccTile)*((fp.height + kAccTile - 1)/kAccTile);
+        const int* tileList = nullptr;
+        if (fp.shardWorld > 1)
+        {
+            if (accumulate_tile_list(r, fp))
+                return -1;
+            tileList = r->accTilesDev;
+            tiles = r->accTilesCount;
+        }
+        if (tiles > 0)
+            hipLaunchKernelGGL(k_accumulate_tiled, dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev, tileList);
+    }
+    else
+    {
+        const int gridPix = (int)((npix + kBlock - 1)/kBlock);
+        hipLaunchKernelGGL(k_accumulate, dim3(gridPix), dim3(kBlock), 0, st, r->ps, fp, target);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp, bool accumulate = true)
 {
     const size_t npix = (size_t)fp.width*fp.height;
     // path slots of this shard per pass and per batch (slot_pixel / slot_of, tn_kernels.h): rank-local numbering
@@ -751,6 +797,8 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         return fail("render: batch too large");
     fp.shardPerPass = (uint32_t)perPass;
     fp.genCount = (uint32_t)slots;
+    fp.accBegin = 0;
+    fp.accEnd = fp.numPasses;
     fp.rrStart = r->rrStart;
     fp.queueCapacity = (uint32_t)r->batchSlots;
     const int gridFlat = (int)std::max<size_t>(1, (slots + kBlock - 1)/kBlock);
@@ -822,34 +870,15 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         }
     }
 
-    {
-        ScopedTimer t(r, KN_ACCUMULATE, st);
-        const int halo = 1 + (int)floorf(fp.filterWidth) + (int)ceilf(fp.filterWidth);
-        if (halo <= kAccMaxHalo && fp.filterWidth >= 0.0f && fp.width < 65536 && fp.height < 65536)
-        {
-            int tiles = ((fp.width + kAccTile - 1)/kAccTile)*((fp.height + kAccTile - 1)/kAccTile);
-            const int* tileList = nullptr;
-            if (fp.shardWorld > 1)
-            {
-                if (accumulate_tile_list(r, fp))
-                    return -1;
-                tileList = r->accTilesDev;
-                tiles = r->accTilesCount;
-            }
-            if (tiles > 0)
-                hipLaunchKernelGGL(k_accumulate_tiled, dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, r->accum, r->passSeedsDev, tileList);
-        }
-        else
-        {
-            const int gridPix = (int)((npix + kBlock - 1)/kBlock);
-            hipLaunchKernelGGL(k_accumulate, dim3(gridPix), dim3(kBlock), 0, st, r->ps, fp, r->accum);
-        }
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    r->lastFp = fp;
+    if (!accumulate)
+        return 0;
+    return launch_accumulate(r, st, fp, r->accum);
 }
 
-int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, int passes, hipStream_t st)
+// traceOnly: the passes must fit ONE batch; their paths are traced (radiance left in ps.rad, r->lastFp set) but not
+// accumulated -- the caller adds them pass range by pass range (launch_accumulate) into buffers of its choice (look-ahead).
+int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, int passes, hipStream_t st, bool traceOnly = false)
 {
     if (!r || !camera || !options)
         return fail("render: null argument");
@@ -931,14 +960,158 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
     if (ensure_batch(r, perPass*(size_t)perBatch, fp.maxDepth))
         return -1;
 
+    if (traceOnly && perBatch < passes)
+        return fail("render: look-ahead batch does not fit");
     for (int done = 0; done < passes; done += perBatch)
     {
         fp.passBase = done;
         fp.numPasses = std::min(perBatch, passes - done);
-        if (render_batch(r, st, cam, fp))
+        if (render_batch(r, st, cam, fp, !traceOnly))
             return -1;
     }
     r->passIndex += (uint32_t)passes;
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------
+// Look-ahead for the reference's call pattern (main.cpp:246-250: Render() = ONE pass + the full-frame running sum to
+// the host, 16 times per displayed frame, render.cu:1099-1102).  A call cannot return before its own pass has been
+// copied out, and the copy cannot start before the pass is done -- inside one call there is nothing to overlap.  Across
+// calls there is: while call k's image crosses PCIe, the passes call k+1 will most probably ask for (same camera, same
+// options: the caller's loop) are already being traced into a SECOND accumulator, accumSpec = accum + those passes.  If
+// the next call matches, the buffers swap and only the copy is left to do; if it does not (or any other entry point
+// intervenes), the speculation is dropped -- accum itself was never touched by it.  Results are bit-identical to the
+// plain path (same seeds, same adds in the same order); only the statistics counters run one call ahead.
+
+void lookahead_cancel(tinsel_hip* r)
+{
+    if (!r || r->specQueue.empty())
+        return;
+    (void)hipSetDevice(r->device);
+    (void)hipStreamSynchronize(r->workStream);
+    for (tinsel_hip::SpecShot& shot : r->specQueue)
+    {
+        r->specFree.push_back(shot.buf);
+        r->eventPool.push_back(shot.ready);
+    }
+    r->specQueue.clear();
+}
+
+void lookahead_release(tinsel_hip* r)
+{
+    lookahead_cancel(r);
+    for (float4* b : r->specFree)
+        (void)hipFree(b);
+    r->specFree.clear();
+    if (r->pinnedPtr) { (void)hipHostUnregister(r->pinnedPtr); r->pinnedPtr = nullptr; r->pinnedBytes = 0; }
+}
+
+// Speculate `depth` more calls: ONE batch of depth x passes passes is traced (as efficient as the resident path's batches),
+// then each call's passes are added to a buffer of their own, chained: shot j = shot j-1 + call j's passes.
+int lookahead_extend(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, int passes, int depth)
+{
+    const size_t bytes = sizeof(float4)*(size_t)r->width*r->height;
+    const uint32_t committed = r->passIndex;
+    r->passIndex = r->specNextPass;
+    const int rc = render_impl(r, camera, options, passes*depth, r->workStream, true);
+    r->passIndex = committed;
+    if (rc)
+        return -1;
+    const float4* src = r->specQueue.empty() ? r->accum : r->specQueue.back().buf;
+    for (int j = 0; j < depth; ++j)
+    {
+        float4* dst = nullptr;
+        if (!r->specFree.empty())
+        {
+            dst = r->specFree.back();
+            r->specFree.pop_back();
+        }
+        else
+            HIP_TRY(hipMalloc((void**)&dst, bytes));
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, r->workStream));
+        FrameParams fp = r->lastFp;
+        fp.accBegin = j*passes;
+        fp.accEnd = (j + 1)*passes;
+        if (launch_accumulate(r, r->workStream, fp, dst))
+            return -1;
+        tinsel_hip::SpecShot shot = { dst, get_event(r) };
+        HIP_TRY(hipEventRecord(shot.ready, r->workStream));
+        r->specQueue.push_back(shot);
+        src = dst;
+    }
+    r->specNextPass += (uint32_t)(passes*depth);
+    return 0;
+}
+
+int lookahead_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, float* out_rgba, int passes)
+{
+    HIP_TRY(hipSetDevice(r->device));
+    const size_t bytes = sizeof(float4)*(size_t)r->width*r->height;
+    if (!r->workStream)
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&r->workStream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&r->copyStream, hipStreamNonBlocking));
+    }
+
+    // 1. this call's passes: already traced (the front of the speculation queue) or traced now
+    const bool hit = !r->specQueue.empty() && passes == r->specPasses && memcmp(camera, &r->specCamera, sizeof(*camera)) == 0 &&
+                     memcmp(options, &r->specOptions, sizeof(*options)) == 0;
+    if (hit)
+    {
+        tinsel_hip::SpecShot shot = r->specQueue.front();
+        r->specQueue.pop_front();
+        HIP_TRY(hipEventSynchronize(shot.ready));
+        r->eventPool.push_back(shot.ready);
+        r->specFree.push_back(r->accum);        // the previous running sum: copied out by the previous call, copied from by this shot
+        r->accum = shot.buf;
+        r->passIndex += (uint32_t)passes;
+    }
+    else
+    {
+        lookahead_cancel(r);
+        if (render_impl(r, camera, options, passes, r->workStream))
+            return -1;
+        HIP_TRY(hipStreamSynchronize(r->workStream));
+        r->specNextPass = r->passIndex;
+    }
+
+    // 2. the running sum starts towards the host (page-locked in place once: the caller hands the same array every call)
+    if (r->pinnedPtr != (void*)out_rgba || r->pinnedBytes != bytes)
+    {
+        if (r->pinnedPtr)
+            (void)hipHostUnregister(r->pinnedPtr);
+        r->pinnedPtr = nullptr;
+        r->pinnedBytes = 0;
+        if (hipHostRegister(out_rgba, bytes, hipHostRegisterDefault) == hipSuccess)
+        {
+            r->pinnedPtr = out_rgba;
+            r->pinnedBytes = bytes;
+        }
+        else
+            (void)hipGetLastError();        // pageable copy below: still correct
+    }
+    HIP_TRY(hipMemcpyAsync(out_rgba, r->accum, bytes, hipMemcpyDeviceToHost, r->copyStream));
+
+    // 3. meanwhile keep the speculation queue between `depth` and 2 x depth calls deep: a batch of `depth` calls is traced
+    //    while the previous batch's running sums are being copied out one call at a time
+    if (options->mode == TINSEL_MODE_PATHTRACE && options->max_depth >= 1)
+    {
+        const size_t perPass = slots_per_pass(r, r->width, r->height);
+        const int fit = (int)std::max<size_t>(1, batch_slots(r)/(perPass*(size_t)passes));
+        // half a batch per speculation (two are in flight), at most 16 calls: 4 at 1024^2, 16 for the small interactive frames
+        const int depth = r->lookaheadDepth > 0 ? std::max(1, std::min(r->lookaheadDepth, fit)) : std::max(1, std::min(16, fit/2));
+        if ((int)r->specQueue.size() <= depth && batch_slots(r) >= perPass*(size_t)passes)
+        {
+            r->specCamera = *camera;
+            r->specOptions = *options;
+            r->specPasses = passes;
+            if (lookahead_extend(r, camera, options, passes, depth))
+                lookahead_cancel(r);            // could not speculate: the plain path still works
+        }
+    }
+
+    HIP_TRY(hipStreamSynchronize(r->copyStream));
     return 0;
 }
 
@@ -1446,7 +1619,10 @@ void tinsel_hip_destroy(tinsel_hip* r)
     if (!r)
         return;
     (void)hipSetDevice(r->device);
+    lookahead_release(r);
     (void)hipDeviceSynchronize();
+    if (r->workStream) (void)hipStreamDestroy(r->workStream);
+    if (r->copyStream) (void)hipStreamDestroy(r->copyStream);
     if (r->walkProf)
     {
         unsigned long long wp[16] = { 0 };
@@ -1482,6 +1658,8 @@ void tinsel_hip_destroy(tinsel_hip* r)
 
 int tinsel_hip_init(tinsel_hip* r, int width, int height)
 {
+    if (r)
+        lookahead_release(r);
     if (!r || width <= 0 || height <= 0)
         return fail("init: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
@@ -1499,6 +1677,8 @@ int tinsel_hip_init(tinsel_hip* r, int width, int height)
 
 int tinsel_hip_init_external(tinsel_hip* r, int width, int height, float* device_accum)
 {
+    if (r)
+        lookahead_release(r);
     if (!r || width <= 0 || height <= 0 || !device_accum)
         return fail("init_external: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
@@ -1515,11 +1695,28 @@ int tinsel_hip_init_external(tinsel_hip* r, int width, int height, float* device
 
 int tinsel_hip_render_async(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, int passes, void* stream)
 {
+    lookahead_cancel(r);
     return render_impl(r, camera, options, passes, (hipStream_t)stream);
+}
+
+int tinsel_hip_set_lookahead(tinsel_hip* r, int enable)
+{
+    if (!r)
+        return fail("set_lookahead: null");
+    if (!enable)
+        lookahead_cancel(r);
+    r->lookahead = enable != 0;
+    if (const char* e = getenv("TINSEL_HIP_LOOKAHEAD_DEPTH"))
+        r->lookaheadDepth = std::max(0, atoi(e));
+    return 0;
 }
 
 int tinsel_hip_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, float* out_rgba, int passes)
 {
+    if (r && r->lookahead && out_rgba && camera && options && r->accum && r->accumOwned && passes >= 1 &&
+        options->width == r->width && options->height == r->height)
+        return lookahead_render(r, camera, options, out_rgba, passes);
+    lookahead_cancel(r);
     if (render_impl(r, camera, options, passes, nullptr))
         return -1;
     if (out_rgba)
@@ -1633,6 +1830,7 @@ int tinsel_image_quantize_rgb8(const float* rgba, int width, int height, unsigne
 
 int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
 {
+    lookahead_cancel(r);
     if (!r || (mode != TINSEL_BVH_REFERENCE && mode != TINSEL_BVH_LBVH))
         return fail("set_mesh_bvh: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
@@ -1692,6 +1890,7 @@ int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
 
 int tinsel_hip_set_russian_roulette(tinsel_hip* r, int start_bounce)
 {
+    lookahead_cancel(r);
     if (!r || start_bounce < 0)
         return fail("set_russian_roulette: bad arguments");
     r->rrStart = start_bounce;
@@ -1700,6 +1899,7 @@ int tinsel_hip_set_russian_roulette(tinsel_hip* r, int start_bounce)
 
 int tinsel_hip_write_accum(tinsel_hip* r, const float* rgba, uint32_t next_pass_index)
 {
+    lookahead_cancel(r);
     if (!r || !r->accum || !rgba)
         return fail("write_accum: bad arguments (Init first)");
     HIP_TRY(hipSetDevice(r->device));
@@ -1711,6 +1911,7 @@ int tinsel_hip_write_accum(tinsel_hip* r, const float* rgba, uint32_t next_pass_
 
 int tinsel_hip_set_shard(tinsel_hip* r, int rank, int world, int tile)
 {
+    lookahead_cancel(r);
     if (!r || world < 1 || rank < 0 || rank >= world || tile < 1)
         return fail("set_shard: bad arguments");
     if (rank != r->shardRank || world != r->shardWorld || tile != r->shardTile)
@@ -1727,6 +1928,7 @@ int tinsel_hip_set_shard(tinsel_hip* r, int rank, int world, int tile)
 
 int tinsel_hip_set_pipeline(tinsel_hip* r, int pipeline)
 {
+    lookahead_cancel(r);
     if (!r || pipeline < TINSEL_PIPELINE_WAVEFRONT || pipeline > TINSEL_PIPELINE_AUTO)
         return fail("set_pipeline: bad arguments");
     r->pipeline = pipeline;
@@ -1735,6 +1937,7 @@ int tinsel_hip_set_pipeline(tinsel_hip* r, int pipeline)
 
 int tinsel_hip_set_pass_index(tinsel_hip* r, uint32_t pass_index)
 {
+    lookahead_cancel(r);
     if (!r)
         return fail("set_pass_index: null");
     r->passIndex = pass_index;
@@ -1778,6 +1981,7 @@ int tinsel_hip_stats_detail(tinsel_hip* r, unsigned long long* out8)
 
 int tinsel_hip_set_detail_counters(tinsel_hip* r, int enable)
 {
+    lookahead_cancel(r);
     if (!r)
         return fail("set_detail_counters: null");
     r->countDetail = enable != 0;
@@ -1786,6 +1990,7 @@ int tinsel_hip_set_detail_counters(tinsel_hip* r, int enable)
 
 void tinsel_hip_reset_stats(tinsel_hip* r)
 {
+    lookahead_cancel(r);
     if (!r)
         return;
     (void)hipSetDevice(r->device);
@@ -1796,6 +2001,7 @@ void tinsel_hip_reset_stats(tinsel_hip* r)
 
 int tinsel_hip_enable_kernel_timing(tinsel_hip* r, int enable)
 {
+    lookahead_cancel(r);
     if (!r)
         return fail("enable_kernel_timing: null");
     r->timing = enable != 0;
@@ -1804,6 +2010,7 @@ int tinsel_hip_enable_kernel_timing(tinsel_hip* r, int enable)
 
 int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entries)
 {
+    lookahead_cancel(r);
     if (!r || !out)
         return fail("kernel_times: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
@@ -1838,6 +2045,7 @@ int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entr
 
 int tinsel_hip_reserve(tinsel_hip* r, int passes, int max_depth)
 {
+    lookahead_cancel(r);
     if (!r || !r->accum || passes < 1 || max_depth < 1)
         return fail("reserve: bad arguments (Init first)");
     HIP_TRY(hipSetDevice(r->device));
@@ -1850,6 +2058,7 @@ int tinsel_hip_reserve(tinsel_hip* r, int passes, int max_depth)
 
 int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths)
 {
+    lookahead_cancel(r);
     if (!r || max_paths < 1024)
         return fail("set_batch_paths: bad arguments");
     r->maxBatchSlots = (size_t)max_paths;
@@ -1859,6 +2068,7 @@ int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths)
 
 long long tinsel_hip_read_batch_radiance(tinsel_hip* r, float* out_rgbx, unsigned long long max_paths)
 {
+    lookahead_cancel(r);
     if (!r || !out_rgbx)
         return fail("read_batch_radiance: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
@@ -1872,6 +2082,7 @@ long long tinsel_hip_read_batch_radiance(tinsel_hip* r, float* out_rgbx, unsigne
 int tinsel_hip_leaf(tinsel_hip* r, int op, int index, int n, const float* in, int in_stride, const uint32_t* seeds,
                     float* out, int out_stride, const tinsel_camera* camera, int width, int height)
 {
+    lookahead_cancel(r);
     if (!r || n <= 0 || !out || out_stride <= 0 || op < 0 || op > kLeafDisplay)
         return fail("leaf: bad arguments");
     if ((op == kLeafBsdfEval || op == kLeafBsdfSample || op == kLeafPrimIntersect || op == kLeafPrimSample) &&
@@ -2075,6 +2286,7 @@ struct tinsel_hip_group
 {
     std::vector<GroupMember> members;
     bool oneDevice = false;         // validation: all members on device 0, device-local sum instead of RCCL
+    bool solo = true;               // one member used directly: no threads, no reduce, total aliases its accumulator
     int width = 0, height = 0;
     float4* total = nullptr;        // on member 0's device; == member 0's accumulator when there is one member
 
@@ -2162,7 +2374,7 @@ int group_run(tinsel_hip_group* g, int job)
 int group_reduce(tinsel_hip_group* g)
 {
     const size_t n = g->members.size();
-    if (n == 1)
+    if (g->solo)
         return 0;                       // total IS member 0's accumulator
     if (!g->oneDevice)
         return group_run(g, GJ_REDUCE);
@@ -2204,7 +2416,7 @@ void tinsel_hip_group_destroy(tinsel_hip_group* g)
         if (m.stream)
             (void)hipStreamDestroy(m.stream);
     }
-    if (g->total && g->members.size() > 1)
+    if (g->total && !g->solo)
     {
         (void)hipSetDevice(g->members[0].device);
         (void)hipFree(g->total);
@@ -2238,8 +2450,12 @@ tinsel_hip_group* tinsel_hip_group_create(const tinsel_scene_desc* scene, int nu
     if (tile <= 0)
         tile = 64;
 
+    // TINSEL_HIP_GROUP_FORCE_RCCL=1: a ONE-member group also takes the threaded path and a 1-rank ncclReduce -- the only
+    // way to execute the RCCL calls (dlopen, communicator, reduce into `total` on the member's stream) on a single-GPU box
+    const bool forceRccl = getenv("TINSEL_HIP_GROUP_FORCE_RCCL") && atoi(getenv("TINSEL_HIP_GROUP_FORCE_RCCL")) != 0 && !oneDevice;
     tinsel_hip_group* g = new tinsel_hip_group();
     g->oneDevice = oneDevice && n > 1;
+    g->solo = n == 1 && !forceRccl;
     g->members.resize((size_t)n);
     for (int k = 0; k < n; ++k)
     {
@@ -2255,7 +2471,7 @@ tinsel_hip_group* tinsel_hip_group_create(const tinsel_scene_desc* scene, int nu
             return nullptr;
         }
     }
-    if (n > 1 && !g->oneDevice)
+    if (!g->solo && !g->oneDevice)
     {
         std::vector<int> devs((size_t)n);
         std::vector<ncclComm_t> comms((size_t)n);
@@ -2277,7 +2493,7 @@ tinsel_hip_group* tinsel_hip_group_create(const tinsel_scene_desc* scene, int nu
         for (int k = 0; k < n; ++k)
             g->members[(size_t)k].comm = comms[(size_t)k];
     }
-    if (n > 1)
+    if (!g->solo)
         for (int k = 0; k < n; ++k)
             g->members[(size_t)k].thread = std::thread(group_worker, g, k);
     return g;
@@ -2289,7 +2505,7 @@ int tinsel_hip_group_init(tinsel_hip_group* g, int width, int height)
         return fail("group_init: bad arguments");
     g->width = width;
     g->height = height;
-    if (g->members.size() == 1)
+    if (g->solo)
     {
         if (tinsel_hip_init(g->members[0].r, width, height))
             return -1;
@@ -2313,7 +2529,7 @@ int tinsel_hip_group_render(tinsel_hip_group* g, const tinsel_camera* camera, co
         return fail("group_render: null argument");
     if (!g->total)
         return fail("group_render: Init first");
-    if (g->members.size() == 1)
+    if (g->solo)
         return tinsel_hip_render(g->members[0].r, camera, options, out_rgba, passes);
     g->camera = *camera;
     g->options = *options;
@@ -2334,7 +2550,7 @@ int tinsel_hip_group_present(tinsel_hip_group* g, const tinsel_options* options,
     if (!g || !g->total || !options)
         return fail("group_present: bad arguments (Init and Render first)");
     tinsel_hip* r0 = g->members[0].r;
-    if (g->members.size() == 1)
+    if (g->solo)
         return tinsel_hip_present(r0, options, nlm_width, nlm_falloff, out_rgba);
     if (group_reduce(g))
         return -1;

@@ -77,6 +77,7 @@ struct FrameParams
     int width, height;
     int passBase;           // first pass of this batch (index into passSeeds)
     int numPasses;          // passes in this batch
+    int accBegin, accEnd;   // the batch passes [accBegin, accEnd) the accumulate kernels add (all of them, or one call's worth: look-ahead)
     int maxDepth;
     int shardRank, shardWorld, shardTile;
     int shardTilesX, shardOwnedTiles;   // tiles per frame row; tiles this shard owns (t % world == rank)
@@ -1074,7 +1075,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FramePar
 
     float4 acc = accum[pix];
 
-    for (int s = 0; s < fp.numPasses; ++s)
+    for (int s = fp.accBegin; s < fp.accEnd; ++s)
     {
         for (int j = j0; j <= j1; ++j)
         {
@@ -1177,14 +1178,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
         entLive[k] = e < side*side && entGx[k] >= 0 && entGy[k] >= 0 && entGx[k] < fp.width && entGy[k] < fp.height &&
                      pixel_owned(fp, entGx[k], entGy[k]);
         nextRa[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (entLive[k] && fp.numPasses > 0)
-            nextRa[k] = ps.rad[slot_of(fp, 0, entGx[k], entGy[k])];
+        if (entLive[k] && fp.accBegin < fp.accEnd)
+            nextRa[k] = ps.rad[slot_of(fp, fp.accBegin, entGx[k], entGy[k])];
     }
 
-    for (int s = 0; s < fp.numPasses; ++s)
+    for (int s = fp.accBegin; s < fp.accEnd; ++s)
     {
         float4 curRa[2] = { nextRa[0], nextRa[1] };
-        if (s + 1 < fp.numPasses)
+        if (s + 1 < fp.accEnd)
             for (int k = 0; k < 2; ++k)
                 if (entLive[k])
                     nextRa[k] = ps.rad[slot_of(fp, s + 1, entGx[k], entGy[k])];
