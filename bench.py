@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--tile", type=int, default=64, help="pixel-tile edge of the multi-GPU shard")
     ap.add_argument("--no-second-config", action="store_true", help="skip BASELINE config 3 (the 524k-triangle mesh)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (traffic / VALU counts become null)")
+    ap.add_argument("--no-fast", action="store_true", help="skip the opt-in tolerance-arithmetic leg (fast_msamples_s / fast_l2)")
+    ap.add_argument("--arith", choices=["exact", "fast"], default="exact", help="arithmetic arm of the TIMED run (default: the bit-exact parity path)")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)      # the child process the PMC passes profile
     return ap.parse_args()
 
@@ -207,6 +209,8 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     if args.roulette > 0:
         r.set_russian_roulette(args.roulette)
     r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
+    if args.arith == "fast":
+        r.set_arithmetic(abi.ARITH_FAST)
     if world > 1:
         r.set_shard(rank, world, args.tile)     # path slots are rank-local: the same batch size as N = 1 holds the same number of live paths
     accum = torch.zeros((opt.height, opt.width, 4), dtype=torch.float32, device="cuda")
@@ -343,6 +347,44 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         api_1pass = calls*opt.width*opt.height/(t3 - t2)/1e6
         ra.close()
 
+    # ---- the opt-in tolerance-arithmetic arm (tinsel_hip_set_arithmetic): rate and distance, N = 1 only ---------
+    fast = None
+    if world == 1 and not args.no_fast and args.arith == "exact":
+        try:
+            spp = 256
+            rf = tinsel_amd.create_gpu_renderer(scene, local)
+            rf.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
+            rf.init(opt.width, opt.height)
+            rf.reserve(max(spp, args.steps), opt.max_depth)
+            exact_img = rf.render(cam, opt, passes=spp)
+            rf.set_arithmetic(abi.ARITH_FAST)
+            rf.init(opt.width, opt.height)
+            rf.set_pass_index(0)
+            fast_img = rf.render(cam, opt, passes=spp)
+            wa = np.where(exact_img[..., 3:4] > 0, exact_img[..., 3:4], 1.0)
+            wb = np.where(fast_img[..., 3:4] > 0, fast_img[..., 3:4], 1.0)
+            dd = (exact_img[..., :3]/wa - fast_img[..., :3]/wb).astype(np.float64)
+            l2 = float(np.sqrt(np.mean(np.sum(dd*dd, axis=-1))))
+            # one pass, path by path: how many paths left the exact path's track (radiance off by > 1e-3 relative)
+            rf.set_pass_index(0); rf.render(cam, opt, passes=1, readback=False); rad_f = rf.batch_radiance(1, opt.height, opt.width)
+            rf.set_arithmetic(abi.ARITH_EXACT)
+            rf.set_pass_index(0); rf.render(cam, opt, passes=1, readback=False); rad_e = rf.batch_radiance(1, opt.height, opt.width)
+            rel = np.abs(rad_f - rad_e).max(axis=-1)/np.maximum(1e-3, np.abs(rad_e).max(axis=-1))
+            rf.set_arithmetic(abi.ARITH_FAST)
+            fblocks, ftotal = [], 0.0
+            rf.render(cam, opt, passes=max(1, args.warmup), readback=False)
+            while ftotal < 0.25 and len(fblocks) < 1000:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rf.render(cam, opt, passes=args.steps, readback=False)
+                fblocks.append(time.perf_counter() - t0)
+                ftotal += fblocks[-1]
+            rf.close()
+            fast = {"msamples_s": args.steps*opt.width*opt.height/statistics.median(fblocks)/1e6, "l2_vs_exact_at_spp": [l2, spp],
+                    "divergent_paths_fraction": float((rel > 1e-3).mean()), "identical_paths_fraction": float((rad_f == rad_e).all(axis=-1).mean())}
+        except Exception as e:
+            fast = {"msamples_s": None, "error": str(e)}
+
     # ---- roofline of the dominant kernel ----------------------------------------------------------
     gpu_ms = sum(v[1] for v in ktimes.values())
     trace_kernels = ("k_walk", "k_extend", "k_shadow", "k_mega", "k_bounce")
@@ -429,6 +471,10 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         "pcie_inclusive_msamples_s": pcie,
         "api_1pass_msamples_s": api_1pass,
         "api_1pass_plain_msamples_s": api_1pass_plain,
+        "arithmetic": args.arith,
+        "fast_msamples_s": fast["msamples_s"] if fast else None,
+        "fast_l2": fast["l2_vs_exact_at_spp"][0] if (fast and fast.get("l2_vs_exact_at_spp")) else None,
+        "fast": fast,
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
@@ -489,7 +535,7 @@ def main():
             if k not in line:
                 line[k] = v
         if second is not None:
-            line["configs"] = [{k: head[k] for k in ("metric", "value", "unit", "ms_per_step", "mrays_per_s", "config", "roofline", "cpu_baseline", "timed_blocks")}, second]
+            line["configs"] = [{k: head[k] for k in ("metric", "value", "unit", "ms_per_step", "mrays_per_s", "config", "roofline", "cpu_baseline", "timed_blocks", "fast_msamples_s", "fast_l2")}, second]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -267,6 +267,18 @@ int tinsel_hip_set_shard(tinsel_hip* r, int rank, int world, int tile);
 
 int tinsel_hip_set_pipeline(tinsel_hip* r, int pipeline);
 
+/* Arithmetic contract of the path kernels.
+ * TINSEL_ARITH_EXACT (default, the parity path): no FMA contraction, IEEE divide / sqrt, glibc 2.35's sinf / cosf / expf
+ *   restated -- every path bit-identical to the reference's CPU PathTrace on the same seeds.
+ * TINSEL_ARITH_FAST (opt-in): the same kernels built the way the reference builds itself (`-O3 -ffast-math`, makefile:4;
+ *   `-use_fast_math -prec-div=false -prec-sqrt=false`, tinsel.vcxproj:134): FMA contraction, v_rcp / v_rsq / v_sqrt,
+ *   the hardware's sin / cos / exp.  Same seeds, same RNG streams; paths agree to rounding until a branch flips, and the
+ *   image stays within the stated 1e-3 per-pixel L2 of the CPU reference at the spp the BASELINE configs use (measured by
+ *   tests/test_gpu_fast.py and reported by bench.py as fast_l2).  Not bit-reproducible against the reference. */
+enum { TINSEL_ARITH_EXACT = 0, TINSEL_ARITH_FAST = 1 };
+int tinsel_hip_set_arithmetic(tinsel_hip* r, int mode);
+int tinsel_hip_get_arithmetic(tinsel_hip* r);
+
 /* The per-pass seed is the (pass_index+1)-th output of Random(1).Rand()
  * (mirrors `seed = Random(frame)` / `seed.Rand()`, render.cu:1050-1052,1099).
  * A new renderer starts at pass 0; Init does not reset it (nor does the reference). */

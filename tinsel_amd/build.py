@@ -1,9 +1,13 @@
 """Builds tinsel_amd/libtinsel_hip.so (the C-ABI of include/tinsel_hip.h) with hipcc for gfx950.
 
-The library is built IN-TREE so that it travels with the repository snapshot to the GPU box.
-Flags that are part of the numerical contract (DESIGN.md "Arithmetic"):
-  -ffp-contract=off   no FMA contraction: every fp32 op rounds once, like the CPU oracle's
-  (no -ffast-math)    IEEE division / sqrt, ocml sinf/cosf/expf/logf/acosf/atan2f
+The library is built IN-TREE so that it travels with the repository snapshot to the GPU box.  Two translation units,
+two floating-point contracts (tn_launch.h):
+  csrc/tinsel_hip.hip    host side + every kernel under the PARITY contract (DESIGN.md "Arithmetic"):
+      -ffp-contract=off   no FMA contraction: every fp32 op rounds once, like the CPU oracle's
+      (no -ffast-math)    IEEE division / sqrt; sinf/cosf/expf/acosf/atan2f restate glibc 2.35's algorithms
+  csrc/tinsel_fast.hip   the path kernels again under the opt-in TOLERANCE contract (tinsel_hip_set_arithmetic):
+      -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -freciprocal-math -fgpu-flush-denormals-to-zero
+      (never -ffinite-math-only: the traversal relies on 1/0 = inf like the reference)
 """
 import os
 import shutil
@@ -13,15 +17,19 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "tinsel_hip.hip")
+SRC_FAST = os.path.join(HERE, "csrc", "tinsel_fast.hip")
 OUT = os.path.join(HERE, "libtinsel_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))] + \
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
+DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if not f.startswith("_")] + \
        [os.path.join(ROOT, "include", "tinsel_hip.h")]
 
-HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-    "-ffp-contract=off", "-fno-fast-math",
+COMMON_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
 ]
+HIPCC_FLAGS = COMMON_FLAGS + ["-ffp-contract=off", "-fno-fast-math"]
+FAST_FLAGS = COMMON_FLAGS + ["-DTN_FAST=1", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math",
+                             "-fgpu-flush-denormals-to-zero", "-DTN_WAVES_BOUNCE=3"]
 
 
 def hipcc():
@@ -41,10 +49,24 @@ def up_to_date():
 def build(force=False, verbose=True, extra=()):
     if not force and up_to_date():
         return OUT
-    cmd = [hipcc()] + HIPCC_FLAGS + list(extra) + ["-o", OUT, SRC]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cc = hipcc()
+    jobs = [
+        [cc] + HIPCC_FLAGS + list(extra) + ["-c", SRC, "-o", os.path.join(OBJ_DIR, "tinsel_hip.o")],
+        [cc] + FAST_FLAGS + list(extra) + ["-c", SRC_FAST, "-o", os.path.join(OBJ_DIR, "tinsel_fast.o")],
+    ]
+    procs = []
+    for cmd in jobs:                    # the two translation units compile side by side
+        if verbose:
+            print("[tinsel_amd.build]", " ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
+    for p, cmd in zip(procs, jobs):
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", OUT, os.path.join(OBJ_DIR, "tinsel_hip.o"), os.path.join(OBJ_DIR, "tinsel_fast.o")]
     if verbose:
-        print("[tinsel_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        print("[tinsel_amd.build]", " ".join(link), flush=True)
+    subprocess.run(link, check=True)
     return OUT
 
 

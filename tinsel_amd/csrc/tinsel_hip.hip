@@ -6,7 +6,7 @@
 
 #include "../../include/tinsel_hip.h"
 
-#include "tn_kernels.h"
+#include "tn_launch.h"
 #include "tn_lbvh.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -355,6 +355,8 @@ struct tinsel_hip
     size_t maxBatchSlots = 8u << 20;
     bool batchSlotsExplicit = false;     // set by TINSEL_HIP_BATCH_PATHS / tinsel_hip_set_batch_paths
     int pipeline = TINSEL_PIPELINE_AUTO;
+    int arith = TINSEL_ARITH_EXACT;     // which build of the path kernels runs (tinsel_hip_set_arithmetic)
+    bool pathKernelsPrepared = false;
     bool countDetail = false;
 
     uint32_t passIndex = 0;
@@ -548,49 +550,68 @@ int pick_stack(int need)
 
 size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes; }
 
-// kernel variant selection: COUNT (detail counters on) x LDS (whole scene staged into LDS, compile-time ds_read)
-#define TN_DISPATCH2(KERNEL, COUNTV, LDSV, ...)                                                   \
-    do {                                                                                           \
-        if (COUNTV) { if (LDSV) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__);            \
-                      else hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__); }              \
-        else        { if (LDSV) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__);           \
-                      else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); }             \
-    } while (0)
+// The path kernels exist twice (tn_launch.h): this translation unit's, bit-identical to the CPU oracle, and
+// tinsel_fast.hip's, built under the tolerance contract.  tinsel_hip_set_arithmetic picks the arm.
+extern "C" void tinsel_fast_launch_path_kernel(int which, const void* launchArgs, void* stream);
+extern "C" void tinsel_fast_prepare_path_kernels(int sharedMemLimit);
+extern "C" unsigned tinsel_fast_launch_args_size(void);
+
+void launch_path(tinsel_hip* r, int which, const LaunchArgs& a, hipStream_t st)
+{
+    if (r->arith == TINSEL_ARITH_FAST)
+        tinsel_fast_launch_path_kernel(which, &a, st);
+    else
+        launch_path_kernel(which, a, st);
+}
 
 // k_walk's records are used by the scan kernels unless the detail counters are on (those count the inline walk)
 const float4* walk_records(const tinsel_hip* r) { return r->countDetail ? nullptr : r->walkRec; }
 
-void launch_extend(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
+bool noBinPrims()
 {
-    TN_DISPATCH2(k_extend, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed, (uint32_t)r->batchSlots,
-                 walk_records(r), (uint32_t)r->walkPrims.count);
+    static const bool off = getenv("TINSEL_HIP_NO_BIN") != nullptr;
+    return off;
 }
 
-void launch_shadow(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* queue, int bounce)
+// what every launch of a batch shares
+LaunchArgs batch_args(tinsel_hip* r, const CameraParams& cam, const FrameParams& fp)
 {
-    TN_DISPATCH2(k_shadow, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, queue, bounce, r->stackNeed, (uint32_t)r->batchSlots,
-                 walk_records(r), (uint32_t)r->walkPrims.count);
+    LaunchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene = r->scene;
+    a.ps = r->ps;
+    a.ctl = r->ctl;
+    a.cam = cam;
+    a.fp = fp;
+    a.passSeeds = r->passSeedsDev;
+    a.queueNee = r->queueNee;
+    a.walkRec = walk_records(r);
+    a.walkPrims = (uint32_t)r->walkPrims.count;
+    a.bins = noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims;
+    a.stackEntries = r->stackNeed;
+    a.countDetail = r->countDetail ? 1 : 0;
+    a.ldsBytes = (uint32_t)stack_bytes(r);
+    return a;
 }
 
-// k_walk (tn_walk.h): closest hits of the front rays of `queue` against the meshes in HBM, ahead of the scan kernel.
+// k_walk (tn_walk.h): closest hits of the front rays of `queue` against the large meshes in HBM, ahead of the scan kernel.
 // One 1024-thread workgroup per CU whose LDS holds the traversal stacks and, in what is left of the 160 KB, the top of
 // the walked trees; trees too deep for that (a device-built LBVH of 524k triangles: 48 entries per lane) run 256-thread
 // workgroups without a staged top.
-void launch_walk(tinsel_hip* r, hipStream_t st, const uint32_t* queue, const uint32_t* frontCount, bool shadowRays)
+void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* queue, const uint32_t* frontCount, bool shadowRays)
 {
     static const int gridMult = getenv("TINSEL_HIP_WALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_WALK_GRID_MULT")) : 1;
     static const int refillMin = getenv("TINSEL_HIP_WALK_REFILL") ? atoi(getenv("TINSEL_HIP_WALK_REFILL")) : 16;
     static const int leafMin = getenv("TINSEL_HIP_WALK_LEAFMIN") ? atoi(getenv("TINSEL_HIP_WALK_LEAFMIN")) : 8;
     static const int topLimit = getenv("TINSEL_HIP_WALK_TOP") ? atoi(getenv("TINSEL_HIP_WALK_TOP")) : 1 << 20;      // nodes; 0: no staged top (A/B)
     static const int forceBlock = getenv("TINSEL_HIP_WALK_BLOCK") ? atoi(getenv("TINSEL_HIP_WALK_BLOCK")) : 0;
-    static bool attrSet = false;
-    if (!attrSet)
+    if (!r->pathKernelsPrepared)
     {
-        (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, r->sharedMemLimit);
-        (void)hipFuncSetAttribute((const void*)k_walk<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, r->sharedMemLimit);
-        attrSet = true;
+        prepare_path_kernels(r->sharedMemLimit);
+        tinsel_fast_prepare_path_kernels(r->sharedMemLimit);
+        r->pathKernelsPrepared = true;
     }
-    WalkJob job;
+    WalkJob& job = a.walk;
     job.queue = queue;
     job.frontCount = frontCount;
     job.rayO = r->ps.rayO;
@@ -632,44 +653,10 @@ void launch_walk(tinsel_hip* r, hipStream_t st, const uint32_t* queue, const uin
     }
     const size_t items = r->batchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1)*(size_t)r->walkPrims.count;
     const int perCU = big ? gridMult : gridMult*4;
-    const int grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
-    if (big)
-        hipLaunchKernelGGL((k_walk<1024, 4>), dim3(grid), dim3(1024), lds, st, r->scene, job);
-    else
-        hipLaunchKernelGGL((k_walk<256, 5>), dim3(grid), dim3(256), lds, st, r->scene, job);
-}
-
-void launch_mega(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
-{
-    TN_DISPATCH2(k_mega, r->countDetail, r->scene.allInArena, dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, r->ps, r->ctl, cam, fp, r->passSeedsDev, r->stackNeed);
-}
-
-template <bool FIRST>
-void launch_bounce_t(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, const CameraParams& cam, const FrameParams& fp)
-{
-    const size_t lds = stack_bytes(r);
-    if (r->countDetail)
-    {
-        if (r->scene.allInArena)
-            hipLaunchKernelGGL((k_bounce<true, FIRST, true>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
-        else
-            hipLaunchKernelGGL((k_bounce<true, FIRST, false>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
-    }
-    else
-    {
-        if (r->scene.allInArena)
-            hipLaunchKernelGGL((k_bounce<false, FIRST, true>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
-        else
-            hipLaunchKernelGGL((k_bounce<false, FIRST, false>), dim3(grid), dim3(kBlock), lds, st, r->scene, r->ps, r->ctl, qin, qout, bounce, r->stackNeed, cam, fp, r->passSeedsDev);
-    }
-}
-
-void launch_bounce(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, const CameraParams& cam, const FrameParams& fp)
-{
-    if (bounce == 0)
-        launch_bounce_t<true>(r, st, grid, qin, qout, bounce, cam, fp);
-    else
-        launch_bounce_t<false>(r, st, grid, qin, qout, bounce, cam, fp);
+    a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
+    a.walkBig = big ? 1 : 0;
+    a.ldsBytes = (uint32_t)lds;
+    launch_path(r, PK_WALK, a, st);
 }
 
 void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
@@ -678,20 +665,6 @@ void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams&
         hipLaunchKernelGGL((k_normals<true>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum, r->stackNeed);
     else
         hipLaunchKernelGGL((k_normals<false>), dim3(grid), dim3(kBlock), stack_bytes(r), st, r->scene, cam, fp, r->accum, r->stackNeed);
-}
-
-bool noBinPrims()
-{
-    static const bool off = getenv("TINSEL_HIP_NO_BIN") != nullptr;
-    return off;
-}
-
-void launch_shade(tinsel_hip* r, hipStream_t st, int grid, const uint32_t* qin, uint32_t* qout, int bounce, int maxDepth)
-{
-    if (r->scene.allInArena)
-        hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), r->scene.arenaBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth, r->rrStart, (uint32_t)r->batchSlots, noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims);
-    else
-        hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), r->scene.arenaLdsBytes, st, r->scene, r->ps, r->ctl, qin, qout, r->queueNee, bounce, maxDepth, r->rrStart, (uint32_t)r->batchSlots, noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims);
 }
 
 // Accumulate tiles (16x16 pixels + filter halo) that contain at least one pixel owned by this shard; cached per
@@ -817,55 +790,72 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         // env_loft 3008 -> 2443; 4 rays veach 1304 -> 1340; 9 rays features 540 -> 668
         pipeline = (r->scene.allInArena && r->neePerPath <= 2) ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
 
+    LaunchArgs a = batch_args(r, cam, fp);
     if (pipeline == TINSEL_PIPELINE_MEGAKERNEL)
     {
         ScopedTimer t(r, KN_MEGA, st);
-        launch_mega(r, st, gridFlat, cam, fp);
+        a.grid = gridFlat;
+        launch_path(r, PK_MEGA, a, st);
     }
     else if (pipeline == TINSEL_PIPELINE_WAVEFRONT)
     {
+        a.grid = gridPersist;
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
             ScopedTimer t(r, KN_BOUNCE, st);
-            launch_bounce(r, st, gridPersist, r->queues[bounce & 1], r->queues[(bounce + 1) & 1], bounce, cam, fp);
+            a.bounce = bounce;
+            a.queueIn = r->queues[bounce & 1];
+            a.queueOut = r->queues[(bounce + 1) & 1];
+            launch_path(r, PK_BOUNCE, a, st);
         }
     }
     else
     {
-        const BinPrims bins = noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims;
         const bool walk = walk_records(r) != nullptr;
+        const uint32_t ldsTrace = a.ldsBytes, ldsShade = r->scene.allInArena ? r->scene.arenaBytes : r->scene.arenaLdsBytes;
         {
             ScopedTimer t(r, KN_GENERATE, st);
-            hipLaunchKernelGGL(k_generate, dim3(gridPersist), dim3(kBlock), 0, st, r->ps, r->ctl, r->queues[0], cam, fp, r->passSeedsDev, r->scene.primBoxes, bins);
+            a.grid = gridPersist;
+            a.queueOut = r->queues[0];
+            launch_path(r, PK_GENERATE, a, st);
         }
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
             uint32_t* qin = r->queues[bounce & 1];
             uint32_t* qout = r->queues[(bounce + 1) & 1];
-            const uint32_t* qtrace = qin;
+            a.bounce = bounce;
             if (walk)
             {
                 ScopedTimer t(r, KN_WALK, st);
-                launch_walk(r, st, qtrace, r->ctl.activeCount + bounce, false);
+                launch_walk(r, st, a, qin, r->ctl.activeCount + bounce, false);
             }
             {
                 ScopedTimer t(r, KN_EXTEND, st);
-                launch_extend(r, st, gridTrace, qtrace, bounce);
+                a.grid = gridTrace;
+                a.ldsBytes = ldsTrace;
+                a.queueIn = qin;
+                launch_path(r, PK_EXTEND, a, st);
             }
             {
                 ScopedTimer t(r, KN_SHADE, st);
-                launch_shade(r, st, gridPersist, qin, qout, bounce, fp.maxDepth);
+                a.grid = gridPersist;
+                a.ldsBytes = ldsShade;
+                a.queueIn = qin;
+                a.queueOut = qout;
+                launch_path(r, PK_SHADE, a, st);
             }
             if (r->neePerPath > 0)
             {
-                const uint32_t* qshadow = r->queueNee;
                 if (walk)
                 {
                     ScopedTimer t(r, KN_WALK, st);
-                    launch_walk(r, st, qshadow, r->ctl.neeCount + bounce, true);
+                    launch_walk(r, st, a, r->queueNee, r->ctl.neeCount + bounce, true);
                 }
                 ScopedTimer t(r, KN_SHADOW, st);
-                launch_shadow(r, st, gridTrace, qshadow, bounce);
+                a.grid = gridTrace;
+                a.ldsBytes = ldsTrace;
+                a.queueIn = r->queueNee;
+                launch_path(r, PK_SHADOW, a, st);
             }
         }
     }
@@ -1925,6 +1915,19 @@ int tinsel_hip_set_shard(tinsel_hip* r, int rank, int world, int tile)
     r->shardTile = tile;
     return 0;
 }
+
+int tinsel_hip_set_arithmetic(tinsel_hip* r, int mode)
+{
+    lookahead_cancel(r);
+    if (!r || (mode != TINSEL_ARITH_EXACT && mode != TINSEL_ARITH_FAST))
+        return fail("set_arithmetic: bad arguments");
+    if (tinsel_fast_launch_args_size() != sizeof(LaunchArgs))
+        return fail("set_arithmetic: the two builds of the path kernels disagree on the launch record");
+    r->arith = mode;
+    return 0;
+}
+
+int tinsel_hip_get_arithmetic(tinsel_hip* r) { return r ? r->arith : TINSEL_ARITH_EXACT; }
 
 int tinsel_hip_set_pipeline(tinsel_hip* r, int pipeline)
 {

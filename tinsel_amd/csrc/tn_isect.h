@@ -40,8 +40,13 @@ struct TraceCounters
 #define TN_TTICK(c, k)
 #endif
 
+#if TN_FAST
+TN_D float minf_ref(float a, float b) { return fminf(a, b); }       // tolerance arm: v_min_f32 / v_max_f32
+TN_D float maxf_ref(float a, float b) { return fmaxf(a, b); }
+#else
 TN_D float minf_ref(float a, float b) { return a < b ? a : b; }     // intersection.h:369
 TN_D float maxf_ref(float a, float b) { return a > b ? a : b; }     // intersection.h:370
+#endif
 
 // IntersectRayAABBFast (intersection.h:373-397)
 TN_D bool ray_aabb(V3 pos, V3 rcp, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t)

@@ -28,6 +28,12 @@ namespace tn {
 #ifndef TN_WAVES_FUSED
 #define TN_WAVES_FUSED 2
 #endif
+// k_bounce alone: the tolerance arm's k_bounce needs ~205 VGPRs and is faster squeezed to 168 (3 waves per SIMD, ~100 B of
+// scratch: cornell 3203 -> 3827 Msamples/s); its k_shade is not (veach 1698 -> 1563), and the exact arm's k_bounce (256 VGPRs
+// + scratch already) is 1.4-1.8x slower when squeezed.
+#ifndef TN_WAVES_BOUNCE
+#define TN_WAVES_BOUNCE TN_WAVES_FUSED
+#endif
 #ifndef TN_WAVES_TRACE
 #define TN_WAVES_TRACE 4
 #endif
@@ -438,7 +444,7 @@ TN_D bool begin_path(const CameraParams& cam, const FrameParams& fp, const uint3
 #endif
 
 template <bool COUNT, bool FIRST, bool LDS>
-__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_bounce(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueIn,
+__global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueIn,
                                                    uint32_t* __restrict__ queueOut, int bounce, int stackEntries, CameraParams cam,
                                                    FrameParams fp, const uint32_t* __restrict__ passSeeds)
 {

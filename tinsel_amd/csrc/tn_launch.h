@@ -1,0 +1,108 @@
+// tn_launch.h -- the launches of the path kernels, as one function of a plain argument block.
+//
+// The library carries the path kernels TWICE, from two translation units built with different floating-point contracts:
+//   tinsel_hip.hip   (namespace tn)        -ffp-contract=off, IEEE divide / sqrt, glibc's transcendentals restated:
+//                                          bit-identical to the CPU oracle -- the default and the parity path;
+//   tinsel_fast.hip  (namespace tn_fast)   FMA contraction, v_rcp / v_rsq / v_sqrt, hardware sin / cos / exp:
+//                                          the opt-in tolerance arm (tinsel_hip_set_arithmetic), like the reference's
+//                                          own `-O3 -ffast-math` / `-use_fast_math` builds (makefile:4, tinsel.vcxproj:134).
+// Both include this header (the second one with `tn` renamed), so the two arms differ in arithmetic only: same kernels,
+// same queues, same launch geometry.  The host fills a LaunchArgs per launch and hands it to launch_path_kernel of the
+// arm in force.
+#pragma once
+
+#include "tn_kernels.h"
+
+namespace tn {
+
+enum PathKernel : int
+{
+    PK_GENERATE = 0, PK_EXTEND, PK_SHADE, PK_SHADOW, PK_BOUNCE, PK_MEGA, PK_WALK,
+};
+
+struct LaunchArgs
+{
+    DevScene scene;
+    PathState ps;
+    QueueCtl ctl;
+    CameraParams cam;
+    FrameParams fp;
+    const uint32_t* passSeeds;
+    const uint32_t* queueIn;        // extension / shade / bounce input queue, shadow queue for PK_SHADOW
+    uint32_t* queueOut;             // next bounce's queue (PK_GENERATE: queue 0)
+    uint32_t* queueNee;             // shadow queue filled by PK_SHADE
+    const float4* walkRec;          // k_walk's records (null: meshes are walked inline)
+    uint32_t walkPrims;
+    BinPrims bins;                  // primitives whose leaf-box test sorts the queues
+    WalkJob walk;                   // PK_WALK
+    int walkBig;                    // PK_WALK: 1024-thread workgroups with an LDS-resident tree top, else 256-thread ones
+    int bounce;
+    int stackEntries;
+    int countDetail;                // detail counters on: the COUNT kernel variants
+    int grid;
+    uint32_t ldsBytes;              // dynamic LDS of the launch
+};
+
+inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
+{
+    const dim3 grid((unsigned)a.grid), block(kBlock);
+    const bool lds = a.scene.allInArena != 0, count = a.countDetail != 0;
+    switch (which)
+    {
+    case PK_GENERATE:
+        hipLaunchKernelGGL(k_generate, grid, block, 0, st, a.ps, a.ctl, a.queueOut, a.cam, a.fp, a.passSeeds, a.scene.primBoxes, a.bins);
+        break;
+    case PK_EXTEND:
+#define TN_LAUNCH2(KERNEL, ...)                                                                                        \
+        do {                                                                                                           \
+            if (count) { if (lds) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__); } \
+            else       { if (lds) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); } \
+        } while (0)
+        TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+        break;
+    case PK_SHADOW:
+        TN_LAUNCH2(k_shadow, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+        break;
+    case PK_MEGA:
+        TN_LAUNCH2(k_mega, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.cam, a.fp, a.passSeeds, a.stackEntries);
+        break;
+#undef TN_LAUNCH2
+    case PK_SHADE:
+        if (lds)
+            hipLaunchKernelGGL((k_shade<true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.queueNee, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.fp.queueCapacity, a.bins);
+        else
+            hipLaunchKernelGGL((k_shade<false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.queueNee, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.fp.queueCapacity, a.bins);
+        break;
+    case PK_BOUNCE:
+#define TN_LAUNCH_BOUNCE(FIRST)                                                                                        \
+        do {                                                                                                           \
+            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, FIRST, true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
+                         else hipLaunchKernelGGL((k_bounce<true, FIRST, false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
+            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, FIRST, true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
+                         else hipLaunchKernelGGL((k_bounce<false, FIRST, false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
+        } while (0)
+        if (a.bounce == 0)
+            TN_LAUNCH_BOUNCE(true);
+        else
+            TN_LAUNCH_BOUNCE(false);
+#undef TN_LAUNCH_BOUNCE
+        break;
+    case PK_WALK:
+        if (a.walkBig)
+            hipLaunchKernelGGL((k_walk<1024, 4>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
+        else
+            hipLaunchKernelGGL((k_walk<256, 5>), grid, dim3(256), a.ldsBytes, st, a.scene, a.walk);
+        break;
+    default:
+        break;
+    }
+}
+
+// k_walk asks for more dynamic LDS than the default launch limit allows
+inline void prepare_path_kernels(int sharedMemLimit)
+{
+    (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+    (void)hipFuncSetAttribute((const void*)k_walk<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+}
+
+} // namespace tn

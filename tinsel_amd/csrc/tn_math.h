@@ -96,9 +96,13 @@ TN_HD V3 face_forward(V3 n, V3 v) { return (dot(v, n) < 0.0f) ? -n : n; }
 //   * acosf / atan2f (probe lookups): glibc 2.35 still uses the fdlibm fp32 routines for these; m_acosf /
 //     m_atanf / m_atan2f restate them in the same fp32 operation order (also checked exhaustively).
 // TN_LIBM_DOUBLE=0 switches everything to the 1-2 ulp ocml fp32 routines (A/B only).
-#ifndef TN_LIBM_DOUBLE
-#define TN_LIBM_DOUBLE 1
+#ifndef TN_FAST
+#define TN_FAST 0           // 1: the tolerance arm (tinsel_fast.hip): hardware transcendentals, see tn_launch.h
 #endif
+#ifndef TN_LIBM_DOUBLE
+#define TN_LIBM_DOUBLE (!TN_FAST)
+#endif
+__device__ const unsigned long long kExp2fTab[32] = { 0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL, 0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL, 0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL, 0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL, 0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL, 0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL, 0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL, 0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL };
 #if TN_LIBM_DOUBLE
 TN_D void sincos_wide(double x, float& s, float& c)
 {
@@ -170,7 +174,6 @@ TN_D void m_sincosf(float y, float& s, float& c)
 TN_D float m_sinf(float x) { float s, c; m_sincosf(x, s, c); return s; }
 TN_D float m_cosf(float x) { float s, c; m_sincosf(x, s, c); return c; }
 
-__device__ const unsigned long long kExp2fTab[32] = { 0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL, 0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL, 0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL, 0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL, 0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL, 0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL, 0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL, 0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL };
 
 // glibc 2.35 expf, the __expf_fma ifunc variant an FMA-capable x86-64 host runs (e_expf.c, non-TOINT path: the
 // SHIFT trick; the compiler contracted InvLn2N*x + SHIFT and InvLn2N*x - kd into FMAs there, so they are FMAs here)
@@ -333,11 +336,34 @@ TN_D float m_atan2f(float y, float x)
     if (m == 2) return pi - (z - pi_lo);
     return (z - pi_lo) - pi;
 }
+#elif TN_FAST
+// tolerance arm.  TN_FAST_NATIVE_TRIG=1: v_sin_f32 / v_cos_f32 / v_exp_f32 (absolute error ~1e-6: visibly more paths leave
+// the exact arm's track in specular scenes); 0 (default): ocml's fp32 routines (1-2 ulp)
+#ifndef TN_FAST_NATIVE_TRIG
+#define TN_FAST_NATIVE_TRIG 0
+#endif
+#if TN_FAST_NATIVE_TRIG
+TN_D void m_sincosf(float x, float& s, float& c) { s = __sinf(x); c = __cosf(x); }
+TN_D float m_sinf(float x) { return __sinf(x); }
+TN_D float m_cosf(float x) { return __cosf(x); }
+TN_D float m_expf(float x) { return __expf(x); }
+template <class Tab> TN_D float m_expf_tab(float x, const Tab&) { return __expf(x); }
+#else
+TN_D void m_sincosf(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+TN_D float m_sinf(float x) { return ::sinf(x); }
+TN_D float m_cosf(float x) { return ::cosf(x); }
+TN_D float m_expf(float x) { return ::expf(x); }
+template <class Tab> TN_D float m_expf_tab(float x, const Tab&) { return ::expf(x); }
+#endif
+TN_D float m_logf(float x) { return __logf(x); }
+TN_D float m_acosf(float x) { return ::acosf(x); }
+TN_D float m_atan2f(float y, float x) { return ::atan2f(y, x); }
 #else
 TN_D void m_sincosf(float x, float& s, float& c) { s = ::sinf(x); c = ::cosf(x); }
 TN_D float m_sinf(float x) { return ::sinf(x); }
 TN_D float m_cosf(float x) { return ::cosf(x); }
 TN_D float m_expf(float x) { return ::expf(x); }
+template <class Tab> TN_D float m_expf_tab(float x, const Tab&) { return ::expf(x); }
 TN_D float m_logf(float x) { return ::logf(x); }
 TN_D float m_acosf(float x) { return ::acosf(x); }
 TN_D float m_atan2f(float y, float x) { return ::atan2f(y, x); }
