@@ -104,3 +104,56 @@ def test_cfg3_524k_triangle_standin_window():
     _, orad, _ = O.render_seeded(h, cam, opt, 0, 1, window=(900, 480, 996, 576), want_accum=False, want_radiance=True)
     O.free(h)
     assert np.array_equal(rad, orad[0])
+
+
+def _busiest_window(scene, cam, opt, size=96, step=48):
+    """The size x size window of the frame with the most geometric discontinuities (eNormals image: neighbouring pixels whose
+    normals differ a lot or that hit / miss differently) -- silhouettes, where traversal is least coherent."""
+    import tinsel_amd
+    nopt = opt.copy()
+    nopt.mode = abi.MODE_NORMALS
+    r = tinsel_amd.create_gpu_renderer(scene)
+    r.init(opt.width, opt.height)
+    n = r.render(cam, nopt, passes=1)
+    r.close()
+    edge = (np.abs(np.diff(n, axis=0))[:, :-1].max(axis=-1) > 0.25) | (np.abs(np.diff(n, axis=1))[:-1].max(axis=-1) > 0.25)
+    best, where = -1, (0, 0)
+    for y0 in range(0, opt.height - size, step):
+        for x0 in range(0, opt.width - size, step):
+            c = int(edge[y0:y0 + size, x0:x0 + size].sum())
+            if c > best:
+                best, where = c, (x0, y0)
+    return where, best
+
+
+@pytest.mark.parametrize("label,pack,W,H,depth,pass_index", [
+    ("cfg5 veach 3840x2160", os.path.join(oa.GOLDEN, "veach.pack"), 3840, 2160, 4, 137),
+    ("cfg4 glass 1920x1080 depth 12", os.path.join(oa.GOLDEN, "glass.pack"), 1920, 1080, 12, 1000),
+    ("cfg3 ajax stand-in 524288 tris 1920x1080", LARGE, 1920, 1080, 4, 211),
+], ids=["cfg5", "cfg4", "cfg3"])
+def test_silhouette_window_at_a_late_pass_is_bit_identical(label, pack, W, H, depth, pass_index):
+    """A second window per big config, placed by the scene itself on its busiest silhouettes (incoherent traversal, rays
+    that graze the mesh, k_walk with half-empty waves) and at a pass index in the hundreds (the seed chain far from its
+    start): every path of it bit-identical to the oracle's PathTrace."""
+    import tinsel_amd
+    if not os.path.exists(pack):
+        pytest.skip("%s not on this box" % pack)
+    scene = tinsel_amd.Scene.load_pack(pack)
+    cam, opt = scene.camera, scene.options.copy()
+    opt.width, opt.height, opt.max_depth, opt.mode = W, H, depth, abi.MODE_PATHTRACE
+    (x0, y0), edges = _busiest_window(scene, cam, opt)
+    assert edges > 50, "no silhouette found in %s" % label
+
+    r = tinsel_amd.create_gpu_renderer(scene)
+    r.init(W, H)
+    r.set_pass_index(pass_index)
+    r.render(cam, opt, passes=1, readback=False)
+    rad = r.batch_radiance(1, H, W)[0, y0:y0 + 96, x0:x0 + 96]
+    r.close()
+
+    O = _oracle()
+    h = O.load_pack(pack)
+    _, orad, _ = O.render_seeded(h, cam, opt, pass_index, 1, window=(x0, y0, x0 + 96, y0 + 96), want_accum=False, want_radiance=True)
+    O.free(h)
+    exact = (rad == orad[0]).all(axis=-1)
+    assert exact.all(), "%s window (%d, %d), pass %d: %d of %d paths differ" % (label, x0, y0, pass_index, (~exact).sum(), exact.size)
