@@ -227,6 +227,15 @@ int tinsel_hip_read_accum(tinsel_hip* r, float* out_rgba);
 enum { TINSEL_BVH_REFERENCE = 0, TINSEL_BVH_LBVH = 1 };
 int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms);
 
+/* Refit for deforming meshes (per-frame vertex animation with unchanged topology; the reference rebuilds with its host SAH
+ * sweep, mesh.cpp:314-338 -- 1.1 s for 524k triangles): `primitive`'s mesh gets new vertex positions (num_vertices x 3
+ * floats, host; must be the vertex count the mesh was created with) and optionally new vertex normals; the triangle
+ * records are re-gathered and every box of the mesh's CURRENT tree (the reference's, or a device-built one) is recomputed
+ * bottom-up on the device -- exactly the boxes the reference's builder would store for that tree shape; the area CDF and
+ * PrimitiveArea of every instance follow (Mesh::RebuildCDF's serial order).  All instances of the mesh change.  Meshes
+ * small enough for the LDS-staged arena are refused (create a new renderer: it costs less than the refit). */
+int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_xyz, int num_vertices, const float* normals_xyz);
+
 /* Russian roulette, OPT-IN (start_bounce = 0, the default, is the reference's behaviour: render.cpp:250 runs every
  * path to maxDepth and so does the parity path).  With start_bounce = b > 0, after every bounce i >= b - 1 that has a
  * successor the path survives with probability q = min(1, max(throughput.rgb)) and its throughput is divided by q: the

@@ -310,6 +310,12 @@ struct tinsel_hip
 
     // mesh table as uploaded (reference trees) and as it currently is; device-built trees (tn_lbvh.h)
     std::vector<DevMesh> meshesRef, meshesNow;
+    // what a refit needs on the host (tinsel_hip_refit_mesh): per mesh the vertex count and the index triples, per
+    // primitive its mesh and the endTransform scale of PrimitiveArea
+    std::vector<int> meshNumVertices;
+    std::vector<std::vector<int32_t>> meshIndices;
+    std::vector<int> primMesh;
+    std::vector<float> primEndScale;
     int sceneStackNeed = 1;
     int bvhMode = TINSEL_BVH_REFERENCE;
     int rrStart = 0;                    // > 0: Russian roulette from this bounce on (opt-in)
@@ -1264,6 +1270,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         memset(&o, 0, sizeof(o));
 
         make_material(p, mats[(size_t)i]);
+        r->primEndScale.push_back(p.end_transform.s);
         if (p.light_samples > 0)
         {
             if (p.type == TINSEL_GEOM_PLANE)
@@ -1386,6 +1393,8 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 }
                 if (dm.stackNeed > maxMeshNeed)
                     maxMeshNeed = dm.stackNeed;
+                r->meshNumVertices.push_back(g.num_vertices);
+                r->meshIndices.emplace_back(g.indices, g.indices + (size_t)numTris*3);
                 o.mesh = (uint32_t)meshes.size();
                 meshIndex[g.id] = o.mesh;
                 meshes.push_back(dm);
@@ -1397,6 +1406,11 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             ok = false;
         }
     }
+
+    r->primMesh.assign((size_t)P, -1);
+    for (int i = 0; i < P && ok; ++i)
+        if (prims[(size_t)i].type == kPrimMesh)
+            r->primMesh[(size_t)i] = (int)prims[(size_t)i].mesh;
 
     ConvertedBvh sceneBvh;
     if (ok && !convert_bvh(desc->bvh_nodes, desc->num_bvh_nodes, P, 0, sceneBvh))
@@ -1875,6 +1889,92 @@ int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
     for (size_t k = 0; k < prevAllocs; ++k)
         (void)hipFree(r->lbvhAllocs[k]);
     r->lbvhAllocs.erase(r->lbvhAllocs.begin(), r->lbvhAllocs.begin() + (long)prevAllocs);
+    return 0;
+}
+
+// Refit of a deforming mesh: new vertex positions (and optionally normals), same topology, same tree shape.
+int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_xyz, int num_vertices, const float* normals_xyz)
+{
+    lookahead_cancel(r);
+    if (!r || !positions_xyz || primitive < 0 || primitive >= r->scene.numPrims || r->primMesh[(size_t)primitive] < 0)
+        return fail("refit_mesh: bad arguments (a mesh primitive and its new positions)");
+    const int mi = r->primMesh[(size_t)primitive];
+    DevMesh& dm = r->meshesNow[(size_t)mi];
+    if (dm.inArena)
+        return fail("refit_mesh: this mesh is small enough to live in the LDS-staged scene arena; create a new renderer for it");
+    if (num_vertices != r->meshNumVertices[(size_t)mi])
+        return fail("refit_mesh: the topology must not change (vertex count differs)");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+
+    const int numTris = dm.numTris;
+    const int numNodes = numTris - 1;           // one triangle per leaf: internal nodes
+    float* posDev = nullptr;
+    float* own = nullptr;
+    int* gen = nullptr;
+    int rc = 0;
+    do {
+        if (hipMalloc((void**)&posDev, sizeof(float)*3*(size_t)num_vertices) != hipSuccess ||
+            hipMemcpy(posDev, positions_xyz, sizeof(float)*3*(size_t)num_vertices, hipMemcpyHostToDevice) != hipSuccess) { rc = fail("refit_mesh: upload failed"); break; }
+        hipLaunchKernelGGL(k_refit_tris, dim3((unsigned)((numTris + 255)/256)), dim3(256), 0, nullptr, const_cast<Tri48*>(dm.tris), numTris, posDev);
+        if (normals_xyz && hipMemcpy(const_cast<float*>(dm.normals), normals_xyz, sizeof(float)*3*(size_t)num_vertices, hipMemcpyHostToDevice) != hipSuccess) { rc = fail("refit_mesh: normals upload failed"); break; }
+        if (numNodes > 0)
+        {
+            if (hipMalloc((void**)&own, sizeof(float)*6*(size_t)numNodes) != hipSuccess || hipMalloc((void**)&gen, sizeof(int)*(size_t)numNodes) != hipSuccess)
+            { rc = fail("refit_mesh: device allocation failed"); break; }
+            // the tree in use and, when a device-built one is, the reference's too (switching back must not find stale boxes)
+            const DevMesh* trees[2] = { &dm, r->meshesRef[(size_t)mi].nodes != dm.nodes ? &r->meshesRef[(size_t)mi] : nullptr };
+            for (const DevMesh* tree : trees)
+            {
+                if (!tree || rc)
+                    continue;
+                if (hipMemset(gen, 0, sizeof(int)*(size_t)numNodes) != hipSuccess) { rc = fail("refit_mesh: memset failed"); break; }
+                // the root of a converted tree is node 0 (reference trees: convert_bvh; device-built ones: the Karras root)
+                int rootGen = 0;
+                for (int pass = 1; pass <= 4096 && !rootGen; )
+                {
+                    for (int k = 0; k < 16; ++k, ++pass)
+                        hipLaunchKernelGGL(k_refit_pass, dim3((unsigned)((numNodes + 255)/256)), dim3(256), 0, nullptr, const_cast<Node64*>(tree->nodes), numNodes, dm.tris, own, gen, pass);
+                    if (hipMemcpy(&rootGen, gen + (tree->root & ~kLeafBit), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+                        break;
+                }
+                if (!rootGen)
+                    rc = fail("refit_mesh: the refit did not reach the root");
+            }
+            if (rc)
+                break;
+        }
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail("refit_mesh: kernels failed"); break; }
+    } while (false);
+    if (posDev) (void)hipFree(posDev);
+    if (own) (void)hipFree(own);
+    if (gen) (void)hipFree(gen);
+    if (rc)
+        return rc;
+
+    // Mesh::RebuildCDF (mesh.cpp:340-368) in the reference's own serial fp32 order, then PrimitiveArea of every instance
+    const std::vector<int32_t>& idx = r->meshIndices[(size_t)mi];
+    std::vector<float> cdf((size_t)numTris);
+    float totalArea = 0.0f;
+    for (int t = 0; t < numTris; ++t)
+    {
+        const float* a = positions_xyz + (size_t)idx[(size_t)t*3 + 0]*3;
+        const float* b = positions_xyz + (size_t)idx[(size_t)t*3 + 1]*3;
+        const float* c = positions_xyz + (size_t)idx[(size_t)t*3 + 2]*3;
+        const V3 ab(b[0] - a[0], b[1] - a[1], b[2] - a[2]), ac(c[0] - a[0], c[1] - a[1], c[2] - a[2]);
+        const float area = 0.5f*length(cross(ab, ac));
+        totalArea += area;
+        cdf[(size_t)t] = totalArea;
+    }
+    for (int t = 0; t < numTris; ++t)
+        cdf[(size_t)t] /= totalArea;
+    HIP_TRY(hipMemcpy(const_cast<float*>(dm.cdf), cdf.data(), sizeof(float)*(size_t)numTris, hipMemcpyHostToDevice));
+    for (int p = 0; p < r->scene.numPrims; ++p)
+        if (r->primMesh[(size_t)p] == mi)
+        {
+            const float area = totalArea*r->primEndScale[(size_t)p];          // intersection.h:843-847
+            HIP_TRY(hipMemcpy((void*)&r->scene.mats[p].area, &area, sizeof(float), hipMemcpyHostToDevice));
+        }
     return 0;
 }
 

@@ -218,4 +218,62 @@ __global__ __launch_bounds__(256) void k_lbvh_emit(const unsigned long long* __r
     out[i] = o;
 }
 
+// ---------------------------------------------------------------------------
+// Refit (tinsel_hip_refit_mesh): the vertices of a mesh moved, its topology did not.  The tree keeps its shape -- the
+// reference's SAH tree or a device-built one, both are Node64 arrays -- and every box is recomputed bottom-up from the
+// new triangles: a leaf's box is the min / max of its three vertices (Bounds::AddPoint, maths.h), an internal node's
+// the union of its children's, exactly what the reference's builder stores for the same tree (min / max do not round).
+
+// new positions -> the pre-gathered triangle records (vertex indices ride in the .w lanes)
+__global__ __launch_bounds__(256) void k_refit_tris(Tri48* __restrict__ tris, int numTris, const float* __restrict__ positions)
+{
+    const int t = blockIdx.x*256 + threadIdx.x;
+    if (t >= numTris)
+        return;
+    Tri48 T = tris[t];
+    T.ax = positions[T.i0*3 + 0]; T.ay = positions[T.i0*3 + 1]; T.az = positions[T.i0*3 + 2];
+    T.bx = positions[T.i1*3 + 0]; T.by = positions[T.i1*3 + 1]; T.bz = positions[T.i1*3 + 2];
+    T.cx = positions[T.i2*3 + 0]; T.cy = positions[T.i2*3 + 1]; T.cz = positions[T.i2*3 + 2];
+    tris[t] = T;
+}
+
+// One pass per tree level, like the box fitting of the build: a node is refitted once both children were finished in an
+// EARLIER pass (leaves always are), so no thread ever reads what another one writes in the same launch.
+__global__ __launch_bounds__(256) void k_refit_pass(Node64* __restrict__ nodes, int numNodes, const Tri48* __restrict__ tris,
+                                                    float* __restrict__ own, int* __restrict__ gen, int pass)
+{
+    const int k = blockIdx.x*256 + threadIdx.x;
+    if (k >= numNodes || gen[k] != 0)
+        return;
+    Node64 n = nodes[k];
+    float b[2][6];
+    const uint32_t child[2] = { n.left, n.right };
+    for (int c = 0; c < 2; ++c)
+    {
+        if (child[c] & kLeafBit)
+        {
+            const Tri48 T = tris[child[c] & ~kLeafBit];
+            b[c][0] = fminf(fminf(T.ax, T.bx), T.cx); b[c][1] = fminf(fminf(T.ay, T.by), T.cy); b[c][2] = fminf(fminf(T.az, T.bz), T.cz);
+            b[c][3] = fmaxf(fmaxf(T.ax, T.bx), T.cx); b[c][4] = fmaxf(fmaxf(T.ay, T.by), T.cy); b[c][5] = fmaxf(fmaxf(T.az, T.bz), T.cz);
+        }
+        else
+        {
+            const int g = gen[child[c]];
+            if (g == 0 || g >= pass)
+                return;
+            for (int q = 0; q < 6; ++q)
+                b[c][q] = own[(size_t)child[c]*6 + q];
+        }
+    }
+    n.lminx = b[0][0]; n.lminy = b[0][1]; n.lminz = b[0][2]; n.lmaxx = b[0][3]; n.lmaxy = b[0][4]; n.lmaxz = b[0][5];
+    n.rminx = b[1][0]; n.rminy = b[1][1]; n.rminz = b[1][2]; n.rmaxx = b[1][3]; n.rmaxy = b[1][4]; n.rmaxz = b[1][5];
+    nodes[k] = n;
+    for (int q = 0; q < 3; ++q)
+    {
+        own[(size_t)k*6 + q] = fminf(b[0][q], b[1][q]);
+        own[(size_t)k*6 + 3 + q] = fmaxf(b[0][3 + q], b[1][3 + q]);
+    }
+    gen[k] = pass;
+}
+
 } // namespace tn
