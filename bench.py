@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-second-config", action="store_true", help="skip BASELINE config 3 (the 524k-triangle mesh)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (traffic / VALU counts become null)")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in tolerance-arithmetic leg (fast_msamples_s / fast_l2)")
+    ap.add_argument("--no-api", action="store_true", help="skip the API call-pattern legs (pcie_inclusive / api_1pass), e.g. under rocprofv3 --stats")
     ap.add_argument("--arith", choices=["exact", "fast"], default="exact", help="arithmetic arm of the TIMED run (default: the bit-exact parity path)")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)      # the child process the PMC passes profile
     return ap.parse_args()
@@ -318,7 +319,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
 
     # ---- the API's own call pattern, N = 1 only -------------------------------------------------
     pcie = api_1pass = api_1pass_plain = None
-    if world == 1 and with_extras:
+    if world == 1 and with_extras and not args.no_api:
         # a renderer of its own, with a library-owned accumulator like the C++ shim's (the timed one renders into a torch tensor)
         ra = tinsel_amd.create_gpu_renderer(scene, local)
         ra.init(opt.width, opt.height)

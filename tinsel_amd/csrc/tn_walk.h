@@ -25,7 +25,8 @@
 // (asserted against the inline walk of the other pipelines in tests/test_gpu_parity.py).
 // Tried and measured, not kept: XCD-aware range mapping (each XCD a contiguous eighth of the queue so that its L2 holds
 // one patch of the tree: 24.1 -> 29.4 ms; the interleaved ranges already share their working set in TIME), 8 waves per
-// SIMD at 64 VGPRs (spills: 24.8 -> 38.6 ms).
+// SIMD at 64 VGPRs (spills: 24.8 -> 38.6 ms); node and triangle fetches issued together and waited for once per iteration
+// (no separate triangle phase: 22.5 -> 24.8 ms -- the triangle arithmetic then runs every iteration for ~6 lanes).
 #pragma once
 
 #include "tn_isect.h"
