@@ -34,6 +34,9 @@ namespace tn {
 #ifndef TN_WAVES_BOUNCE
 #define TN_WAVES_BOUNCE TN_WAVES_FUSED
 #endif
+#ifndef TN_WAVES_SHADE
+#define TN_WAVES_SHADE TN_WAVES_FUSED
+#endif
 #ifndef TN_WAVES_TRACE
 #define TN_WAVES_TRACE 4
 #endif
@@ -774,7 +777,7 @@ TN_D NeeRec load_nee(const PathState& ps, uint32_t slot, int k)
 }
 
 template <bool LDS>
-__global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_shade(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ queueNext, uint32_t* __restrict__ queueNee, int bounce, int maxDepth, int rrStart,
                                                   uint32_t queueCapacity, BinPrims bp)
 {
