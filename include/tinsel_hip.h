@@ -236,6 +236,15 @@ int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms);
  * small enough for the LDS-staged arena are refused (create a new renderer: it costs less than the refit). */
 int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_xyz, int num_vertices, const float* normals_xyz);
 
+/* Importance sampling of the environment probe.  TINSEL_PROBE_CDF (default): the reference's two binary searches over
+ * the row and column CDFs (ProbeSample, probe.h:205-236; ~21 dependent loads per sample on the 1600x800 loft.hdr) --
+ * sample-identical to the reference.  TINSEL_PROBE_ALIAS (opt-in): an alias table over the W*H texels built once on the
+ * host from the same pdf tables; consumes the same two random numbers, draws texels with the same probabilities and
+ * returns the same pdf for a texel, so the estimator is as unbiased -- but a given seed picks another texel, so images
+ * agree with the reference's statistically, not sample for sample. */
+enum { TINSEL_PROBE_CDF = 0, TINSEL_PROBE_ALIAS = 1 };
+int tinsel_hip_set_probe_sampling(tinsel_hip* r, int mode);
+
 /* Russian roulette, OPT-IN (start_bounce = 0, the default, is the reference's behaviour: render.cpp:250 runs every
  * path to maxDepth and so does the parity path).  With start_bounce = b > 0, after every bounce i >= b - 1 that has a
  * successor the path survives with probability q = min(1, max(throughput.rgb)) and its throughput is divided by q: the

@@ -352,6 +352,7 @@ struct tinsel_hip
     float4* walkRec = nullptr;                          // k_walk's closest-hit records (tn_walk.h); batch-sized
     bool walkEnabled = true;                            // TINSEL_HIP_NO_WALK: walk meshes inline in k_extend / k_shadow (A/B)
     unsigned long long* walkProf = nullptr;             // developer-only (-DTN_WALK_PROF builds): section counters of k_walk
+    uint2* probeAlias = nullptr;                        // alias table of the probe (tinsel_hip_set_probe_sampling), built on first use
     int sharedMemLimit = 65536;
     uint32_t* passSeedsDev = nullptr;
     size_t passSeedsCap = 0;
@@ -1627,6 +1628,7 @@ void tinsel_hip_destroy(tinsel_hip* r)
     (void)hipDeviceSynchronize();
     if (r->workStream) (void)hipStreamDestroy(r->workStream);
     if (r->copyStream) (void)hipStreamDestroy(r->copyStream);
+    if (r->probeAlias) (void)hipFree(r->probeAlias);
     if (r->walkProf)
     {
         unsigned long long wp[16] = { 0 };
@@ -1975,6 +1977,70 @@ int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_x
             const float area = totalArea*r->primEndScale[(size_t)p];          // intersection.h:843-847
             HIP_TRY(hipMemcpy((void*)&r->scene.mats[p].area, &area, sizeof(float), hipMemcpyHostToDevice));
         }
+    return 0;
+}
+
+// Probe importance sampling: the reference's two binary searches (default, sample-identical) or an alias table.
+int tinsel_hip_set_probe_sampling(tinsel_hip* r, int mode)
+{
+    lookahead_cancel(r);
+    if (!r || (mode != TINSEL_PROBE_CDF && mode != TINSEL_PROBE_ALIAS))
+        return fail("set_probe_sampling: bad arguments");
+    if (mode == TINSEL_PROBE_CDF || !r->scene.probe.valid)
+    {
+        r->scene.probe.alias = nullptr;
+        return 0;
+    }
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!r->probeAlias)
+    {
+        // Vose's alias method over p(row, col) = pdfY[row]*pdfX[row, col] -- the probabilities ProbeSample's two searches
+        // realise (probe.h:31-79 BuildCDF) -- in double on the host, once
+        const int W = r->scene.probe.width, H = r->scene.probe.height;
+        const size_t n = (size_t)W*H;
+        std::vector<float> px(n), py((size_t)H);
+        HIP_TRY(hipMemcpy(px.data(), r->scene.probe.pdfX, sizeof(float)*n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(py.data(), r->scene.probe.pdfY, sizeof(float)*(size_t)H, hipMemcpyDeviceToHost));
+        std::vector<double> scaled(n);
+        double total = 0.0;
+        for (int j = 0; j < H; ++j)
+            for (int i = 0; i < W; ++i)
+            {
+                const double p = (double)py[(size_t)j]*(double)px[(size_t)j*W + i];
+                scaled[(size_t)j*W + i] = p;
+                total += p;
+            }
+        if (!(total > 0.0))
+            return fail("set_probe_sampling: the probe has no energy");
+        std::vector<uint32_t> small, large;
+        small.reserve(n); large.reserve(n);
+        for (size_t k = 0; k < n; ++k)
+        {
+            scaled[k] = scaled[k]/total*(double)n;
+            (scaled[k] < 1.0 ? small : large).push_back((uint32_t)k);
+        }
+        std::vector<uint2> table(n);
+        while (!small.empty() && !large.empty())
+        {
+            const uint32_t s = small.back(); small.pop_back();
+            const uint32_t l = large.back();
+            const float keep = (float)scaled[s];
+            table[s] = make_uint2(__builtin_bit_cast(uint32_t, keep), l);
+            scaled[l] = (scaled[l] + scaled[s]) - 1.0;
+            if (scaled[l] < 1.0)
+            {
+                large.pop_back();
+                small.push_back(l);
+            }
+        }
+        const float one = 2.0f;         // r2 <= 1 < 2: always keep
+        for (uint32_t k : large) table[k] = make_uint2(__builtin_bit_cast(uint32_t, one), k);
+        for (uint32_t k : small) table[k] = make_uint2(__builtin_bit_cast(uint32_t, one), k);
+        HIP_TRY(hipMalloc((void**)&r->probeAlias, sizeof(uint2)*n));
+        HIP_TRY(hipMemcpy(r->probeAlias, table.data(), sizeof(uint2)*n, hipMemcpyHostToDevice));
+    }
+    r->scene.probe.alias = r->probeAlias;
     return 0;
 }
 

@@ -81,8 +81,23 @@ TN_D void probe_sample(const DevProbe& p, V3& dir, V3& color, float& pdf, Rng& r
     float r1 = rng.randf();
     float r2 = rng.randf();
 
-    int row = lower_bound(p.cdfY, 0, p.height, r1);
-    int col = lower_bound(p.cdfX, row*p.width, (row + 1)*p.width, r2) - row*p.width;
+    int row, col;
+    if (p.alias)
+    {
+        // opt-in alias table (not sample-identical to the reference: same two draws, same distribution over the texels,
+        // ONE dependent 8-B load instead of ~21 for the two binary searches over 800 rows and 1600 columns)
+        const int n = p.width*p.height;
+        const int k = minI(int(r1*float(n)), n - 1);
+        const uint2 e = p.alias[k];
+        const int idx = (r2 < __uint_as_float(e.x)) ? k : (int)e.y;
+        row = idx/p.width;
+        col = idx - row*p.width;
+    }
+    else
+    {
+        row = lower_bound(p.cdfY, 0, p.height, r1);
+        col = lower_bound(p.cdfX, row*p.width, (row + 1)*p.width, r2) - row*p.width;
+    }
 
     float4 c = p.data[row*p.width + col];
     color = V3(c.x, c.y, c.z);

@@ -129,6 +129,9 @@ struct DevProbe
     int32_t width, height;
     int32_t valid;
     int32_t pad;
+    // opt-in (tinsel_hip_set_probe_sampling): alias table over the W*H texels, entry k = { probability of keeping k
+    // (float bits), the texel to take otherwise }; null: the reference's two binary searches (probe.h:205-236)
+    const uint2* alias;
 };
 
 struct DevScene

@@ -89,6 +89,7 @@ def load_library():
     L.tinsel_hip_walked_prims.argtypes = [vp]
     L.tinsel_hip_set_lookahead.argtypes = [vp, ci]
     L.tinsel_hip_refit_mesh.argtypes = [vp, ci, vp, ci, vp]
+    L.tinsel_hip_set_probe_sampling.argtypes = [vp, ci]
     L.tinsel_hip_set_arithmetic.argtypes = [vp, ci]
     L.tinsel_hip_get_arithmetic.argtypes = [vp]
     L.tinsel_hip_group_create.restype = vp
@@ -115,7 +116,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
     "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
     "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_russian_roulette", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
-    "tinsel_hip_walked_prims", "tinsel_hip_set_lookahead", "tinsel_hip_set_arithmetic", "tinsel_hip_get_arithmetic", "tinsel_hip_refit_mesh",
+    "tinsel_hip_walked_prims", "tinsel_hip_set_lookahead", "tinsel_hip_set_arithmetic", "tinsel_hip_get_arithmetic", "tinsel_hip_refit_mesh", "tinsel_hip_set_probe_sampling",
     "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
     "tinsel_hip_group_size", "tinsel_hip_group_member",
 ]
@@ -249,6 +250,10 @@ class HipRenderer:
             nptr = normals.ctypes.data_as(C.c_void_p)
         _check(self._L.tinsel_hip_refit_mesh(self._h, int(primitive), positions.ctypes.data_as(C.c_void_p), int(positions.shape[0]), nptr),
                "tinsel_hip_refit_mesh")
+
+    def set_probe_sampling(self, mode):
+        """abi.PROBE_CDF (the reference's binary searches: sample-identical) or abi.PROBE_ALIAS (O(1) alias table: same distribution)."""
+        _check(self._L.tinsel_hip_set_probe_sampling(self._h, int(mode)), "tinsel_hip_set_probe_sampling")
 
     def set_lookahead(self, on):
         """Trace the next call's passes while this call's image is copied out (tinsel_hip_set_lookahead); images unchanged."""
