@@ -819,7 +819,16 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     else
     {
         const bool walk = walk_records(r) != nullptr;
-        const uint32_t ldsTrace = a.ldsBytes, ldsShade = r->scene.allInArena ? r->scene.arenaBytes : r->scene.arenaLdsBytes;
+        // every mesh primitive walked by k_walk: the scan kernels run their lean variants with the scene-level stack only
+        static const bool noLeanScan = getenv("TINSEL_HIP_NO_LEAN_SCAN") != nullptr;
+        int meshPrims = 0;
+        for (int m : r->primMesh)
+            meshPrims += m >= 0 ? 1 : 0;
+        const bool walkedOnly = walk && !noLeanScan && meshPrims == r->walkPrims.count && !r->scene.allInArena;
+        const int stackScan = walkedOnly ? std::max(1, pick_stack(r->sceneStackNeed)) : r->stackNeed;
+        const uint32_t ldsTrace = walkedOnly ? (uint32_t)(((size_t)stackScan*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes) : a.ldsBytes;
+        const uint32_t ldsShade = r->scene.allInArena ? r->scene.arenaBytes : r->scene.arenaLdsBytes;
+        a.walkedOnly = walkedOnly ? 1 : 0;
         {
             ScopedTimer t(r, KN_GENERATE, st);
             a.grid = gridPersist;
@@ -840,6 +849,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 ScopedTimer t(r, KN_EXTEND, st);
                 a.grid = gridTrace;
                 a.ldsBytes = ldsTrace;
+                a.stackEntries = stackScan;
                 a.queueIn = qin;
                 launch_path(r, PK_EXTEND, a, st);
             }
@@ -861,6 +871,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 ScopedTimer t(r, KN_SHADOW, st);
                 a.grid = gridTrace;
                 a.ldsBytes = ldsTrace;
+                a.stackEntries = stackScan;
                 a.queueIn = r->queueNee;
                 launch_path(r, PK_SHADOW, a, st);
             }

@@ -284,7 +284,7 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
     const DevMesh m = sc.meshes[p.mesh];
     const Tri48* mtris = mesh_tris(sc, m);
     MeshHit h;
-    if (!COUNT && sc.walkRec != nullptr && (p.flags & kPrimWalked))
+    if (SC::kWalkedOnly || (!COUNT && sc.walkRec != nullptr && (p.flags & kPrimWalked)))
     {
         // the mesh-space closest hit of this (ray, primitive) was computed by k_walk with the same ray_mesh arithmetic
         // on the same lo / ld (tn_walk.h); t == FLT_MAX marks "no hit" (ray_mesh's own `closestT < FLT_MAX`)
@@ -297,7 +297,7 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
         h.n = V3(rb.x, rb.y, rb.z);
         h.tri = __float_as_int(rb.w);
     }
-    else if (!ray_mesh<Stack, COUNT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, h, ctr))
+    else if (SC::kWalkedOnly || !ray_mesh<Stack, COUNT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, h, ctr))
         return false;
 
     // interpolate vertex normals (intersection.h:996-1012)

@@ -242,8 +242,8 @@ TN_D void wave_add_stat(unsigned long long* stats, int word, uint32_t v)
 //                 kernel-argument pointers are global, and global + delta would be issued as a global
 //                 load of an LDS aperture address.
 // MUST be reached by every thread of the block.
-template <bool LDS>
-TN_D void stage_scene_lds(SceneT<LDS>& sc, const DevScene& in, uint32_t* ldsWords)
+template <bool LDS, bool WONLY>
+TN_D void stage_scene_lds(SceneT<LDS, WONLY>& sc, const DevScene& in, uint32_t* ldsWords)
 {
     static_cast<DevScene&>(sc) = in;
     unsigned char* lds = reinterpret_cast<unsigned char*>(ldsWords);
@@ -705,13 +705,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q
 // ---------------------------------------------------------------------------
 // k_extend: closest hit for every queued path
 
-template <bool COUNT, bool LDS>
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce, int stackEntries,
+// WONLY: every mesh of the scene is walked by k_walk: the kernel is the flat scan + record reads, built for more waves
+#ifndef TN_WAVES_SCAN
+#define TN_WAVES_SCAN 6
+#endif
+template <bool COUNT, bool LDS, bool WONLY = false>
+__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_extend(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce, int stackEntries,
                                                                   uint32_t queueCapacity, const float4* __restrict__ walkRec, uint32_t walkPrims)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
-    SceneT<LDS> sc;
+    SceneT<LDS, WONLY> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
     const uint32_t frontCount = q.activeCount[bounce], backCount = q.activeBack[bounce];
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_extend(DevScene scIn
 
             float t;
             V3 n;
-            const int prim = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, n, ctr);
+            const int prim = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, n, ctr);
 
             ps.hit[slot] = make_float4(t, n.x, n.y, n.z);
             ps.hitPrim[slot] = prim;
@@ -885,13 +889,13 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
 // k_shadow: SampleLights, part 2 (render.cpp:118-139, 171-224): one thread per path resolves
 // its K shadow rays in the oracle's order, then totalRadiance += pathThroughput*sum (render.cpp:314)
 
-template <bool COUNT, bool LDS>
-__global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce, int stackEntries,
+template <bool COUNT, bool LDS, bool WONLY = false>
+__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_shadow(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce, int stackEntries,
                                                                   uint32_t queueCapacity, const float4* __restrict__ walkRec, uint32_t walkPrims)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
-    SceneT<LDS> sc;
+    SceneT<LDS, WONLY> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
     const uint32_t frontCount = q.neeCount[bounce], backCount = q.neeBack[bounce];
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_shadow(DevScene scIn
                 float t;
                 V3 n;
                 sc.walkItem = (idx*(uint32_t)ps.neePerPath + (uint32_t)k)*walkPrims;
-                const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, time, t, n, ctr);
+                const int hp = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, time, t, n, ctr);
                 rays++;
                 if (r.dist < 0.0f)
                     return (hp < 0) ? r.f : V3(0.0f);       // probe sample: contributes iff unoccluded

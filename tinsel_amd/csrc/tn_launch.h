@@ -36,6 +36,7 @@ struct LaunchArgs
     BinPrims bins;                  // primitives whose leaf-box test sorts the queues
     WalkJob walk;                   // PK_WALK
     int walkBig;                    // PK_WALK: 1024-thread workgroups with an LDS-resident tree top, else 256-thread ones
+    int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
     int bounce;
     int stackEntries;
     int countDetail;                // detail counters on: the COUNT kernel variants
@@ -58,10 +59,16 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             if (count) { if (lds) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__); } \
             else       { if (lds) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); } \
         } while (0)
-        TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+        if (a.walkedOnly && !count && !lds)
+            hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+        else
+            TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
         break;
     case PK_SHADOW:
-        TN_LAUNCH2(k_shadow, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+        if (a.walkedOnly && !count && !lds)
+            hipLaunchKernelGGL((k_shadow<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+        else
+            TN_LAUNCH2(k_shadow, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
         break;
     case PK_MEGA:
         TN_LAUNCH2(k_mega, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.cam, a.fp, a.passSeeds, a.stackEntries);

@@ -167,10 +167,13 @@ struct DevScene
 // Compile-time view of where the scene lives.  SceneT<true>: the whole scene (arena incl. every mesh)
 // has been staged into LDS and all accessors resolve to LDS addresses at compile time (ds_read);
 // SceneT<false>: generic pointers (HBM, or an LDS copy reached through flat loads).
-template <bool LDS>
+// WALKED_ONLY: every mesh primitive of the scene has its closest hits precomputed by k_walk (tn_walk.h), so the scan
+// kernels are compiled without the inline mesh walk (no deep stack, half the registers, twice the waves).
+template <bool LDS, bool WALKED_ONLY = false>
 struct SceneT : DevScene
 {
     static constexpr bool kLds = LDS;
+    static constexpr bool kWalkedOnly = WALKED_ONLY;
     const unsigned char* ldsBase;
     // closest-hit records of the walked primitives for the ray being traced (tn_walk.h): record lane kb of the ray
     // lives at walkRec[(walkItem + kb)*2 .. +1]; null = walk the mesh inline (ray_mesh)
