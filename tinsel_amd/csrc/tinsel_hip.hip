@@ -608,7 +608,7 @@ LaunchArgs batch_args(tinsel_hip* r, const CameraParams& cam, const FrameParams&
 void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* queue, const uint32_t* frontCount, bool shadowRays)
 {
     static const int gridMult = getenv("TINSEL_HIP_WALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_WALK_GRID_MULT")) : 1;
-    static const int refillMin = getenv("TINSEL_HIP_WALK_REFILL") ? atoi(getenv("TINSEL_HIP_WALK_REFILL")) : 16;
+    static const int refillMin = getenv("TINSEL_HIP_WALK_REFILL") ? atoi(getenv("TINSEL_HIP_WALK_REFILL")) : 24;
     static const int leafMin = getenv("TINSEL_HIP_WALK_LEAFMIN") ? atoi(getenv("TINSEL_HIP_WALK_LEAFMIN")) : 8;
     static const int topLimit = getenv("TINSEL_HIP_WALK_TOP") ? atoi(getenv("TINSEL_HIP_WALK_TOP")) : 1 << 20;      // nodes; 0: no staged top (A/B)
     static const int forceBlock = getenv("TINSEL_HIP_WALK_BLOCK") ? atoi(getenv("TINSEL_HIP_WALK_BLOCK")) : 0;

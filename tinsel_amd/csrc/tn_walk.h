@@ -164,6 +164,20 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     }
     __syncthreads();
 
+    // ONE walked primitive (the common case): its record, leaf box and mesh table entry are wave-uniform -- read once, not
+    // behind every refill's ray fetch (the refill is a chain of dependent loads: queue -> slot -> ray -> [box, primitive,
+    // mesh]; the last three were a third of it)
+    const bool single = job.numPrims == 1;
+    Prim64 prim0 = load_prim(sc.prims, job.prim[0]);
+    float4 box0a, box0b;
+    {
+        const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + job.prim[0]);
+        box0a = bp[0]; box0b = bp[1];
+    }
+    const DevMesh* mesh0p = sc.meshes + prim0.mesh;
+    GlobalF4 mesh0nodes = as_global(mesh0p->nodes), mesh0tris = as_global(mesh0p->tris);
+    const uint32_t mesh0root = mesh0p->root;
+
     // per-lane walk state
     bool active = false;
     uint32_t item = 0, ref = 0;
@@ -250,8 +264,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     }
 
                     // the leaf-box test of the scan (trace_flat / the scene BVH walk): same function, same operands
-                    const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + index);
-                    const float4 b0 = bp[0], b1 = bp[1];
+                    float4 b0 = box0a, b1 = box0b;
+                    if (!single)
+                    {
+                        const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + index);
+                        b0 = bp[0]; b1 = bp[1];
+                    }
                     const V3 wrcp(1.0f/wd.x, 1.0f/wd.y, 1.0f/wd.z);
                     float tbox;
                     bool enters = true;         // rays the scan does not box-test (ray_sane) are walked unconditionally
@@ -265,17 +283,28 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     else
                     {
                         // PrimitiveIntersect's mesh branch up to IntersectRayMesh (intersection.h:977-990)
-                        const Prim64 p = load_prim(sc.prims, index);
+                        Prim64 p = prim0;
+                        if (!single)
+                            p = load_prim(sc.prims, index);
                         const Xform x = prim_pose(sc, p, time);
                         o = inv_xform_point(x, wo);
                         d = inv_xform_vector(x, wd);
                         rcp = V3(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
-                        const DevMesh* m = sc.meshes + p.mesh;
-                        mnodes = as_global(m->nodes);
-                        mtris = as_global(m->tris);
+                        if (single)
+                        {
+                            mnodes = mesh0nodes;
+                            mtris = mesh0tris;
+                            ref = mesh0root;
+                        }
+                        else
+                        {
+                            const DevMesh* m = sc.meshes + p.mesh;
+                            mnodes = as_global(m->nodes);
+                            mtris = as_global(m->tris);
+                            ref = m->root;
+                        }
                         topBase = tb;
                         topN = tn;
-                        ref = m->root;
                         sp = 0;
                         closestT = kFltMax;
                         htri = -1;
