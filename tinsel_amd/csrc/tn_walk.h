@@ -26,7 +26,9 @@
 // Tried and measured, not kept: XCD-aware range mapping (each XCD a contiguous eighth of the queue so that its L2 holds
 // one patch of the tree: 24.1 -> 29.4 ms; the interleaved ranges already share their working set in TIME), 8 waves per
 // SIMD at 64 VGPRs (spills: 24.8 -> 38.6 ms); node and triangle fetches issued together and waited for once per iteration
-// (no separate triangle phase: 22.5 -> 24.8 ms -- the triangle arithmetic then runs every iteration for ~6 lanes).
+// (no separate triangle phase: 22.5 -> 24.8 ms -- the triangle arithmetic then runs every iteration for ~6 lanes); triangles
+// requested when a lane arrives at a leaf and tested an iteration later with the data in registers (21.1 -> 25.0 ms: the
+// extra iteration of waiting costs more than the second round trip it saves).
 #pragma once
 
 #include "tn_isect.h"
