@@ -28,7 +28,10 @@
 // SIMD at 64 VGPRs (spills: 24.8 -> 38.6 ms); node and triangle fetches issued together and waited for once per iteration
 // (no separate triangle phase: 22.5 -> 24.8 ms -- the triangle arithmetic then runs every iteration for ~6 lanes); triangles
 // requested when a lane arrives at a leaf and tested an iteration later with the data in registers (21.1 -> 25.0 ms: the
-// extra iteration of waiting costs more than the second round trip it saves).
+// extra iteration of waiting costs more than the second round trip it saves); work claimed dynamically instead of static
+// 1/256 ranges, to even out the tail (3.3 of 4 waves per SIMD resident on average) -- per wave in chunks of 1024 items
+// (21.0 -> 24.8 ms) or per workgroup in chunks of 16384 shared through a 64-bit LDS {cursor, end} (25.4 ms): a CU that stays
+// in ONE contiguous part of the queue for the whole launch keeps that part's subtrees in its L1 / its XCD's L2.
 #pragma once
 
 #include "tn_isect.h"
