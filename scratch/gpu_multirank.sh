@@ -1,14 +1,12 @@
 #!/bin/bash
-export TINSEL_BENCH_BACKEND=gloo TINSEL_BENCH_ONE_DEVICE=1
-for n in 2 4; do
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2951$n bench.py --gpus $n --steps 16 --warmup 2 > /tmp/mr.json 2> /tmp/mr.err
-echo "rc=$?"; grep -i "validation\|error\|Traceback" /tmp/mr.err | head -5
-python - <<PY
+# bench.py's N-rank path end to end on ONE device (gloo stand-in for RCCL; validation, not a measurement): N = 2, 4, 8
+cd $GRAFT_REPO_ROOT
+export TINSEL_BENCH_BACKEND=gloo TINSEL_BENCH_ONE_DEVICE=1 HSA_ENABLE_IPC_MODE_LEGACY=0
+for n in 2 4 8; do
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600+n)) bench.py --gpus $n --steps 8 --warmup 2 > /tmp/mr_$n.json 2> /tmp/mr_$n.err
+  echo "N=$n rc=$?"; grep -h "validation" /tmp/mr_$n.err | tail -1; python -c "
 import json
-try:
-    d=json.loads(open('/tmp/mr.json').read().strip().splitlines()[-1])
-    print('n_gpus', d['n_gpus'], 'value', round(d['value'],1), 'ms_per_step', round(d['ms_per_step'],3), d['config']['parallelism'], 'rays/sample', round(d['config']['rays_per_sample'],3), 'cpu', d['cpu_baseline'])
-except Exception as e:
-    print('no json', e); print(open('/tmp/mr.err').read()[-1500:])
-PY
+for l in open('/tmp/mr_$n.json'):
+    if l.startswith('{'):
+        d=json.loads(l); print('  n_gpus', d['n_gpus'], 'value %.1f' % d['value'], 'ms_per_step %.3f' % d['ms_per_step'], d['config']['parallelism'], d['roofline']['kernel_ms'])"
 done
