@@ -291,8 +291,8 @@ struct DeviceArena
 };
 
 const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals", "k_bounce",
-                               "k_present", "k_nlm_means", "k_nlm", "k_walk" };
-enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_WALK, KN_COUNT };
+                               "k_present", "k_nlm_means", "k_nlm", "k_walk", "k_lights" };
+enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_WALK, KN_LIGHTS, KN_COUNT };
 
 struct TimedSpan { int kernel; hipEvent_t start, stop; };
 
@@ -345,7 +345,13 @@ struct tinsel_hip
     uint32_t* ctlBase = nullptr;
     size_t ctlWords = 0;
     uint32_t* queues[2] = { nullptr, nullptr };
-    uint32_t* queueNee = nullptr;
+    // the split pipeline's dense state (SplitState, tn_kernels.h), allocated when that pipeline first runs
+    SplitState ss;
+    bool batchSplit = false;            // ss is allocated for the current batch buffers
+    size_t splitCap = 0;                // positions per SplitState array: the batch slots + one wave of padding per region
+    uint32_t splitMaxRegions = 0;
+    uint32_t* walkList = nullptr;       // k_walk's work list (k_seg_expand) and the prefix of the regions' front counts behind it
+    uint32_t* segPrefix = nullptr;
     BinPrims binPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };
     BinPrims walkPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };   // the subset of binPrims whose closest hits k_walk computes (large trees)
     int walkPrimMesh[7] = { 0, 0, 0, 0, 0, 0, 0 };         // DevScene::meshes index of each walked primitive
@@ -359,6 +365,8 @@ struct tinsel_hip
     unsigned long long* statsDev = nullptr;
 
     size_t lastBatchSlots = 0;
+    int lastPipeline = TINSEL_PIPELINE_WAVEFRONT;   // of the last batch (queue_counts)
+    uint32_t lastRegions = 0;
     size_t maxBatchSlots = 8u << 20;
     bool batchSlotsExplicit = false;     // set by TINSEL_HIP_BATCH_PATHS / tinsel_hip_set_batch_paths
     int pipeline = TINSEL_PIPELINE_AUTO;
@@ -401,6 +409,7 @@ void free_batch(tinsel_hip* r)
         (void)hipFree(p);
     r->batchAllocs.clear();
     r->walkRec = nullptr;
+    r->batchSplit = false;
     r->batchSlots = 0;
     r->batchNee = -1;
     r->batchDepth = -1;
@@ -416,26 +425,80 @@ int batch_alloc(tinsel_hip* r, T** out, size_t count)
     return 0;
 }
 
+// blocks per CU of the streaming kernels' fixed grid.  Swept 4..256 on every config: 32 is best everywhere (finer static
+// ranges even out the tail; beyond 64 the per-block staging and the shorter ranges cost more than they give)
+int grid_mult()
+{
+    static const int m = getenv("TINSEL_HIP_GRID_MULT") ? std::max(1, atoi(getenv("TINSEL_HIP_GRID_MULT"))) : 32;
+    return m;
+}
+
+int resolve_pipeline(const tinsel_hip* r)
+{
+    if (r->pipeline != TINSEL_PIPELINE_AUTO)
+        return r->pipeline;
+    // measured fused -> split, Msamples/s: 1 NEE ray per bounce cornell 2588 -> 1630; 2 rays cornell+probe 1840 -> 1375,
+    // env_loft 3008 -> 2443; 4 rays veach 1304 -> 1340; 9 rays features 540 -> 668
+    return (r->scene.allInArena && r->neePerPath <= 2) ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
+}
+
+// The split pipeline's state (SplitState, tn_kernels.h): by POSITION, two buffers of everything a bounce rewrites
+int alloc_split(tinsel_hip* r, size_t slots, int maxDepth)
+{
+    const size_t K = (size_t)r->neePerPath;
+    const size_t maxRegions = (size_t)r->numCUs*(size_t)grid_mult()*(kBlock/kWave);
+    const size_t cap = slots + maxRegions*kWave;        // a region is a whole number of waves long
+    SplitState& ss = r->ss;
+    memset(&ss, 0, sizeof(ss));
+    for (int b = 0; b < 2; ++b)
+        if (batch_alloc(r, &ss.rayO[b], cap) || batch_alloc(r, &ss.rayD[b], cap) || batch_alloc(r, &ss.thr[b], cap) ||
+            batch_alloc(r, &ss.rad[b], cap) || batch_alloc(r, &ss.absorb[b], r->scene.hasMedia ? cap : 1) || batch_alloc(r, &ss.rngId[b], cap))
+            return -1;
+    if (batch_alloc(r, &ss.hit, cap) || batch_alloc(r, &ss.hitPrim, cap) || batch_alloc(r, &ss.pathNee, K ? cap : 1) ||
+        batch_alloc(r, &ss.neeRay, cap*K*2) || batch_alloc(r, &ss.neeSky, r->scene.probe.valid ? cap : 1) ||
+        batch_alloc(r, &ss.neeMeta, K ? cap : 1) || batch_alloc(r, &ss.neeRes, cap*K) ||
+        batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)) ||
+        batch_alloc(r, &ss.neeFront, maxRegions*(size_t)maxDepth) || batch_alloc(r, &ss.neeBack, maxRegions*(size_t)maxDepth))
+        return -1;
+    ss.radOut = r->ps.rad;
+    ss.neePerPath = (int32_t)K;
+    ss.capacity = (uint32_t)cap;
+    r->splitCap = cap;
+    r->splitMaxRegions = (uint32_t)maxRegions;
+    // k_walk: one 32-B closest hit per (ray, walked primitive), by position; extension and shadow rays share the buffer
+    r->walkRec = nullptr;
+    r->walkList = nullptr;
+    r->segPrefix = nullptr;
+    if (r->walkPrims.count > 0 && r->walkEnabled && (double)cap*(K > 1 ? K : 1)*r->walkPrims.count < 2147483648.0)
+        if (batch_alloc(r, &r->walkRec, cap*(size_t)(K > 1 ? K : 1)*(size_t)r->walkPrims.count*2) || batch_alloc(r, &r->walkList, cap) ||
+            batch_alloc(r, &r->segPrefix, maxRegions + 1))
+            return -1;
+    return 0;
+}
+
 int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
 {
     const int K = r->neePerPath;
-    if (r->batchSlots >= slots && r->batchNee == K && r->batchDepth >= maxDepth)
+    const bool split = resolve_pipeline(r) == TINSEL_PIPELINE_WAVEFRONT_SPLIT;
+    if (r->batchSlots >= slots && r->batchNee == K && r->batchDepth >= maxDepth && r->batchSplit == split)
         return 0;
     free_batch(r);
 
+    // the radiance of finished paths by slot is what every pipeline hands to the accumulate kernels; the rest of the
+    // by-slot state belongs to the fused and megakernel pipelines
     PathState& ps = r->ps;
-    if (batch_alloc(r, &ps.rayO, slots) || batch_alloc(r, &ps.rayD, slots) || batch_alloc(r, &ps.thr, slots) ||
-        batch_alloc(r, &ps.rad, slots) || batch_alloc(r, &ps.absorb, slots) || batch_alloc(r, &ps.rngRaster, slots) ||
-        batch_alloc(r, &ps.hit, slots) || batch_alloc(r, &ps.hitPrim, slots) ||
-        batch_alloc(r, &ps.nee, slots*(size_t)K*4) || batch_alloc(r, &ps.neeThr, slots) ||
-        batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots) || batch_alloc(r, &r->queueNee, slots))
+    memset(&ps, 0, sizeof(ps));
+    if (batch_alloc(r, &ps.rad, slots))
         return -1;
-    ps.neePerPath = K;
-    // k_walk records: one 32-B closest hit per (queued ray, walked primitive); extension and shadow rays share the buffer
-    r->walkRec = nullptr;
-    if (r->walkPrims.count > 0 && r->walkEnabled && (double)slots*(K > 1 ? K : 1)*r->walkPrims.count < 2147483648.0)
-        if (batch_alloc(r, &r->walkRec, slots*(size_t)(K > 1 ? K : 1)*(size_t)r->walkPrims.count*2))
+    if (split)
+    {
+        if (alloc_split(r, slots, maxDepth))
             return -1;
+    }
+    else if (batch_alloc(r, &ps.rayO, slots) || batch_alloc(r, &ps.rayD, slots) || batch_alloc(r, &ps.thr, slots) ||
+             batch_alloc(r, &ps.absorb, slots) || batch_alloc(r, &ps.rngRaster, slots) ||
+             batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots))
+        return -1;
 
     // slots of other shards are never written (gen_slot): keep their radiance at zero for the test hook
     HIP_TRY(hipMemset(ps.rad, 0, sizeof(float4)*slots));
@@ -456,6 +519,7 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
     r->batchSlots = slots;
     r->batchNee = K;
     r->batchDepth = maxDepth;
+    r->batchSplit = split;
     return 0;
 }
 
@@ -591,7 +655,6 @@ LaunchArgs batch_args(tinsel_hip* r, const CameraParams& cam, const FrameParams&
     a.cam = cam;
     a.fp = fp;
     a.passSeeds = r->passSeedsDev;
-    a.queueNee = r->queueNee;
     a.walkRec = walk_records(r);
     a.walkPrims = (uint32_t)r->walkPrims.count;
     a.bins = noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims;
@@ -605,7 +668,7 @@ LaunchArgs batch_args(tinsel_hip* r, const CameraParams& cam, const FrameParams&
 // One 1024-thread workgroup per CU whose LDS holds the traversal stacks and, in what is left of the 160 KB, the top of
 // the walked trees; trees too deep for that (a device-built LBVH of 524k triangles: 48 entries per lane) run 256-thread
 // workgroups without a staged top.
-void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* queue, const uint32_t* frontCount, bool shadowRays)
+void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* regionCounts, bool shadowRays)
 {
     static const int gridMult = getenv("TINSEL_HIP_WALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_WALK_GRID_MULT")) : 1;
     static const int refillMin = getenv("TINSEL_HIP_WALK_REFILL") ? atoi(getenv("TINSEL_HIP_WALK_REFILL")) : 24;
@@ -618,12 +681,18 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* qu
         tinsel_fast_prepare_path_kernels(r->sharedMemLimit);
         r->pathKernelsPrepared = true;
     }
+    // the work list: the front entries of every region (paths / shadow-ray bundles whose ray enters a walked mesh's box)
+    const SplitState& ss = a.ss;
+    hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, regionCounts, ss.numRegions, r->segPrefix);
+    hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
     WalkJob& job = a.walk;
-    job.queue = queue;
-    job.frontCount = frontCount;
-    job.rayO = r->ps.rayO;
-    job.rayD = r->ps.rayD;
-    job.nee = r->ps.nee;
+    job.queue = r->walkList;
+    job.frontCount = r->segPrefix + ss.numRegions;
+    job.rayO = ss.rayO[a.bounce & 1];
+    job.rayD = ss.rayD[a.bounce & 1];
+    job.nee = ss.neeRay;
+    job.neeStride = ss.capacity;
+    job.neeMeta = ss.neeMeta;
     job.rec = r->walkRec;
     job.neePerPath = shadowRays ? r->neePerPath : 0;
     job.numPrims = r->walkPrims.count;
@@ -658,7 +727,7 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* qu
             lds += (size_t)n*sizeof(Node64);
         }
     }
-    const size_t items = r->batchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1)*(size_t)r->walkPrims.count;
+    const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1)*(size_t)r->walkPrims.count;
     const int perCU = big ? gridMult : gridMult*4;
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
     a.walkBig = big ? 1 : 0;
@@ -761,7 +830,7 @@ int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, floa
     else
     {
         const int gridPix = (int)((npix + kBlock - 1)/kBlock);
-        hipLaunchKernelGGL(k_accumulate, dim3(gridPix), dim3(kBlock), 0, st, r->ps, fp, target);
+        hipLaunchKernelGGL(k_accumulate, dim3(gridPix), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -782,20 +851,17 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     fp.rrStart = r->rrStart;
     fp.queueCapacity = (uint32_t)r->batchSlots;
     const int gridFlat = (int)std::max<size_t>(1, (slots + kBlock - 1)/kBlock);
-    // blocks per CU of the streaming kernels' fixed grid.  Swept 4..256 on every config: 32 is best everywhere (finer
-    // static ranges even out the tail; beyond 64 the per-block staging and the shorter ranges cost more than they give)
-    static const int gridMult = getenv("TINSEL_HIP_GRID_MULT") ? atoi(getenv("TINSEL_HIP_GRID_MULT")) : 32;
+    const int gridMult = grid_mult();
     const int gridPersist = (int)std::max<size_t>(1, std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMult));
     static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : gridMult;
     const int gridTrace = (int)std::max<size_t>(1, std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMultTrace));
     HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
     r->lastBatchSlots = slots;
 
-    int pipeline = r->pipeline;
-    if (pipeline == TINSEL_PIPELINE_AUTO)
-        // measured fused -> split, Msamples/s: 1 NEE ray per bounce cornell 2588 -> 1630; 2 rays cornell+probe 1840 -> 1375,
-        // env_loft 3008 -> 2443; 4 rays veach 1304 -> 1340; 9 rays features 540 -> 668
-        pipeline = (r->scene.allInArena && r->neePerPath <= 2) ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
+    const int pipeline = resolve_pipeline(r);
+    if ((pipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT) != r->batchSplit)
+        return fail("render: path buffers were reserved for another pipeline");
+    r->lastPipeline = pipeline;
 
     LaunchArgs a = batch_args(r, cam, fp);
     if (pipeline == TINSEL_PIPELINE_MEGAKERNEL)
@@ -829,51 +895,60 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         const uint32_t ldsTrace = walkedOnly ? (uint32_t)(((size_t)stackScan*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes) : a.ldsBytes;
         const uint32_t ldsShade = r->scene.allInArena ? r->scene.arenaBytes : r->scene.arenaLdsBytes;
         a.walkedOnly = walkedOnly ? 1 : 0;
+        // one region per wave of the streaming grid (SplitState, tn_kernels.h)
+        a.ss = r->ss;
+        a.ss.numRegions = (uint32_t)gridPersist*(kBlock/kWave);
+        a.ss.regionLen = (uint32_t)(((slots + a.ss.numRegions - 1)/a.ss.numRegions + kWave - 1)/kWave*kWave);
+        if (a.ss.numRegions > r->splitMaxRegions || (size_t)a.ss.numRegions*a.ss.regionLen > r->splitCap)
+            return fail("render: split-pipeline buffers too small for this batch");
+        r->lastRegions = a.ss.numRegions;
+        const size_t W = a.ss.numRegions;
         {
             ScopedTimer t(r, KN_GENERATE, st);
             a.grid = gridPersist;
-            a.queueOut = r->queues[0];
             launch_path(r, PK_GENERATE, a, st);
         }
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
-            uint32_t* qin = r->queues[bounce & 1];
-            uint32_t* qout = r->queues[(bounce + 1) & 1];
             a.bounce = bounce;
             if (walk)
             {
                 ScopedTimer t(r, KN_WALK, st);
-                launch_walk(r, st, a, qin, r->ctl.activeCount + bounce, false);
+                a.grid = gridPersist;
+                launch_walk(r, st, a, r->ss.segFront + (size_t)bounce*W, false);
             }
             {
                 ScopedTimer t(r, KN_EXTEND, st);
                 a.grid = gridTrace;
                 a.ldsBytes = ldsTrace;
                 a.stackEntries = stackScan;
-                a.queueIn = qin;
                 launch_path(r, PK_EXTEND, a, st);
-            }
-            {
-                ScopedTimer t(r, KN_SHADE, st);
-                a.grid = gridPersist;
-                a.ldsBytes = ldsShade;
-                a.queueIn = qin;
-                a.queueOut = qout;
-                launch_path(r, PK_SHADE, a, st);
             }
             if (r->neePerPath > 0)
             {
+                {
+                    ScopedTimer t(r, KN_LIGHTS, st);
+                    a.grid = gridPersist;
+                    a.ldsBytes = ldsShade;
+                    launch_path(r, PK_LIGHTS, a, st);
+                }
                 if (walk)
                 {
                     ScopedTimer t(r, KN_WALK, st);
-                    launch_walk(r, st, a, r->queueNee, r->ctl.neeCount + bounce, true);
+                    a.grid = gridPersist;
+                    launch_walk(r, st, a, r->ss.neeFront + (size_t)bounce*W, true);
                 }
                 ScopedTimer t(r, KN_SHADOW, st);
                 a.grid = gridTrace;
                 a.ldsBytes = ldsTrace;
                 a.stackEntries = stackScan;
-                a.queueIn = r->queueNee;
                 launch_path(r, PK_SHADOW, a, st);
+            }
+            {
+                ScopedTimer t(r, KN_SHADE, st);
+                a.grid = gridPersist;
+                a.ldsBytes = ldsShade;
+                launch_path(r, PK_SHADE, a, st);
             }
         }
     }
@@ -2303,6 +2378,47 @@ int tinsel_hip_leaf(tinsel_hip* r, int op, int index, int n, const float* in, in
 int tinsel_hip_stack_entries(tinsel_hip* r) { return r ? r->stackNeed : 0; }
 int tinsel_hip_walked_prims(tinsel_hip* r) { return (r && r->walkEnabled) ? r->walkPrims.count : 0; }
 int tinsel_hip_nee_per_path(tinsel_hip* r) { return r ? r->neePerPath : 0; }
+
+int tinsel_hip_queue_counts(tinsel_hip* r, uint32_t* out, int max_bounces)
+{
+    if (!r || !out || max_bounces < 1)
+        return fail("queue_counts: bad arguments");
+    if (!r->ctlBase || r->batchDepth < 1)
+        return fail("queue_counts: nothing rendered yet");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int n = std::min(max_bounces, std::min(r->batchDepth, r->lastFp.maxDepth));
+    if (r->lastPipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT && r->batchSplit)
+    {
+        // the split pipeline keeps its counts per region
+        const size_t W = r->lastRegions;
+        std::vector<uint32_t> seg(W*(size_t)n*4);
+        uint32_t* const src[4] = { r->ss.segFront, r->ss.segBack, r->ss.neeFront, r->ss.neeBack };
+        for (int a = 0; a < 4; ++a)
+            HIP_TRY(hipMemcpy(seg.data() + (size_t)a*W*n, src[a], W*(size_t)n*sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int b = 0; b < n; ++b)
+        {
+            unsigned long long live = 0, nee = 0;
+            for (size_t g = 0; g < W; ++g)
+            {
+                live += seg[(size_t)b*W + g] + seg[W*n + (size_t)b*W + g];
+                nee += seg[2*W*n + (size_t)b*W + g] + seg[3*W*n + (size_t)b*W + g];
+            }
+            out[b] = (uint32_t)live;
+            out[max_bounces + b] = r->neePerPath > 0 ? (uint32_t)nee : 0u;
+        }
+        return n;
+    }
+    std::vector<uint32_t> ctl(r->ctlWords);
+    HIP_TRY(hipMemcpy(ctl.data(), r->ctlBase, r->ctlWords*sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const size_t D = (size_t)r->batchDepth + 1;
+    for (int b = 0; b < n; ++b)
+    {
+        out[b] = ctl[(size_t)b] + ctl[5*D + (size_t)b];
+        out[max_bounces + b] = ctl[D + (size_t)b] + ctl[6*D + (size_t)b];
+    }
+    return n;
+}
 
 // ---------------------------------------------------------------------------
 // scene packs

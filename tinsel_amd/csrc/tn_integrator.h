@@ -5,8 +5,8 @@
 //
 //   PathTrace loop body (render.cpp:250-385):
 //     on_hit_begin   :255-310   medium bookkeeping, Beer-Lambert, emission with BSDF-side MIS
-//     nee_*          :103-227   SampleLights split into  prepare (RNG + BSDF terms, before the
-//                               shadow trace)  and  resolve (after it)
+//     nee_*          :103-227   SampleLights split into  sample (RNG draws + the shadow ray, before the
+//                               trace)  and  contrib (BSDF terms + MIS, after it, for the rays that arrive)
 //     bsdf_step      :322-363   light-hit termination, BSDFSample/BSDFEval, throughput, next ray
 //     on_miss        :365-384   sky / probe with MIS
 #pragma once
@@ -107,17 +107,16 @@ TN_D void on_hit_begin(PathRegs& p, const Mat& mat, float t, V3 n, int bounce, H
     }
 }
 
-// One NEE shadow ray: everything SampleLights knows BEFORE its Trace() call.
-struct NeeRec
+// One NEE shadow ray: what SampleLights knows BEFORE its Trace() call and without the BSDF -- the RNG draws and the
+// geometry of the sample.  The BSDF terms of the sample (render.cpp:198-199, :127-128) are pure functions of the hit
+// and of `wi`: they are evaluated AFTER the trace, only for the samples that reach their light (nee_contrib_*), which
+// is the oracle's own order (render.cpp:171-219) and the same floats.
+struct NeeGeo
 {
     V3 o;               // shadow origin
     V3 wi;
     float dist;         // sqrtf(dSq) for area lights; < 0 marks a probe sample
     float nl;           // |dot(lightNormal, wi)|
-    V3 f;               // BSDFEval toward wi   (probe: the finished contribution if unoccluded)
-    float bsdfPdf;
-    float absDot;       // |dot(wi, shadingNormal)|
-    int light;          // light primitive index
 };
 
 // PrimitiveSample (intersection.h:855-904) for light `prim`
@@ -170,90 +169,99 @@ TN_D void primitive_sample(const SC& sc, int index, float time, V3& pos, V3& nor
     // planes are never lights (PrimitiveSample asserts, intersection.h:871-875)
 }
 
-// render.cpp:158-170 + the BSDF terms of :198-199 (pure functions, hoisted above the trace)
+// render.cpp:158-170: sample a point of `light`, the shadow ray towards it
 template <class SC>
-TN_D void nee_prepare_light(const SC& sc, const Mat& surf, const HitCtx& h, float time, int light, Rng& rng, NeeRec& r)
+TN_D void nee_sample_light(const SC& sc, V3 hitP, V3 hitN, float time, int light, Rng& rng, NeeGeo& g)
 {
     V3 lightPos, lightNormal;
     primitive_sample(sc, light, time, lightPos, lightNormal, rng);
 
-    V3 wi = lightPos - h.p;
+    V3 wi = lightPos - hitP;
     float dSq = length_sq(wi);
     wi = divs(wi, sqrtf(dSq));                  // wi /= sqrtf(dSq)  (maths.h:251)
 
-    r.o = h.p + face_forward(h.n, wi)*kRayEpsilon;
-    r.wi = wi;
-    r.dist = sqrtf(dSq);
-    r.nl = absf(dot(lightNormal, wi));
-    r.bsdfPdf = bsdf_pdf(surf, h.etaI, h.etaO, h.n, h.wo, wi);
-    r.f = bsdf_eval(surf, h.etaI, h.etaO, h.n, h.wo, wi);
-    r.absDot = absf(dot(wi, h.n));
-    r.light = light;
+    g.o = hitP + face_forward(hitN, wi)*kRayEpsilon;
+    g.wi = wi;
+    g.dist = sqrtf(dSq);
+    g.nl = absf(dot(lightNormal, wi));
 }
 
-// render.cpp:175-219: the part after Trace().  `hitPrim` < 0 means the shadow ray missed.
-TN_D V3 nee_resolve_light(const DevScene& sc, const NeeRec& r, int hitPrim, float t)
+// render.cpp:175-196, the tests between Trace() and the BSDF: does the shadow ray (closest hit `hitPrim` at `t`) reach
+// its light sample?
+TN_D bool nee_light_reached(const NeeGeo& g, int hitPrim, float t)
+{
+    const float kTolerance = 1.e-2f;
+    return hitPrim >= 0 && fabsf(t - g.dist) <= kTolerance && !(absf(g.nl) < 1.e-6f);
+}
+
+// render.cpp:196-219 for a sample that reached its light: MIS weight, BSDFPdf / BSDFEval toward wi, the contribution
+TN_D V3 nee_contrib_light(const DevScene& sc, const Mat& surf, const HitCtx& h, V3 wi, float nl, int light, int hitPrim, float t)
 {
     V3 L(0.0f);
-    if (hitPrim < 0)
-        return L;
+    const Mat128* lm = sc.mats + light;
+    const float lightArea = lm->area;
+    const int lightSamples = lm->lightSamples;
+    float tSq = t*t;
+    float lightPdf = ((1.0f/lightArea)*tSq)/nl;
 
-    const float kTolerance = 1.e-2f;
-    if (fabsf(t - r.dist) <= kTolerance)
+    const float bsdfPdf = bsdf_pdf(surf, h.etaI, h.etaO, h.n, h.wo, wi);
+    if (bsdfPdf > 0.0f)
     {
-        if (absf(r.nl) < 1.e-6f)
-            return L;
+        int N = int(float(lightSamples) + kBsdfSamples);
+        float cbsdf = kBsdfSamples/N;
+        float clight = float(lightSamples)/N;
+        float weight = clight*lightPdf/(cbsdf*bsdfPdf + clight*lightPdf);
 
-        const Mat128* lm = sc.mats + r.light;
-        const float lightArea = lm->area;
-        const int lightSamples = lm->lightSamples;
-        float tSq = t*t;
-        float lightPdf = ((1.0f/lightArea)*tSq)/r.nl;
-
-        if (r.bsdfPdf > 0.0f)
-        {
-            int N = int(float(lightSamples) + kBsdfSamples);
-            float cbsdf = kBsdfSamples/N;
-            float clight = float(lightSamples)/N;
-            float weight = clight*lightPdf/(cbsdf*r.bsdfPdf + clight*lightPdf);
-
-            const Mat128* hm = sc.mats + hitPrim;
-            V3 em(hm->emission[0], hm->emission[1], hm->emission[2]);
-            L = weight*r.f*em*(r.absDot/maxT(1.e-3f, lightPdf));
-        }
+        const V3 f = bsdf_eval(surf, h.etaI, h.etaO, h.n, h.wo, wi);
+        const float absDot = absf(dot(wi, h.n));
+        const Mat128* hm = sc.mats + hitPrim;
+        V3 em(hm->emission[0], hm->emission[1], hm->emission[2]);
+        L = weight*f*em*(absDot/maxT(1.e-3f, lightPdf));
     }
     return L;
 }
 
-// render.cpp:107-140: probe sample; the whole contribution is known before the trace
-TN_D void nee_prepare_probe(const DevScene& sc, const Mat& surf, const HitCtx& h, Rng& rng, NeeRec& r)
+// render.cpp:107-116: the probe sample and its shadow ray
+TN_D void nee_sample_probe(const DevScene& sc, V3 hitP, V3 hitN, Rng& rng, NeeGeo& g, V3& skyColor, float& skyPdf)
 {
-    V3 skyColor, wi;
-    float skyPdf;
+    V3 wi;
     probe_sample(sc.probe, wi, skyColor, skyPdf, rng);
 
-    r.o = h.p + face_forward(h.n, wi)*kRayEpsilon;
-    r.wi = wi;
-    r.dist = -1.0f;
-    r.nl = 0.0f;
-    r.light = -1;
-    r.absDot = 0.0f;
+    g.o = hitP + face_forward(hitN, wi)*kRayEpsilon;
+    g.wi = wi;
+    g.dist = -1.0f;
+    g.nl = 0.0f;
+}
 
+// render.cpp:118-139 for an unoccluded probe sample
+TN_D V3 nee_contrib_probe(const Mat& surf, const HitCtx& h, V3 wi, V3 skyColor, float skyPdf)
+{
+    V3 L(0.0f);
     float bsdfPdf = bsdf_pdf(surf, h.etaI, h.etaO, h.n, h.wo, wi);
-    V3 f = bsdf_eval(surf, h.etaI, h.etaO, h.n, h.wo, wi);
-    r.bsdfPdf = bsdfPdf;
-    r.f = V3(0.0f);
-
     if (bsdfPdf > 0.0f)
     {
+        V3 f = bsdf_eval(surf, h.etaI, h.etaO, h.n, h.wo, wi);
         int N = int(kProbeSamples + kBsdfSamples);
         float cbsdf = kBsdfSamples/N;
         float csky = float(kProbeSamples)/N;
         float weight = csky*skyPdf/(cbsdf*bsdfPdf + csky*skyPdf);
         if (weight > 0.0f)
-            r.f = divs(weight*skyColor*f*absf(dot(wi, h.n)), skyPdf);
+            L = divs(weight*skyColor*f*absf(dot(wi, h.n)), skyPdf);
     }
+    return L;
 }
+
+// Which light does NEE ray k belong to?  Rays arrive in order (probe first, then lights x samples): the cursor walks along.
+struct LightCursor
+{
+    int li = 0, sInLight = 0;
+    TN_D int next(const DevScene& sc)
+    {
+        while (sInLight >= sc.mats[sc.lights[li]].lightSamples) { ++li; sInLight = 0; }
+        ++sInLight;
+        return sc.lights[li];
+    }
+};
 
 // Sums per-light contributions in the oracle's order.  `contrib(k)` returns the resolved
 // contribution of NEE ray k (k counts the probe ray first, then lights x samples).

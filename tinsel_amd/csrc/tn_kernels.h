@@ -37,6 +37,9 @@ namespace tn {
 #ifndef TN_WAVES_SHADE
 #define TN_WAVES_SHADE TN_WAVES_FUSED
 #endif
+#ifndef TN_WAVES_LIGHTS
+#define TN_WAVES_LIGHTS 4
+#endif
 #ifndef TN_WAVES_TRACE
 #define TN_WAVES_TRACE 4
 #endif
@@ -54,11 +57,6 @@ struct PathState
     float4* rad;        // radiance.xyz, rayType (int bits)
     float4* absorb;     // rayAbsorption.xyz, -
     float4* rngRaster;  // rng.s1, rng.s2 (bits), rasterX, rasterY     (rasterX < -1e29: slot not owned by this shard)
-    float4* hit;        // t, n.xyz
-    int32_t* hitPrim;
-    float4* nee;        // [slot*neeStride + 4*k + {0..3}] : {o,dist} {wi,nl} {f,bsdfPdf} {absDot,light,-,-}
-    float4* neeThr;     // throughput at NEE time
-    int32_t neePerPath; // K
 };
 
 struct QueueCtl
@@ -525,32 +523,33 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                 if (sc.totalLightSamples > 0)
                 {
                     const V3 thrAtNee = p.thr;
-                    int li = 0, sInLight = 0;
+                    LightCursor lights;
                     V3 sum = nee_sum(sc, [&](int k) -> V3 {
-                        NeeRec r;
-                        // the 28-register material record is re-read per sample instead of living across the shadow trace
-                        const Mat matK = load_mat(sc.mats, prim);
+                        NeeGeo g;
+                        V3 skyColor;
+                        float skyPdf = 0.0f;
+                        int light = -1;
                         if (sc.probe.valid && k == 0)
-                        {
-                            nee_prepare_probe(sc, matK, h, p.rng, r);
-                        }
+                            nee_sample_probe(sc, h.p, h.n, p.rng, g, skyColor, skyPdf);
                         else
                         {
-                            // NEE rays arrive in order: walk (light, sample) along with k
-                            while (sInLight >= sc.mats[sc.lights[li]].lightSamples) { ++li; sInLight = 0; }
-                            nee_prepare_light(sc, matK, h, p.time, sc.lights[li], p.rng, r);
-                            ++sInLight;
+                            light = lights.next(sc);
+                            nee_sample_light(sc, h.p, h.n, p.time, light, p.rng, g);
                         }
                         TN_TICK(2)
                         float ts;
                         V3 nn;
-                        const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, p.time, ts, nn, TN_CTR_NEE);
+                        const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, g.o, g.wi, p.time, ts, nn, TN_CTR_NEE);
                         TN_TICK(3)
                         rays++;
                         shadowRays++;
-                        if (r.dist < 0.0f)
-                            return (hp < 0) ? r.f : V3(0.0f);
-                        return nee_resolve_light(sc, r, hp, ts);
+                        // the BSDF terms only for the samples that arrive; the 28-register material record is re-read here
+                        // instead of living across the shadow trace
+                        if (light < 0)
+                            return (hp < 0) ? nee_contrib_probe(load_mat(sc.mats, prim), h, g.wi, skyColor, skyPdf) : V3(0.0f);
+                        if (!nee_light_reached(g, hp, ts))
+                            return V3(0.0f);
+                        return nee_contrib_light(sc, load_mat(sc.mats, prim), h, g.wi, g.nl, light, hp, ts);
                     });
                     p.rad = p.rad + thrAtNee*sum;
                 }
@@ -615,9 +614,9 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
 }
 
 // ===========================================================================
-// The SPLIT variant of the pipeline (TINSEL_PIPELINE_WAVEFRONT_SPLIT): the same bounce cut into
-// three kernels with hit / NEE records parked in HBM in between.  Kept as an A/B arm: it trades
-// ~3x the state traffic for smaller kernels (k_extend/k_shadow 132-136 VGPRs vs k_bounce's).
+// The SPLIT variant of the pipeline (TINSEL_PIPELINE_WAVEFRONT_SPLIT): the same bounce cut into k_extend / k_lights /
+// k_shadow / k_shade with hit and shadow-ray records parked in HBM in between: lean trace kernels (and k_walk ahead of
+// them) for scenes with meshes in HBM or many shadow rays per bounce.
 
 // ---------------------------------------------------------------------------
 // Queues sorted by "enters a big mesh" (split pipeline, scenes with a mesh in HBM).  k_shade, which produces the next
@@ -652,98 +651,183 @@ TN_D bool ray_enters_big_mesh(const PrimBox* __restrict__ primBoxes, const BinPr
 }
 
 // ---------------------------------------------------------------------------
-// k_generate
-
-__global__ __launch_bounds__(kBlock, 4) void k_generate(PathState ps, QueueCtl q, uint32_t* queue0, CameraParams cam, FrameParams fp,
-                                                     const uint32_t* __restrict__ passSeeds, const PrimBox* __restrict__ primBoxes, BinPrims bp)
+// Path state of the split pipeline: DENSE.  What bounds its kernels is HBM traffic, and the L2 fetches 128-B lines: a 16-B
+// record read through a queue of sparse (or sorted) slots costs a whole line -- measured on glass, maxDepth 12, the
+// light-sampling kernel went from 25 ps per path at bounce 0 (4.8 TB/s) to 157 ps at bounce 11, 6.6 % of the slots alive.
+// So nothing here is indexed by a path's slot: the batch is cut into one REGION of `regionLen` positions per wave of the
+// grid, and the live paths of a region are PACKED at its two ends -- in front the paths whose ray enters the box of a
+// mesh in HBM (k_walk's work, and waves of the scan kernels that are all-mesh or no-mesh), at the back all others.
+// k_shade reads a path's state at its position in buffer `bounce & 1` and writes the survivor to its new position in the
+// other buffer; positions come from a wave64 ballot, so there is no queue, no atomic and no barrier, and every load and
+// store of every kernel is a run of consecutive 16-B records.  A path carries its slot (the pixel/pass it belongs to)
+// to write its radiance where the accumulate kernels look for it.  A path never leaves its region, so that write stays
+// local too.
+struct SplitState
 {
-    __shared__ uint32_t s_scan[kScanWords];
-    const uint32_t count = fp.genCount;
-    const uint32_t rounds = block_rounds(count);
-    const uint32_t first = blockIdx.x*rounds*kBlock;
-    uint32_t samples = 0;
+    float4* rayO[2];    // [bounce & 1][position]: origin.xyz, time
+    float4* rayD[2];    // dir.xyz, bsdfPdf
+    float4* thr[2];     // throughput.xyz, rayEta
+    float4* rad[2];     // radiance.xyz, rayType (int bits)
+    float4* absorb[2];  // rayAbsorption.xyz, -          (scenes with absorbing media only)
+    float4* rngId[2];   // rng.s1, rng.s2, path slot (bits), -
+    float4* hit;        // [position] this bounce's closest hit: t, n.xyz
+    int32_t* hitPrim;
+    uint32_t* pathNee;  // [position] NEE position q of the path's shadow rays of this bounce
+    float4* neeRay;     // [(k*2 + {0, 1})*capacity + q] = {o, dist} {wi, nl}: lanes are consecutive q        (k_lights -> k_walk, k_shadow, k_shade)
+    float4* neeSky;     // [q] the probe sample's {skyColor, skyPdf}                                           (k_lights -> k_shade)
+    float2* neeMeta;    // [q] {position of the path (bits), rayTime}                                          (k_lights -> k_walk, k_shadow)
+    float2* neeRes;     // [k*capacity + q] = {primitive whose emission arrives (int bits; < 0: nothing does), t}  (k_shadow -> k_shade)
+    float4* radOut;     // [slot] radiance of finished paths (PathState::rad: what the accumulate kernels read)
+    uint32_t* segFront; // [bounce][region] paths packed at the front of the region when the bounce starts
+    uint32_t* segBack;  // [bounce][region] ... at its back
+    uint32_t* neeFront; // [bounce][region] the same for the paths that have shadow rays, by NEE position
+    uint32_t* neeBack;
+    uint32_t numRegions, regionLen;     // regionLen is a multiple of 64
+    uint32_t capacity;  // positions per array
+    int32_t neePerPath; // K
+};
 
-    for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
+TN_D uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// the i-th live entry of a region packed at both ends
+TN_D uint32_t region_pos(uint32_t base, uint32_t len, uint32_t nFront, uint32_t i)
+{
+    return i < nFront ? base + i : base + len - 1u - (i - nFront);
+}
+
+// Appends to the two ends of a region, one wave at a time.  push() must be reached by every lane that is still in the
+// caller's loop (lanes with nothing to append pass keep = false).
+struct RegionAppend
+{
+    uint32_t base, len, nFront, nBack;      // wave-uniform
+    TN_D uint32_t push(bool keep, bool front)
     {
-        const uint32_t base = first + r0*kBlock;
-        const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
-        uint32_t keep = 0, keepBack = 0;
-        for (uint32_t g = 0; g < groups; ++g)
+        const unsigned long long below = (1ull << __lane_id()) - 1ull;
+        const unsigned long long fm = __ballot(keep && front), bm = __ballot(keep && !front);
+        const uint32_t pos = front ? base + nFront + (uint32_t)__popcll(fm & below)
+                                   : base + len - 1u - (nBack + (uint32_t)__popcll(bm & below));
+        nFront += (uint32_t)__popcll(fm);
+        nBack += (uint32_t)__popcll(bm);
+        return pos;
+    }
+};
+
+constexpr uint32_t kRegionsPerBlock = kBlock/kWave;
+
+TN_D void load_state(const SplitState& ss, int buf, uint32_t pos, PathRegs& p, uint32_t& slot, bool hasMedia)
+{
+    const float4 ro = ss.rayO[buf][pos], rd = ss.rayD[buf][pos], th = ss.thr[buf][pos], ra = ss.rad[buf][pos];
+    const float4 ab = hasMedia ? ss.absorb[buf][pos] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 rr = ss.rngId[buf][pos];
+    p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
+    p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
+    p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
+    p.rad = V3(ra.x, ra.y, ra.z); p.rayType = __float_as_int(ra.w);
+    p.absorption = V3(ab.x, ab.y, ab.z);
+    p.rng.s1 = __float_as_uint(rr.x); p.rng.s2 = __float_as_uint(rr.y);
+    slot = __float_as_uint(rr.z);
+}
+
+TN_D void store_state(const SplitState& ss, int buf, uint32_t pos, const PathRegs& p, uint32_t slot, bool hasMedia)
+{
+    ss.rayO[buf][pos] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
+    ss.rayD[buf][pos] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
+    ss.thr[buf][pos] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
+    ss.rad[buf][pos] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
+    if (hasMedia)
+        ss.absorb[buf][pos] = make_float4(p.absorption.x, p.absorption.y, p.absorption.z, 0.0f);
+    ss.rngId[buf][pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), 0.0f);
+}
+
+// ---------------------------------------------------------------------------
+// k_generate: camera paths of the batch into buffer 0; region r takes the generation indices [r*regionLen, (r+1)*regionLen)
+
+__global__ __launch_bounds__(kBlock, 4) void k_generate(SplitState ss, QueueCtl q, CameraParams cam, FrameParams fp,
+                                                     const uint32_t* __restrict__ passSeeds, const PrimBox* __restrict__ primBoxes, BinPrims bp, int hasMedia)
+{
+    const uint32_t lane = __lane_id();
+    uint32_t samples = 0;
+    for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
+    {
+        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        const uint32_t begin = r*ss.regionLen;
+        const uint32_t end = (begin + ss.regionLen) < fp.genCount ? (begin + ss.regionLen) : fp.genCount;
+        for (uint32_t i0 = begin; i0 < end; i0 += kWave)
         {
-            const uint32_t idx = base + g*kBlock + threadIdx.x;
-            uint32_t slot;
-            if (idx >= count || !gen_slot(fp, idx, slot))
-                continue;
-            PathRegs p;
-            float rx, ry;
-            if (begin_path(cam, fp, passSeeds, slot, p, rx, ry))
-            {
-                store_path(ps, slot, p, rx, ry, true);
-                // sorted like every later queue: camera rays that enter a mesh in HBM in front (k_walk takes those)
-                if (bp.count == 0 || ray_enters_big_mesh(primBoxes, bp, p.o, p.d)) keep |= 1u << g; else keepBack |= 1u << g;
-                samples++;
-            }
-            else
-            {
-                ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                ps.rngRaster[slot] = make_float4(0.0f, 0.0f, -1e30f, -1e30f);
-            }
-        }
-        auto slotOf = [&](int i) -> uint32_t {
+            const uint32_t idx = i0 + lane;
             uint32_t slot = 0;
-            (void)gen_slot(fp, base + (uint32_t)i*kBlock + threadIdx.x, slot);
-            return slot;
-        };
-        if (bp.count)
-            block_append2(keep, keepBack, q.activeCount + 0, q.activeBack + 0, queue0, s_scan, slotOf, fp.queueCapacity - 1u);
-        else
-            block_append(keep, q.activeCount + 0, queue0, s_scan, slotOf);
+            bool live = false, front = true;
+            PathRegs p;
+            if (idx < end && gen_slot(fp, idx, slot))
+            {
+                float rx, ry;
+                if (begin_path(cam, fp, passSeeds, slot, p, rx, ry))
+                {
+                    live = true;
+                    // camera rays that enter a mesh in HBM in front (k_walk takes those)
+                    front = bp.count == 0 || ray_enters_big_mesh(primBoxes, bp, p.o, p.d);
+                    samples++;
+                }
+                else
+                    ss.radOut[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            const uint32_t pos = out.push(live, front);
+            if (live)
+                store_state(ss, 0, pos, p, slot, hasMedia != 0);
+        }
+        if (lane == 0)
+        {
+            ss.segFront[r] = out.nFront;
+            ss.segBack[r] = out.nBack;
+        }
     }
     wave_add_stat(q.stats, 1, samples);
 }
 
 // ---------------------------------------------------------------------------
-// k_extend: closest hit for every queued path
+// k_extend: closest hit of every live path
 
 // WONLY: every mesh of the scene is walked by k_walk: the kernel is the flat scan + record reads, built for more waves
 #ifndef TN_WAVES_SCAN
 #define TN_WAVES_SCAN 6
 #endif
 template <bool COUNT, bool LDS, bool WONLY = false>
-__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_extend(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue, int bounce, int stackEntries,
-                                                                  uint32_t queueCapacity, const float4* __restrict__ walkRec, uint32_t walkPrims)
+__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_extend(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
+                                                                  const float4* __restrict__ walkRec, uint32_t walkPrims)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
     SceneT<LDS, WONLY> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
-    const uint32_t frontCount = q.activeCount[bounce], backCount = q.activeBack[bounce];
-    const uint32_t count = frontCount + backCount;
-    const uint32_t rounds = block_rounds(count);
-    const uint32_t first = blockIdx.x*rounds*kBlock;
+    const uint32_t lane = __lane_id();
+    const int cur = bounce & 1;
     uint32_t rays = 0;
     TraceCounters ctr = { 0, 0, 0 };
     sc.walkRec = walkRec;           // k_walk's records of the front rays (null: meshes are walked inline)
 
+    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
     {
-        for (uint32_t g = 0; g < rounds; ++g)
+        const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
+        const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
+        for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
-            const uint32_t idx = first + g*kBlock + threadIdx.x;
-            if (idx >= count)
-                continue;
-            const uint32_t slot = queue[two_ended(idx, frontCount, backCount, queueCapacity)];
-            const float4 ro = ps.rayO[slot];
-            const float4 rd = ps.rayD[slot];
-            sc.walkItem = idx*walkPrims;        // only front rays (idx < frontCount) ever reach a walked primitive
+            const uint32_t j = j0 + lane;
+            if (j < n)
+            {
+                const uint32_t pos = region_pos(r*ss.regionLen, ss.regionLen, nFront, j);
+                const float4 ro = ss.rayO[cur][pos];
+                const float4 rd = ss.rayD[cur][pos];
+                sc.walkItem = pos*walkPrims;        // only front rays ever reach a walked primitive
 
-            float t;
-            V3 n;
-            const int prim = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, n, ctr);
+                float t;
+                V3 n3;
+                const int prim = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, n3, ctr);
 
-            ps.hit[slot] = make_float4(t, n.x, n.y, n.z);
-            ps.hitPrim[slot] = prim;
-            rays++;
+                ss.hit[pos] = make_float4(t, n3.x, n3.y, n3.z);
+                ss.hitPrim[pos] = prim;
+                rays++;
+            }
         }
     }
 
@@ -757,180 +841,151 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
 }
 
 // ---------------------------------------------------------------------------
-// k_shade
+// The shading half of a bounce, cut where the registers say (measured with -Rpass-analysis=kernel-resource-usage: light
+// sampling with its mesh / moving-primitive branches wants ~170 VGPRs beside a live material record, the BSDF step 125):
+//   k_lights   SampleLights' RNG draws (render.cpp:107-116, 158-170): needs only the hit point, its normal and the RNG; parks the
+//              K shadow rays of every path that hit something (32 B each), packed like the paths themselves
+//   k_shadow   traces them and parks, per ray, which primitive's emission arrives (8 B)
+//   k_shade    on_hit_begin / on_miss, the BSDF terms of the arriving samples only, totalRadiance += throughput*sum
+//              (render.cpp:314), the BSDF step, the survivor to its new position
+// The path's RNG stream is the oracle's: k_lights draws before k_shade's BSDF sample, as SampleLights does before BSDFSample.
 
-TN_D void store_nee(const PathState& ps, uint32_t slot, int k, const NeeRec& r)
+TN_D void store_nee_ray(const SplitState& ss, uint32_t q, int k, const NeeGeo& g)
 {
-    float4* dst = ps.nee + ((size_t)slot*ps.neePerPath + k)*4;
-    dst[0] = make_float4(r.o.x, r.o.y, r.o.z, r.dist);
-    dst[1] = make_float4(r.wi.x, r.wi.y, r.wi.z, r.nl);
-    dst[2] = make_float4(r.f.x, r.f.y, r.f.z, r.bsdfPdf);
-    dst[3] = make_float4(r.absDot, __int_as_float(r.light), 0.0f, 0.0f);
-}
-
-TN_D NeeRec load_nee(const PathState& ps, uint32_t slot, int k)
-{
-    const float4* src = ps.nee + ((size_t)slot*ps.neePerPath + k)*4;
-    const float4 a = src[0], b = src[1], c = src[2], d = src[3];
-    NeeRec r;
-    r.o = V3(a.x, a.y, a.z); r.dist = a.w;
-    r.wi = V3(b.x, b.y, b.z); r.nl = b.w;
-    r.f = V3(c.x, c.y, c.z); r.bsdfPdf = c.w;
-    r.absDot = d.x; r.light = __float_as_int(d.y);
-    return r;
+    float4* dst = ss.neeRay + (size_t)(k*2)*ss.capacity + q;
+    dst[0] = make_float4(g.o.x, g.o.y, g.o.z, g.dist);
+    dst[ss.capacity] = make_float4(g.wi.x, g.wi.y, g.wi.z, g.nl);
 }
 
 template <bool LDS>
-__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queue,
-                                                  uint32_t* __restrict__ queueNext, uint32_t* __restrict__ queueNee, int bounce, int maxDepth, int rrStart,
-                                                  uint32_t queueCapacity, BinPrims bp)
+__global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scIn, SplitState ss, int bounce, BinPrims bp)
 {
-    __shared__ uint32_t s_scan[kScanWords];
     extern __shared__ uint32_t s_arena[];
     SceneT<LDS> sc;
     stage_scene_lds(sc, scIn, s_arena);
-    const uint32_t frontCount = q.activeCount[bounce], backCount = q.activeBack[bounce];
-    const uint32_t count = frontCount + backCount;
-    const uint32_t rounds = block_rounds(count);
-    const uint32_t first = blockIdx.x*rounds*kBlock;
+    const uint32_t lane = __lane_id();
+    const int cur = bounce & 1;
+    const int K = ss.neePerPath;
 
-    for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
+    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
     {
-        const uint32_t base = first + r0*kBlock;
-        const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
-
-        uint32_t keepNee = 0, keepNext = 0, keepNeeBack = 0, keepNextBack = 0;
-        for (uint32_t g = 0; g < groups; ++g)
+        const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
+        const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
+        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
-            const uint32_t idx = base + g*kBlock + threadIdx.x;
-            if (idx >= count)
-                continue;
-            const uint32_t slot = queue[two_ended(idx, frontCount, backCount, queueCapacity)];
+            const uint32_t j = j0 + lane;
+            const uint32_t pos = region_pos(r*ss.regionLen, ss.regionLen, nFront, j < n ? j : 0u);
+            const bool has = j < n && ss.hitPrim[pos] >= 0;
 
-            PathRegs p;
-            float rx, ry;
-            load_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
-
-            const int prim = ps.hitPrim[slot];
-            if (prim < 0)
+            V3 hitP, hitN;
+            float time = 0.0f;
+            Rng rng;
+            NeeGeo ray0;
+            V3 skyColor;
+            float skyPdf = 0.0f;
+            LightCursor lights;
+            bool front = bp.count == 0;         // no big mesh: everything goes to the front
+            if (has)
             {
-                on_miss(sc, p, bounce);
-                ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
-                continue;
-            }
+                const float4 ro = ss.rayO[cur][pos], rd = ss.rayD[cur][pos], hh = ss.hit[pos], rr = ss.rngId[cur][pos];
+                hitP = V3(ro.x, ro.y, ro.z) + V3(rd.x, rd.y, rd.z)*hh.x;       // on_hit_begin's h.p (render.cpp:275)
+                hitN = V3(hh.y, hh.z, hh.w);
+                time = ro.w;
+                rng.s1 = __float_as_uint(rr.x); rng.s2 = __float_as_uint(rr.y);
 
-            const float4 hh = ps.hit[slot];
-            const Mat mat = load_mat(sc.mats, prim);
-
-            HitCtx h;
-            on_hit_begin(p, mat, hh.x, V3(hh.y, hh.z, hh.w), bounce, h);
-
-            // SampleLights, part 1 (render.cpp:107-170): consume the RNG, emit shadow-ray records
-            int k = 0;
-            bool neeInMesh = bp.count == 0;         // no big mesh: everything goes to the front
-            if (sc.probe.valid)
-            {
-                NeeRec r;
-                nee_prepare_probe(sc, mat, h, p.rng, r);
-                store_nee(ps, slot, k++, r);
-                neeInMesh = neeInMesh || ray_enters_big_mesh(sc.primBoxes, bp, r.o, r.wi);
-            }
-            for (int li = 0; li < sc.numLights; ++li)
-            {
-                const int light = sc.lights[li];
-                const int ns = sc.mats[light].lightSamples;
-                for (int s = 0; s < ns; ++s)
+                // the first shadow ray stays in registers across the append; the others are drawn after it
+                if (sc.probe.valid)
+                    nee_sample_probe(sc, hitP, hitN, rng, ray0, skyColor, skyPdf);
+                else
+                    nee_sample_light(sc, hitP, hitN, time, lights.next(sc), rng, ray0);
+                front = front || ray_enters_big_mesh(sc.primBoxes, bp, ray0.o, ray0.wi);
+                if (!front && K > 1)
                 {
-                    NeeRec r;
-                    nee_prepare_light(sc, mat, h, p.time, light, p.rng, r);
-                    store_nee(ps, slot, k++, r);
-                    neeInMesh = neeInMesh || ray_enters_big_mesh(sc.primBoxes, bp, r.o, r.wi);
+                    // does ANY of the path's rays enter a mesh in HBM?  a replay of the remaining draws on a copy of the stream
+                    Rng replay = rng;
+                    LightCursor lc = lights;
+                    for (int k = 1; k < K && !front; ++k)
+                    {
+                        NeeGeo g;
+                        nee_sample_light(sc, hitP, hitN, time, lc.next(sc), replay, g);
+                        front = ray_enters_big_mesh(sc.primBoxes, bp, g.o, g.wi);
+                    }
                 }
             }
-            if (k > 0)
+            const uint32_t q = out.push(has, front);
+            if (has)
             {
-                ps.neeThr[slot] = make_float4(p.thr.x, p.thr.y, p.thr.z, 0.0f);
-                if (neeInMesh) keepNee |= 1u << g; else keepNeeBack |= 1u << g;
-            }
-
-            // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
-            int res = kTerminate;
-            if (bounce + 1 < maxDepth)
-                res = bsdf_step(p, mat, h);
-            if (res == kContinue && rrStart > 0 && bounce + 1 >= rrStart && !roulette_survives(p))
-                res = kTerminate;
-
-            if (res == kContinue)
-            {
-                store_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
-                if (bp.count == 0 || ray_enters_big_mesh(sc.primBoxes, bp, p.o, p.d)) keepNext |= 1u << g; else keepNextBack |= 1u << g;
-            }
-            else
-            {
-                ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
+                store_nee_ray(ss, q, 0, ray0);
+                if (sc.probe.valid)
+                    ss.neeSky[q] = make_float4(skyColor.x, skyColor.y, skyColor.z, skyPdf);
+                for (int k = 1; k < K; ++k)
+                {
+                    NeeGeo g;
+                    nee_sample_light(sc, hitP, hitN, time, lights.next(sc), rng, g);
+                    store_nee_ray(ss, q, k, g);
+                }
+                ss.neeMeta[q] = make_float2(__uint_as_float(pos), time);
+                ss.pathNee[pos] = q;
+                *reinterpret_cast<float2*>(ss.rngId[cur] + pos) = make_float2(__uint_as_float(rng.s1), __uint_as_float(rng.s2));
             }
         }
-
-        auto slotOf = [&](int i) -> uint32_t { return queue[two_ended(base + (uint32_t)i*kBlock + threadIdx.x, frontCount, backCount, queueCapacity)]; };
-        if (bp.count)
+        if (lane == 0)
         {
-            block_append2(keepNee, keepNeeBack, q.neeCount + bounce, q.neeBack + bounce, queueNee, s_scan, slotOf, queueCapacity - 1u);
-            block_append2(keepNext, keepNextBack, q.activeCount + bounce + 1, q.activeBack + bounce + 1, queueNext, s_scan, slotOf, queueCapacity - 1u);
-        }
-        else
-        {
-            block_append(keepNee, q.neeCount + bounce, queueNee, s_scan, slotOf);
-            block_append(keepNext, q.activeCount + bounce + 1, queueNext, s_scan, slotOf);
+            ss.neeFront[(size_t)bounce*ss.numRegions + r] = out.nFront;
+            ss.neeBack[(size_t)bounce*ss.numRegions + r] = out.nBack;
         }
     }
 }
 
-// ---------------------------------------------------------------------------
-// k_shadow: SampleLights, part 2 (render.cpp:118-139, 171-224): one thread per path resolves
-// its K shadow rays in the oracle's order, then totalRadiance += pathThroughput*sum (render.cpp:314)
-
+// k_shadow: the Trace() calls of SampleLights (render.cpp:117, 172) and the tests that follow them (:118, :175-196): one
+// lane per path traces its K shadow rays and leaves, per ray, the primitive whose emission arrives (or -1) and its t.
 template <bool COUNT, bool LDS, bool WONLY = false>
-__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_shadow(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueNee, int bounce, int stackEntries,
-                                                                  uint32_t queueCapacity, const float4* __restrict__ walkRec, uint32_t walkPrims)
+__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_shadow(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
+                                                                  const float4* __restrict__ walkRec, uint32_t walkPrims)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
     SceneT<LDS, WONLY> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
-    const uint32_t frontCount = q.neeCount[bounce], backCount = q.neeBack[bounce];
-    const uint32_t count = frontCount + backCount;
-    const uint32_t rounds = block_rounds(count);
-    const uint32_t first = blockIdx.x*rounds*kBlock;
+    const uint32_t lane = __lane_id();
     uint32_t rays = 0;
     TraceCounters ctr = { 0, 0, 0 };
     sc.walkRec = walkRec;
+    const int K = ss.neePerPath;
 
+    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
     {
-        for (uint32_t g = 0; g < rounds; ++g)
+        const uint32_t nFront = wave_uniform(ss.neeFront[(size_t)bounce*ss.numRegions + r]);
+        const uint32_t n = nFront + wave_uniform(ss.neeBack[(size_t)bounce*ss.numRegions + r]);
+        for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
-            const uint32_t idx = first + g*kBlock + threadIdx.x;
-            if (idx >= count)
+            const uint32_t j = j0 + lane;
+            if (j >= n)
                 continue;
-            const uint32_t slot = queueNee[two_ended(idx, frontCount, backCount, queueCapacity)];
-            const float time = ps.rayO[slot].w;     // rayTime never changes along a path
+            const uint32_t qn = region_pos(r*ss.regionLen, ss.regionLen, nFront, j);
+            const float time = ss.neeMeta[qn].y;
 
-            V3 sum = nee_sum(sc, [&](int k) -> V3 {
-                const NeeRec r = load_nee(ps, slot, k);
+            for (int k = 0; k < K; ++k)
+            {
+                const float4* src = ss.neeRay + (size_t)(k*2)*ss.capacity + qn;
+                const float4 a = src[0], b = src[ss.capacity];
+                NeeGeo ray;
+                ray.o = V3(a.x, a.y, a.z); ray.dist = a.w;
+                ray.wi = V3(b.x, b.y, b.z); ray.nl = b.w;
                 float t;
-                V3 n;
-                sc.walkItem = (idx*(uint32_t)ps.neePerPath + (uint32_t)k)*walkPrims;
-                const int hp = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, time, t, n, ctr);
+                V3 n3;
+                sc.walkItem = (qn*(uint32_t)K + (uint32_t)k)*walkPrims;
+                const int hp = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT>(sc, st, ray.o, ray.wi, time, t, n3, ctr);
                 rays++;
-                if (r.dist < 0.0f)
-                    return (hp < 0) ? r.f : V3(0.0f);       // probe sample: contributes iff unoccluded
-                return nee_resolve_light(sc, r, hp, t);
-            });
-
-            const float4 nt = ps.neeThr[slot];
-            float4 ra = ps.rad[slot];
-            V3 rad = V3(ra.x, ra.y, ra.z) + V3(nt.x, nt.y, nt.z)*sum;
-            ps.rad[slot] = make_float4(rad.x, rad.y, rad.z, ra.w);
+                int arrives;
+                if (ray.dist < 0.0f)
+                    arrives = (hp < 0) ? 0 : -1;            // probe sample: contributes iff unoccluded
+                else
+                    arrives = nee_light_reached(ray, hp, t) ? hp : -1;
+                ss.neeRes[(size_t)k*ss.capacity + qn] = make_float2(__int_as_float(arrives), t);
+            }
         }
     }
 
@@ -941,6 +996,157 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
         wave_add_stat(q.stats, 2, ctr.internal);
         wave_add_stat(q.stats, 3, ctr.tris);
         wave_add_stat(q.stats, 4, ctr.prims);
+    }
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp)
+{
+    extern __shared__ uint32_t s_arena[];
+    SceneT<LDS> sc;
+    stage_scene_lds(sc, scIn, s_arena);
+    const uint32_t lane = __lane_id();
+    const int cur = bounce & 1, nxt = cur ^ 1;
+    const int K = ss.neePerPath;
+    const bool hasMedia = sc.hasMedia != 0;
+
+    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
+    {
+        const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
+        const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
+        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        for (uint32_t j0 = 0; j0 < n; j0 += kWave)
+        {
+            const uint32_t j = j0 + lane;
+            bool alive = false, front = true;
+            PathRegs p;
+            uint32_t slot = 0;
+            if (j < n)
+            {
+                const uint32_t pos = region_pos(r*ss.regionLen, ss.regionLen, nFront, j);
+                load_state(ss, cur, pos, p, slot, hasMedia);
+
+                const int prim = ss.hitPrim[pos];
+                if (prim < 0)
+                {
+                    on_miss(sc, p, bounce);
+                }
+                else
+                {
+                    const float4 hh = ss.hit[pos];
+                    const Mat mat = load_mat(sc.mats, prim);
+
+                    HitCtx h;
+                    on_hit_begin(p, mat, hh.x, V3(hh.y, hh.z, hh.w), bounce, h);
+
+                    // SampleLights, after the traces (render.cpp:118-139, 171-224): k_shadow left, per shadow ray, the primitive
+                    // whose emission arrives; the BSDF terms are evaluated for those rays only
+                    if (K > 0)
+                    {
+                        const uint32_t qn = ss.pathNee[pos];
+                        LightCursor lights;
+                        const float2* res = ss.neeRes + qn;
+                        const float4* wis = ss.neeRay + (size_t)ss.capacity + qn;       // {wi, nl} of ray k at wis[k*2*capacity]
+                        V3 sum = nee_sum(sc, [&](int k) -> V3 {
+                            const float2 rk = res[(size_t)k*ss.capacity];
+                            const int hp = __float_as_int(rk.x);
+                            if (sc.probe.valid && k == 0)
+                            {
+                                if (hp < 0)
+                                    return V3(0.0f);
+                                const float4 w = wis[0], sky = ss.neeSky[qn];
+                                return nee_contrib_probe(mat, h, V3(w.x, w.y, w.z), V3(sky.x, sky.y, sky.z), sky.w);
+                            }
+                            const int light = lights.next(sc);
+                            if (hp < 0)
+                                return V3(0.0f);
+                            const float4 w = wis[(size_t)(k*2)*ss.capacity];
+                            return nee_contrib_light(sc, mat, h, V3(w.x, w.y, w.z), w.w, light, hp, rk.y);
+                        });
+                        p.rad = p.rad + p.thr*sum;
+                    }
+
+                    // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
+                    if (bounce + 1 < maxDepth)
+                        alive = bsdf_step(p, mat, h) == kContinue;
+                    if (alive && rrStart > 0 && bounce + 1 >= rrStart)
+                        alive = roulette_survives(p);
+                    if (alive)
+                        front = bp.count == 0 || ray_enters_big_mesh(sc.primBoxes, bp, p.o, p.d);
+                }
+                if (!alive)
+                    ss.radOut[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
+            }
+            const uint32_t np = out.push(alive, front);
+            if (alive)
+                store_state(ss, nxt, np, p, slot, hasMedia);
+        }
+        if (lane == 0)
+        {
+            ss.segFront[(size_t)(bounce + 1)*ss.numRegions + r] = out.nFront;
+            ss.segBack[(size_t)(bounce + 1)*ss.numRegions + r] = out.nBack;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_walk's work list: the front entries of every region as ONE list of positions, so that its workgroups can cut the
+// work into equal static ranges.  k_seg_prefix: exclusive prefix of the per-region front counts (one workgroup);
+// k_seg_expand: region r writes base_r + i at prefix[r] + i.
+constexpr int kSegBlock = 1024;
+
+__global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __restrict__ counts, uint32_t numRegions, uint32_t* __restrict__ prefix)
+{
+    constexpr uint32_t kWaves = kSegBlock/kWave;
+    __shared__ uint32_t s_wave[kWaves];
+    const uint32_t lane = __lane_id(), wave = threadIdx.x/kWave;
+    // every wave scans one contiguous piece, 64 consecutive counts per step (coalesced)
+    const uint32_t piece = ((numRegions + kWaves - 1u)/kWaves + kWave - 1u)/kWave*kWave;
+    const uint32_t begin = wave*piece < numRegions ? wave*piece : numRegions;
+    const uint32_t end = (begin + piece) < numRegions ? (begin + piece) : numRegions;
+
+    uint32_t sum = 0;
+    for (uint32_t i = begin + lane; i < end; i += kWave)
+        sum += counts[i];
+    for (int off = 32; off > 0; off >>= 1)
+        sum += __shfl_xor(sum, off);
+    if (lane == 0)
+        s_wave[wave] = sum;
+    __syncthreads();
+
+    uint32_t run = 0, total = 0;
+    for (uint32_t w = 0; w < kWaves; ++w)
+    {
+        if (w < wave) run += s_wave[w];
+        total += s_wave[w];
+    }
+    for (uint32_t i0 = begin; i0 < end; i0 += kWave)
+    {
+        const uint32_t i = i0 + lane;
+        const uint32_t v = i < end ? counts[i] : 0u;
+        uint32_t x = v;                                   // inclusive scan across the wave
+        for (int off = 1; off < kWave; off <<= 1)
+        {
+            const uint32_t y = __shfl_up(x, off);
+            if ((int)lane >= off) x += y;
+        }
+        if (i < end)
+            prefix[i] = run + x - v;
+        run += __shfl(x, kWave - 1);
+    }
+    if (threadIdx.x == 0)
+        prefix[numRegions] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void k_seg_expand(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix, uint32_t numRegions,
+                                                       uint32_t regionLen, uint32_t* __restrict__ list)
+{
+    const uint32_t lane = __lane_id();
+    for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < numRegions; r += gridDim.x*(kBlock/kWave))
+    {
+        const uint32_t n = wave_uniform(counts[r]), at = wave_uniform(prefix[r]);
+        for (uint32_t i = lane; i < n; i += kWave)
+            list[at + i] = r*regionLen + i;
     }
 }
 
@@ -992,39 +1198,32 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene scIn, 
                 HitCtx h;
                 on_hit_begin(p, mat, t, n, bounce, h);
 
-                // SampleLights: RNG draws first (all lights, in order), then the traces.  The oracle
-                // interleaves draw/trace per sample; the traces consume no random numbers, so the
-                // stream is identical.  To keep registers bounded the draws are replayed per sample.
+                // SampleLights (render.cpp:103-227): draw, trace, and the BSDF terms for the samples that arrive
                 {
                     const V3 thrAtNee = p.thr;
+                    LightCursor lights;
                     V3 sum = nee_sum(sc, [&](int k) -> V3 {
-                        NeeRec r;
+                        NeeGeo g;
+                        V3 skyColor;
+                        float skyPdf = 0.0f;
+                        int light = -1;
                         if (sc.probe.valid && k == 0)
-                        {
-                            nee_prepare_probe(sc, mat, h, p.rng, r);
-                        }
+                            nee_sample_probe(sc, h.p, h.n, p.rng, g, skyColor, skyPdf);
                         else
                         {
-                            // locate light of NEE ray k
-                            int kk = k - (sc.probe.valid ? 1 : 0);
-                            int li = 0;
-                            for (;; ++li)
-                            {
-                                const int ns = sc.mats[sc.lights[li]].lightSamples;
-                                if (kk < ns)
-                                    break;
-                                kk -= ns;
-                            }
-                            nee_prepare_light(sc, mat, h, p.time, sc.lights[li], p.rng, r);
+                            light = lights.next(sc);
+                            nee_sample_light(sc, h.p, h.n, p.time, light, p.rng, g);
                         }
                         float ts;
                         V3 nn;
-                        const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, r.o, r.wi, p.time, ts, nn, ctr);
+                        const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, g.o, g.wi, p.time, ts, nn, ctr);
                         rays++;
                         shadowRays++;
-                        if (r.dist < 0.0f)
-                            return (hp < 0) ? r.f : V3(0.0f);
-                        return nee_resolve_light(sc, r, hp, ts);
+                        if (light < 0)
+                            return (hp < 0) ? nee_contrib_probe(mat, h, g.wi, skyColor, skyPdf) : V3(0.0f);
+                        if (!nee_light_reached(g, hp, ts))
+                            return V3(0.0f);
+                        return nee_contrib_light(sc, mat, h, g.wi, g.nl, light, hp, ts);
                     });
                     p.rad = p.rad + thrAtNee*sum;
                 }
@@ -1070,7 +1269,7 @@ TN_D float filter_gauss(float x, float falloff, float offset)      // Filter::Ga
     return maxT(0.0f, float(m_expf(-falloff*x*x)) - offset);
 }
 
-__global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FrameParams fp, float4* __restrict__ accum)
+__global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FrameParams fp, float4* __restrict__ accum, const uint32_t* __restrict__ passSeeds)
 {
     const int npix = fp.width*fp.height;
     const int pix = blockIdx.x*kBlock + threadIdx.x;
@@ -1097,8 +1296,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate(PathState ps, FramePar
                 if (!pixel_owned(fp, i, j))
                     continue;       // path not generated by this shard
                 const size_t slot = slot_of(fp, s, i, j);
-                const float4 rr = ps.rngRaster[slot];
-                const float rx = rr.z, ry = rr.w;
+                // the raster position is the first two draws of the path's own stream (camera_sample)
+                Rng rng = Rng::seeded((uint32_t)i + (uint32_t)j*(uint32_t)fp.width + passSeeds[fp.passBase + s]);
+                const float x = rng.randf();
+                const float y = rng.randf();
+                const float rx = x + i, ry = y + j;
 
                 const int startX = maxI(0, int(rx - fw));
                 const int startY = maxI(0, int(ry - fw));

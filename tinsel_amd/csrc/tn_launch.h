@@ -17,20 +17,20 @@ namespace tn {
 
 enum PathKernel : int
 {
-    PK_GENERATE = 0, PK_EXTEND, PK_SHADE, PK_SHADOW, PK_BOUNCE, PK_MEGA, PK_WALK,
+    PK_GENERATE = 0, PK_EXTEND, PK_SHADE, PK_SHADOW, PK_BOUNCE, PK_MEGA, PK_WALK, PK_LIGHTS,
 };
 
 struct LaunchArgs
 {
     DevScene scene;
     PathState ps;
+    SplitState ss;                  // the split pipeline's dense state (PK_GENERATE .. PK_SHADE)
     QueueCtl ctl;
     CameraParams cam;
     FrameParams fp;
     const uint32_t* passSeeds;
-    const uint32_t* queueIn;        // extension / shade / bounce input queue, shadow queue for PK_SHADOW
-    uint32_t* queueOut;             // next bounce's queue (PK_GENERATE: queue 0)
-    uint32_t* queueNee;             // shadow queue filled by PK_SHADE
+    const uint32_t* queueIn;        // PK_BOUNCE: input queue
+    uint32_t* queueOut;             // PK_BOUNCE: next bounce's queue
     const float4* walkRec;          // k_walk's records (null: meshes are walked inline)
     uint32_t walkPrims;
     BinPrims bins;                  // primitives whose leaf-box test sorts the queues
@@ -51,7 +51,7 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
     switch (which)
     {
     case PK_GENERATE:
-        hipLaunchKernelGGL(k_generate, grid, block, 0, st, a.ps, a.ctl, a.queueOut, a.cam, a.fp, a.passSeeds, a.scene.primBoxes, a.bins);
+        hipLaunchKernelGGL(k_generate, grid, block, 0, st, a.ss, a.ctl, a.cam, a.fp, a.passSeeds, a.scene.primBoxes, a.bins, a.scene.hasMedia);
         break;
     case PK_EXTEND:
 #define TN_LAUNCH2(KERNEL, ...)                                                                                        \
@@ -60,25 +60,31 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             else       { if (lds) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); } \
         } while (0)
         if (a.walkedOnly && !count && !lds)
-            hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+            hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims);
         else
-            TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+            TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims);
         break;
     case PK_SHADOW:
         if (a.walkedOnly && !count && !lds)
-            hipLaunchKernelGGL((k_shadow<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+            hipLaunchKernelGGL((k_shadow<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims);
         else
-            TN_LAUNCH2(k_shadow, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.bounce, a.stackEntries, a.fp.queueCapacity, a.walkRec, a.walkPrims);
+            TN_LAUNCH2(k_shadow, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims);
         break;
     case PK_MEGA:
         TN_LAUNCH2(k_mega, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.cam, a.fp, a.passSeeds, a.stackEntries);
         break;
 #undef TN_LAUNCH2
+    case PK_LIGHTS:
+        if (lds)
+            hipLaunchKernelGGL((k_lights<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins);
+        else
+            hipLaunchKernelGGL((k_lights<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins);
+        break;
     case PK_SHADE:
         if (lds)
-            hipLaunchKernelGGL((k_shade<true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.queueNee, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.fp.queueCapacity, a.bins);
+            hipLaunchKernelGGL((k_shade<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins);
         else
-            hipLaunchKernelGGL((k_shade<false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.queueNee, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.fp.queueCapacity, a.bins);
+            hipLaunchKernelGGL((k_shade<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins);
         break;
     case PK_BOUNCE:
 #define TN_LAUNCH_BOUNCE(FIRST)                                                                                        \

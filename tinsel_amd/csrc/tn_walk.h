@@ -42,12 +42,14 @@ constexpr int kWalkMaxPrims = 7;
 
 struct WalkJob
 {
-    const uint32_t* queue;          // ray queue; the FRONT part [0, *frontCount) holds the slots to walk
+    const uint32_t* queue;          // the positions to walk (k_seg_expand: the front entries of every region), *frontCount of them
     const uint32_t* frontCount;
-    const float4* rayO;             // extension rays: origin|time, dir|- by slot
+    const float4* rayO;             // extension rays: origin|time, dir|- by path position (SplitState::rayO / rayD of the bounce)
     const float4* rayD;
-    const float4* nee;              // shadow rays: NEE records [(slot*K + k)*4 + {0: o|dist, 1: wi|nl}]
-    float4* rec;                    // out: [item][2] = {t,u,v,w} {n.xyz, tri};  t == FLT_MAX: no hit
+    const float4* nee;              // shadow rays: SplitState::neeRay [(k*2 + {0: o|dist, 1: wi|nl})*neeStride + q] by NEE position q
+    uint32_t neeStride;
+    const float2* neeMeta;          // shadow rays: SplitState::neeMeta [q] = {path position, rayTime}
+    float4* rec;                    // out: [((position*K + k)*numPrims + walked primitive)][2] = {t,u,v,w} {n.xyz, tri};  t == FLT_MAX: no hit
     int neePerPath;                 // 0: extension rays; K > 0: the K shadow rays of every queued slot
     int numPrims;                   // walked primitives (1..7)
     int prim[kWalkMaxPrims];
@@ -238,14 +240,15 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     const uint32_t k = rem/Kb;
                     const uint32_t kb = rem - k*Kb;
                     const uint32_t slot = job.queue[qi];
+                    const uint32_t recAt = slot*per + rem;      // records are indexed by position, like everything the scan kernels read
 
                     float4 ro, rd;
                     float time;
                     if (job.neePerPath > 0)
                     {
-                        const float4* np = job.nee + ((size_t)slot*Kx + k)*4;
-                        ro = np[0]; rd = np[1];
-                        time = job.rayO[slot].w;        // rayTime never changes along a path
+                        const float4* np = job.nee + (size_t)(k*2u)*job.neeStride + slot;
+                        ro = np[0]; rd = np[job.neeStride];
+                        time = job.neeMeta[slot].y;
                     }
                     else
                     {
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 
                     if (!enters)
                     {
-                        job.rec[(size_t)my*2] = make_float4(kFltMax, 0.0f, 0.0f, 0.0f);
+                        job.rec[(size_t)recAt*2] = make_float4(kFltMax, 0.0f, 0.0f, 0.0f);
                     }
                     else
                     {
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         sp = 0;
                         closestT = kFltMax;
                         htri = -1;
-                        item = my;
+                        item = recAt;
                         active = true;
                     }
                 }

@@ -87,6 +87,8 @@ def load_library():
     L.tinsel_hip_stack_entries.argtypes = [vp]
     L.tinsel_hip_nee_per_path.argtypes = [vp]
     L.tinsel_hip_walked_prims.argtypes = [vp]
+    if hasattr(L, "tinsel_hip_queue_counts"):        # absent from older builds loaded through TINSEL_HIP_LIB for an A/B
+        L.tinsel_hip_queue_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
     L.tinsel_hip_set_lookahead.argtypes = [vp, ci]
     L.tinsel_hip_refit_mesh.argtypes = [vp, ci, vp, ci, vp]
     L.tinsel_hip_set_probe_sampling.argtypes = [vp, ci]
@@ -116,7 +118,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
     "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
     "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_russian_roulette", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
-    "tinsel_hip_walked_prims", "tinsel_hip_set_lookahead", "tinsel_hip_set_arithmetic", "tinsel_hip_get_arithmetic", "tinsel_hip_refit_mesh", "tinsel_hip_set_probe_sampling",
+    "tinsel_hip_walked_prims", "tinsel_hip_queue_counts", "tinsel_hip_set_lookahead", "tinsel_hip_set_arithmetic", "tinsel_hip_get_arithmetic", "tinsel_hip_refit_mesh", "tinsel_hip_set_probe_sampling",
     "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
     "tinsel_hip_group_size", "tinsel_hip_group_member",
 ]
@@ -335,6 +337,13 @@ class HipRenderer:
     def walked_prims(self):
         """Primitives whose mesh BVH the dedicated k_walk kernel traverses (0: all meshes are walked inline)."""
         return self._L.tinsel_hip_walked_prims(self._h)
+
+    def queue_counts(self, max_bounces=64):
+        """(paths alive at the start of each bounce, paths with shadow rays at each bounce) of the last batch."""
+        out = (C.c_uint32*(2*max_bounces))()
+        n = self._L.tinsel_hip_queue_counts(self._h, out, max_bounces)
+        _check(min(n, 0), "tinsel_hip_queue_counts")
+        return list(out[:n]), list(out[max_bounces:max_bounces + n])
 
     def close(self):
         if self._h:
