@@ -895,6 +895,8 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         const uint32_t ldsTrace = walkedOnly ? (uint32_t)(((size_t)stackScan*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes) : a.ldsBytes;
         const uint32_t ldsShade = r->scene.allInArena ? r->scene.arenaBytes : r->scene.arenaLdsBytes;
         a.walkedOnly = walkedOnly ? 1 : 0;
+        // the lean k_extend draws the light samples itself (tn_launch.h launches it when walkedOnly and not counting)
+        const bool lightsInExtend = walkedOnly && !r->countDetail;
         // one region per wave of the streaming grid (SplitState, tn_kernels.h)
         a.ss = r->ss;
         a.ss.numRegions = (uint32_t)gridPersist*(kBlock/kWave);
@@ -926,6 +928,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             }
             if (r->neePerPath > 0)
             {
+                if (!lightsInExtend)
                 {
                     ScopedTimer t(r, KN_LIGHTS, st);
                     a.grid = gridPersist;

@@ -40,6 +40,10 @@ namespace tn {
 #ifndef TN_WAVES_LIGHTS
 #define TN_WAVES_LIGHTS 4
 #endif
+// the lean k_extend carries the light sampling in its tail and needs 123 VGPRs for it
+#ifndef TN_WAVES_SCAN_EXTEND
+#define TN_WAVES_SCAN_EXTEND 4
+#endif
 #ifndef TN_WAVES_TRACE
 #define TN_WAVES_TRACE 4
 #endif
@@ -791,9 +795,76 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(SplitState ss, QueueCtl 
 #ifndef TN_WAVES_SCAN
 #define TN_WAVES_SCAN 6
 #endif
+TN_D void store_nee_ray(const SplitState& ss, uint32_t q, int k, const NeeGeo& g)
+{
+    float4* dst = ss.neeRay + (size_t)(k*2)*ss.capacity + q;
+    dst[0] = make_float4(g.o.x, g.o.y, g.o.z, g.dist);
+    dst[ss.capacity] = make_float4(g.wi.x, g.wi.y, g.wi.z, g.nl);
+}
+
+// SampleLights' RNG draws (render.cpp:107-116, 158-170) for one path per lane: the K shadow rays of every path that hit
+// something (`has`; 32 B each), packed like the paths themselves -- in front the paths with a shadow ray that enters a mesh
+// in HBM.  Needs only the hit point, its normal and the path's RNG.  The stream is the oracle's: these draws come before
+// k_shade's BSDF sample, as SampleLights comes before BSDFSample.  Call with the wave converged (it appends).
+template <class SC>
+TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& bp, int cur, uint32_t pos, bool has, V3 hitP, V3 hitN, float time, RegionAppend& out)
+{
+    const int K = ss.neePerPath;
+    Rng rng;
+    NeeGeo ray0;
+    V3 skyColor;
+    float skyPdf = 0.0f;
+    LightCursor lights;
+    bool front = bp.count == 0;         // no big mesh: everything goes to the front
+    if (has)
+    {
+        const float2 rr = *reinterpret_cast<const float2*>(ss.rngId[cur] + pos);
+        rng.s1 = __float_as_uint(rr.x); rng.s2 = __float_as_uint(rr.y);
+
+        // the first shadow ray stays in registers across the append; the others are drawn after it
+        if (sc.probe.valid)
+            nee_sample_probe(sc, hitP, hitN, rng, ray0, skyColor, skyPdf);
+        else
+            nee_sample_light(sc, hitP, hitN, time, lights.next(sc), rng, ray0);
+        front = front || ray_enters_big_mesh(sc.primBoxes, bp, ray0.o, ray0.wi);
+        if (!front && K > 1)
+        {
+            // does ANY of the path's rays enter a mesh in HBM?  a replay of the remaining draws on a copy of the stream
+            Rng replay = rng;
+            LightCursor lc = lights;
+            for (int k = 1; k < K && !front; ++k)
+            {
+                NeeGeo g;
+                nee_sample_light(sc, hitP, hitN, time, lc.next(sc), replay, g);
+                front = ray_enters_big_mesh(sc.primBoxes, bp, g.o, g.wi);
+            }
+        }
+    }
+    const uint32_t qn = out.push(has, front);
+    if (has)
+    {
+        store_nee_ray(ss, qn, 0, ray0);
+        if (sc.probe.valid)
+            ss.neeSky[qn] = make_float4(skyColor.x, skyColor.y, skyColor.z, skyPdf);
+        for (int k = 1; k < K; ++k)
+        {
+            NeeGeo g;
+            nee_sample_light(sc, hitP, hitN, time, lights.next(sc), rng, g);
+            store_nee_ray(ss, qn, k, g);
+        }
+        ss.neeMeta[qn] = make_float2(__uint_as_float(pos), time);
+        ss.pathNee[pos] = qn;
+        *reinterpret_cast<float2*>(ss.rngId[cur] + pos) = make_float2(__uint_as_float(rng.s1), __uint_as_float(rng.s2));
+    }
+}
+
+// k_extend: closest hit of every live path.  The lean variant (WONLY: every mesh of the scene is walked by k_walk, the
+// kernel is the flat scan + record reads) also draws the light samples, the hit still in registers: there a kernel of its
+// own for them costs more than it saves (524k-triangle config: 2.1 + 2.9 ms apart, 3.9 together); behind the inline mesh
+// walk it is the other way round (the fused kernel needs 170 VGPRs: glass 21.2 + 7.9 apart, 31.5 together at 3 waves).
 template <bool COUNT, bool LDS, bool WONLY = false>
-__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_extend(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
-                                                                  const float4* __restrict__ walkRec, uint32_t walkPrims)
+__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : TN_WAVES_TRACE) void k_extend(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
+                                                                  const float4* __restrict__ walkRec, uint32_t walkPrims, BinPrims bp)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
@@ -802,6 +873,7 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
 
     const uint32_t lane = __lane_id();
     const int cur = bounce & 1;
+    const bool lights = WONLY && ss.neePerPath > 0;
     uint32_t rays = 0;
     TraceCounters ctr = { 0, 0, 0 };
     sc.walkRec = walkRec;           // k_walk's records of the front rays (null: meshes are walked inline)
@@ -810,24 +882,37 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
     {
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
+        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
+            const uint32_t pos = region_pos(r*ss.regionLen, ss.regionLen, nFront, j < n ? j : 0u);
+            bool has = false;
+            V3 hitP, hitN;
+            float time = 0.0f;
             if (j < n)
             {
-                const uint32_t pos = region_pos(r*ss.regionLen, ss.regionLen, nFront, j);
                 const float4 ro = ss.rayO[cur][pos];
                 const float4 rd = ss.rayD[cur][pos];
                 sc.walkItem = pos*walkPrims;        // only front rays ever reach a walked primitive
 
                 float t;
-                V3 n3;
-                const int prim = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, n3, ctr);
+                const int prim = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, hitN, ctr);
 
-                ss.hit[pos] = make_float4(t, n3.x, n3.y, n3.z);
+                ss.hit[pos] = make_float4(t, hitN.x, hitN.y, hitN.z);
                 ss.hitPrim[pos] = prim;
                 rays++;
+                has = prim >= 0;
+                hitP = V3(ro.x, ro.y, ro.z) + V3(rd.x, rd.y, rd.z)*t;       // on_hit_begin's h.p (render.cpp:275)
+                time = ro.w;
             }
+            if (lights)
+                draw_shadow_rays(sc, ss, bp, cur, pos, has, hitP, hitN, time, out);
+        }
+        if (lights && lane == 0)
+        {
+            ss.neeFront[(size_t)bounce*ss.numRegions + r] = out.nFront;
+            ss.neeBack[(size_t)bounce*ss.numRegions + r] = out.nBack;
         }
     }
 
@@ -840,23 +925,7 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
     }
 }
 
-// ---------------------------------------------------------------------------
-// The shading half of a bounce, cut where the registers say (measured with -Rpass-analysis=kernel-resource-usage: light
-// sampling with its mesh / moving-primitive branches wants ~170 VGPRs beside a live material record, the BSDF step 125):
-//   k_lights   SampleLights' RNG draws (render.cpp:107-116, 158-170): needs only the hit point, its normal and the RNG; parks the
-//              K shadow rays of every path that hit something (32 B each), packed like the paths themselves
-//   k_shadow   traces them and parks, per ray, which primitive's emission arrives (8 B)
-//   k_shade    on_hit_begin / on_miss, the BSDF terms of the arriving samples only, totalRadiance += throughput*sum
-//              (render.cpp:314), the BSDF step, the survivor to its new position
-// The path's RNG stream is the oracle's: k_lights draws before k_shade's BSDF sample, as SampleLights does before BSDFSample.
-
-TN_D void store_nee_ray(const SplitState& ss, uint32_t q, int k, const NeeGeo& g)
-{
-    float4* dst = ss.neeRay + (size_t)(k*2)*ss.capacity + q;
-    dst[0] = make_float4(g.o.x, g.o.y, g.o.z, g.dist);
-    dst[ss.capacity] = make_float4(g.wi.x, g.wi.y, g.wi.z, g.nl);
-}
-
+// k_lights: the light samples of a bounce as a kernel of its own (scenes whose k_extend walks meshes inline)
 template <bool LDS>
 __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scIn, SplitState ss, int bounce, BinPrims bp)
 {
@@ -865,70 +934,43 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
     stage_scene_lds(sc, scIn, s_arena);
     const uint32_t lane = __lane_id();
     const int cur = bounce & 1;
-    const int K = ss.neePerPath;
 
     for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
     {
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        // the next round's records are requested before this round's samples are drawn (see k_shade)
+        float4 nro, nrd, nhh;
+        int nprim = -1;
+        uint32_t npos = region_pos(r*ss.regionLen, ss.regionLen, nFront, lane < n ? lane : 0u);
+        if (lane < n)
+        {
+            nro = ss.rayO[cur][npos]; nrd = ss.rayD[cur][npos]; nhh = ss.hit[npos]; nprim = ss.hitPrim[npos];
+        }
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
-            const uint32_t pos = region_pos(r*ss.regionLen, ss.regionLen, nFront, j < n ? j : 0u);
-            const bool has = j < n && ss.hitPrim[pos] >= 0;
-
+            const uint32_t pos = npos;
+            const float4 ro = nro, rd = nrd, hh = nhh;
+            const bool has = j < n && nprim >= 0;
+            {
+                const uint32_t jn = j + kWave;
+                npos = region_pos(r*ss.regionLen, ss.regionLen, nFront, jn < n ? jn : 0u);
+                if (jn < n)
+                {
+                    nro = ss.rayO[cur][npos]; nrd = ss.rayD[cur][npos]; nhh = ss.hit[npos]; nprim = ss.hitPrim[npos];
+                }
+            }
             V3 hitP, hitN;
             float time = 0.0f;
-            Rng rng;
-            NeeGeo ray0;
-            V3 skyColor;
-            float skyPdf = 0.0f;
-            LightCursor lights;
-            bool front = bp.count == 0;         // no big mesh: everything goes to the front
             if (has)
             {
-                const float4 ro = ss.rayO[cur][pos], rd = ss.rayD[cur][pos], hh = ss.hit[pos], rr = ss.rngId[cur][pos];
                 hitP = V3(ro.x, ro.y, ro.z) + V3(rd.x, rd.y, rd.z)*hh.x;       // on_hit_begin's h.p (render.cpp:275)
                 hitN = V3(hh.y, hh.z, hh.w);
                 time = ro.w;
-                rng.s1 = __float_as_uint(rr.x); rng.s2 = __float_as_uint(rr.y);
-
-                // the first shadow ray stays in registers across the append; the others are drawn after it
-                if (sc.probe.valid)
-                    nee_sample_probe(sc, hitP, hitN, rng, ray0, skyColor, skyPdf);
-                else
-                    nee_sample_light(sc, hitP, hitN, time, lights.next(sc), rng, ray0);
-                front = front || ray_enters_big_mesh(sc.primBoxes, bp, ray0.o, ray0.wi);
-                if (!front && K > 1)
-                {
-                    // does ANY of the path's rays enter a mesh in HBM?  a replay of the remaining draws on a copy of the stream
-                    Rng replay = rng;
-                    LightCursor lc = lights;
-                    for (int k = 1; k < K && !front; ++k)
-                    {
-                        NeeGeo g;
-                        nee_sample_light(sc, hitP, hitN, time, lc.next(sc), replay, g);
-                        front = ray_enters_big_mesh(sc.primBoxes, bp, g.o, g.wi);
-                    }
-                }
             }
-            const uint32_t q = out.push(has, front);
-            if (has)
-            {
-                store_nee_ray(ss, q, 0, ray0);
-                if (sc.probe.valid)
-                    ss.neeSky[q] = make_float4(skyColor.x, skyColor.y, skyColor.z, skyPdf);
-                for (int k = 1; k < K; ++k)
-                {
-                    NeeGeo g;
-                    nee_sample_light(sc, hitP, hitN, time, lights.next(sc), rng, g);
-                    store_nee_ray(ss, q, k, g);
-                }
-                ss.neeMeta[q] = make_float2(__uint_as_float(pos), time);
-                ss.pathNee[pos] = q;
-                *reinterpret_cast<float2*>(ss.rngId[cur] + pos) = make_float2(__uint_as_float(rng.s1), __uint_as_float(rng.s2));
-            }
+            draw_shadow_rays(sc, ss, bp, cur, pos, has, hitP, hitN, time, out);
         }
         if (lane == 0)
         {
@@ -937,6 +979,14 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
         }
     }
 }
+
+// ---------------------------------------------------------------------------
+// The shading half of a bounce (the light samples are drawn):
+//   k_shadow   traces the shadow rays and parks, per ray, which primitive's emission arrives (8 B)
+//   k_shade    on_hit_begin / on_miss, the BSDF terms of the arriving samples only, totalRadiance += throughput*sum
+//              (render.cpp:314), the BSDF step, the survivor to its new position
+// (cut where the registers say, -Rpass-analysis=kernel-resource-usage: light sampling with its mesh / moving-primitive
+// branches wants ~170 VGPRs beside a live material record, the BSDF step 125).
 
 // k_shadow: the Trace() calls of SampleLights (render.cpp:117, 172) and the tests that follow them (:118, :175-196): one
 // lane per path traces its K shadow rays and leaves, per ray, the primitive whose emission arrives (or -1) and its t.
@@ -999,6 +1049,37 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
     }
 }
 
+// what k_shade reads of a path before it can do anything: its state, its hit, where its shadow rays are
+struct ShadeFetch
+{
+    float4 ro, rd, th, ra, ab, rr, hh;
+    int prim;
+    uint32_t qn;
+
+    TN_D void issue(const SplitState& ss, int buf, uint32_t pos, bool valid, bool hasMedia, bool hasNee)
+    {
+        if (!valid)
+            return;
+        ro = ss.rayO[buf][pos]; rd = ss.rayD[buf][pos]; th = ss.thr[buf][pos]; ra = ss.rad[buf][pos];
+        ab = hasMedia ? ss.absorb[buf][pos] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        rr = ss.rngId[buf][pos];
+        hh = ss.hit[pos];
+        prim = ss.hitPrim[pos];
+        qn = hasNee ? ss.pathNee[pos] : 0u;
+    }
+
+    TN_D void unpack(PathRegs& p, uint32_t& slot) const
+    {
+        p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
+        p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
+        p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
+        p.rad = V3(ra.x, ra.y, ra.z); p.rayType = __float_as_int(ra.w);
+        p.absorption = V3(ab.x, ab.y, ab.z);
+        p.rng.s1 = __float_as_uint(rr.x); p.rng.s2 = __float_as_uint(rr.y);
+        slot = __float_as_uint(rr.z);
+    }
+};
+
 template <bool LDS>
 __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp)
 {
@@ -1015,25 +1096,33 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        // The kernel runs two waves per SIMD, too few to hide a round's loads behind another wave's arithmetic: the records
+        // of round i + 1 are requested before round i is shaded (they are reads of buffer `cur`, which nothing here writes).
+        ShadeFetch next;
+        next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, lane < n ? lane : 0u), lane < n, hasMedia, K > 0);
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
+            const ShadeFetch f = next;
+            {
+                const uint32_t jn = j + kWave;
+                next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, jn < n ? jn : 0u), jn < n, hasMedia, K > 0);
+            }
             bool alive = false, front = true;
             PathRegs p;
             uint32_t slot = 0;
             if (j < n)
             {
-                const uint32_t pos = region_pos(r*ss.regionLen, ss.regionLen, nFront, j);
-                load_state(ss, cur, pos, p, slot, hasMedia);
+                f.unpack(p, slot);
 
-                const int prim = ss.hitPrim[pos];
+                const int prim = f.prim;
                 if (prim < 0)
                 {
                     on_miss(sc, p, bounce);
                 }
                 else
                 {
-                    const float4 hh = ss.hit[pos];
+                    const float4 hh = f.hh;
                     const Mat mat = load_mat(sc.mats, prim);
 
                     HitCtx h;
@@ -1043,7 +1132,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
                     // whose emission arrives; the BSDF terms are evaluated for those rays only
                     if (K > 0)
                     {
-                        const uint32_t qn = ss.pathNee[pos];
+                        const uint32_t qn = f.qn;
                         LightCursor lights;
                         const float2* res = ss.neeRes + qn;
                         const float4* wis = ss.neeRay + (size_t)ss.capacity + qn;       // {wi, nl} of ray k at wis[k*2*capacity]

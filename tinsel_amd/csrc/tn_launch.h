@@ -60,9 +60,9 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             else       { if (lds) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); } \
         } while (0)
         if (a.walkedOnly && !count && !lds)
-            hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims);
+            hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins);
         else
-            TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims);
+            TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins);
         break;
     case PK_SHADOW:
         if (a.walkedOnly && !count && !lds)
