@@ -437,9 +437,11 @@ int resolve_pipeline(const tinsel_hip* r)
 {
     if (r->pipeline != TINSEL_PIPELINE_AUTO)
         return r->pipeline;
-    // measured fused -> split, Msamples/s: 1 NEE ray per bounce cornell 2588 -> 1630; 2 rays cornell+probe 1840 -> 1375,
-    // env_loft 3008 -> 2443; 4 rays veach 1304 -> 1340; 9 rays features 540 -> 668
-    return (r->scene.allInArena && r->neePerPath <= 2) ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
+    // A scene whose arena is staged whole into LDS runs the fused kernel, whatever its shadow rays per bounce (fused ->
+    // split, Msamples/s: cornell 2550 -> 2055, gloss 6250 -> 4070, env_loft 3540 -> 2260, 4 rays: veach 1295 -> 1267, 9 rays:
+    // features 690 -> 616, 10 rays: features + probe 589 -> 515; until the BSDF terms moved behind the shadow traces the
+    // many-ray scenes were faster split); scenes with meshes or a scene BVH in HBM run the split pipeline.
+    return r->scene.allInArena ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
 }
 
 // The split pipeline's state (SplitState, tn_kernels.h): by POSITION, two buffers of everything a bounce rewrites
