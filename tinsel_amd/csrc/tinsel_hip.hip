@@ -685,7 +685,17 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     }
     // the work list: the front entries of every region (paths / shadow-ray bundles whose ray enters a walked mesh's box)
     const SplitState& ss = a.ss;
-    hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, regionCounts, ss.numRegions, r->segPrefix);
+    // the list visits the regions a golden-section step apart (TINSEL_HIP_WALK_LIST_STEP=1: in order)
+    static const int stepEnv = getenv("TINSEL_HIP_WALK_LIST_STEP") ? atoi(getenv("TINSEL_HIP_WALK_LIST_STEP")) : 0;
+    uint32_t step = stepEnv > 0 ? (uint32_t)stepEnv : (uint32_t)(ss.numRegions*0.6180339887) | 1u;
+    {
+        auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
+        while (step > 1 && gcd(step, ss.numRegions) != 1)
+            step -= 1;
+        if (step >= ss.numRegions)
+            step = 1;
+    }
+    hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, regionCounts, ss.numRegions, step, r->segPrefix);
     hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
     WalkJob& job = a.walk;
     job.queue = r->walkList;
@@ -1546,10 +1556,11 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         const bool flatScan = everyPrimHasALeaf && P <= 64 && !getenv("TINSEL_HIP_NO_FLAT_SCAN");
 
         // primitives whose mesh lives in HBM (flat-scan scenes, the first 7): their leaf-box test sorts the ray queues
-        // (k_generate, k_shade).  Of those, the ones with a LARGE tree are walked by k_walk ahead of the scan kernels
-        // (tn_walk.h); a small tree (glass.tin's 1280-triangle sphere: 80 KB of nodes) is L1/L2-resident and cheaper to walk
-        // inline than to hand over (measured: 732 inline vs 657-690 Msamples/s through k_walk).
-        const int walkMinTris = getenv("TINSEL_HIP_WALK_MIN_TRIS") ? atoi(getenv("TINSEL_HIP_WALK_MIN_TRIS")) : 16384;
+        // (k_generate, k_shade).  Of those, the ones with at least 256 triangles are walked by k_walk ahead of the scan kernels
+        // (tn_walk.h).  That includes trees that stay in L1/L2 (glass.tin's 1280-triangle sphere: 80 KB of nodes): what the
+        // lean kernel buys there is ray replacement for incoherent bounces (glass, maxDepth 12: 924 -> 1001 Msamples/s; with
+        // k_walk's work list in image order it had lost, 732 inline vs 657-690).
+        const int walkMinTris = getenv("TINSEL_HIP_WALK_MIN_TRIS") ? atoi(getenv("TINSEL_HIP_WALK_MIN_TRIS")) : 256;
         r->binPrims.count = 0;
         r->walkPrims.count = 0;
         if (flatScan)

@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
 // k_seg_expand: region r writes base_r + i at prefix[r] + i.
 constexpr int kSegBlock = 1024;
 
-__global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __restrict__ counts, uint32_t numRegions, uint32_t* __restrict__ prefix)
+__global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __restrict__ counts, uint32_t numRegions, uint32_t step, uint32_t* __restrict__ prefix)
 {
     constexpr uint32_t kWaves = kSegBlock/kWave;
     __shared__ uint32_t s_wave[kWaves];
@@ -1194,9 +1194,11 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
     const uint32_t begin = wave*piece < numRegions ? wave*piece : numRegions;
     const uint32_t end = (begin + piece) < numRegions ? (begin + piece) : numRegions;
 
+    // the list visits the regions `step` apart (coprime to their number): entry i of the scan is region i*step mod numRegions
+    auto region = [&](uint32_t i) -> uint32_t { return (uint32_t)(((unsigned long long)i*step) % numRegions); };
     uint32_t sum = 0;
     for (uint32_t i = begin + lane; i < end; i += kWave)
-        sum += counts[i];
+        sum += counts[region(i)];
     for (int off = 32; off > 0; off >>= 1)
         sum += __shfl_xor(sum, off);
     if (lane == 0)
@@ -1212,7 +1214,7 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
     for (uint32_t i0 = begin; i0 < end; i0 += kWave)
     {
         const uint32_t i = i0 + lane;
-        const uint32_t v = i < end ? counts[i] : 0u;
+        const uint32_t v = i < end ? counts[region(i)] : 0u;
         uint32_t x = v;                                   // inclusive scan across the wave
         for (int off = 1; off < kWave; off <<= 1)
         {
@@ -1220,7 +1222,7 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
             if ((int)lane >= off) x += y;
         }
         if (i < end)
-            prefix[i] = run + x - v;
+            prefix[region(i)] = run + x - v;
         run += __shfl(x, kWave - 1);
     }
     if (threadIdx.x == 0)
