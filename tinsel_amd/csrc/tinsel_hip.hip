@@ -291,8 +291,8 @@ struct DeviceArena
 };
 
 const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", "k_accumulate", "k_mega", "k_normals", "k_bounce",
-                               "k_present", "k_nlm_means", "k_nlm", "k_walk", "k_lights" };
-enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_WALK, KN_LIGHTS, KN_COUNT };
+                               "k_present", "k_nlm_means", "k_nlm", "k_walk", "k_lights", "k_seg" };
+enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_WALK, KN_LIGHTS, KN_SEG, KN_COUNT };
 
 struct TimedSpan { int kernel; hipEvent_t start, stop; };
 
@@ -458,7 +458,7 @@ int alloc_split(tinsel_hip* r, size_t slots, int maxDepth)
             return -1;
     if (batch_alloc(r, &ss.hit, cap) || batch_alloc(r, &ss.hitPrim, cap) || batch_alloc(r, &ss.pathNee, K ? cap : 1) ||
         batch_alloc(r, &ss.neeRay, cap*K*2) || batch_alloc(r, &ss.neeSky, r->scene.probe.valid ? cap : 1) ||
-        batch_alloc(r, &ss.neeMeta, K ? cap : 1) || batch_alloc(r, &ss.neeRes, cap*K) ||
+        batch_alloc(r, &ss.neeTime, K ? cap : 1) || batch_alloc(r, &ss.neeRes, cap*K) ||
         batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)) ||
         batch_alloc(r, &ss.neeFront, maxRegions*(size_t)maxDepth) || batch_alloc(r, &ss.neeBack, maxRegions*(size_t)maxDepth))
         return -1;
@@ -695,8 +695,11 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
         if (step >= ss.numRegions)
             step = 1;
     }
-    hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, regionCounts, ss.numRegions, step, r->segPrefix);
-    hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
+    {
+        ScopedTimer t(r, KN_SEG, st);
+        hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, regionCounts, ss.numRegions, step, r->segPrefix);
+        hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
+    }
     WalkJob& job = a.walk;
     job.queue = r->walkList;
     job.frontCount = r->segPrefix + ss.numRegions;
@@ -704,7 +707,7 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     job.rayD = ss.rayD[a.bounce & 1];
     job.nee = ss.neeRay;
     job.neeStride = ss.capacity;
-    job.neeMeta = ss.neeMeta;
+    job.neeTime = ss.neeTime;
     job.rec = r->walkRec;
     job.neePerPath = shadowRays ? r->neePerPath : 0;
     job.numPrims = r->walkPrims.count;
@@ -744,6 +747,7 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
     a.walkBig = big ? 1 : 0;
     a.ldsBytes = (uint32_t)lds;
+    ScopedTimer t(r, KN_WALK, st);
     launch_path(r, PK_WALK, a, st);
 }
 
@@ -927,7 +931,6 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             a.bounce = bounce;
             if (walk)
             {
-                ScopedTimer t(r, KN_WALK, st);
                 a.grid = gridPersist;
                 launch_walk(r, st, a, r->ss.segFront + (size_t)bounce*W, false);
             }
@@ -949,7 +952,6 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 }
                 if (walk)
                 {
-                    ScopedTimer t(r, KN_WALK, st);
                     a.grid = gridPersist;
                     launch_walk(r, st, a, r->ss.neeFront + (size_t)bounce*W, true);
                 }

@@ -679,7 +679,7 @@ struct SplitState
     uint32_t* pathNee;  // [position] NEE position q of the path's shadow rays of this bounce
     float4* neeRay;     // [(k*2 + {0, 1})*capacity + q] = {o, dist} {wi, nl}: lanes are consecutive q        (k_lights -> k_walk, k_shadow, k_shade)
     float4* neeSky;     // [q] the probe sample's {skyColor, skyPdf}                                           (k_lights -> k_shade)
-    float2* neeMeta;    // [q] {position of the path (bits), rayTime}                                          (k_lights -> k_walk, k_shadow)
+    float* neeTime;     // [q] rayTime of the path                                                              (k_lights -> k_walk, k_shadow)
     float2* neeRes;     // [k*capacity + q] = {primitive whose emission arrives (int bits; < 0: nothing does), t}  (k_shadow -> k_shade)
     float4* radOut;     // [slot] radiance of finished paths (PathState::rad: what the accumulate kernels read)
     uint32_t* segFront; // [bounce][region] paths packed at the front of the region when the bounce starts
@@ -852,7 +852,7 @@ TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& b
             nee_sample_light(sc, hitP, hitN, time, lights.next(sc), rng, g);
             store_nee_ray(ss, qn, k, g);
         }
-        ss.neeMeta[qn] = make_float2(__uint_as_float(pos), time);
+        ss.neeTime[qn] = time;
         ss.pathNee[pos] = qn;
         *reinterpret_cast<float2*>(ss.rngId[cur] + pos) = make_float2(__uint_as_float(rng.s1), __uint_as_float(rng.s2));
     }
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
             if (j >= n)
                 continue;
             const uint32_t qn = region_pos(r*ss.regionLen, ss.regionLen, nFront, j);
-            const float time = ss.neeMeta[qn].y;
+            const float time = ss.neeTime[qn];
 
             for (int k = 0; k < K; ++k)
             {

@@ -48,7 +48,7 @@ struct WalkJob
     const float4* rayD;
     const float4* nee;              // shadow rays: SplitState::neeRay [(k*2 + {0: o|dist, 1: wi|nl})*neeStride + q] by NEE position q
     uint32_t neeStride;
-    const float2* neeMeta;          // shadow rays: SplitState::neeMeta [q] = {path position, rayTime}
+    const float* neeTime;           // shadow rays: SplitState::neeTime [q]
     float4* rec;                    // out: [((position*K + k)*numPrims + walked primitive)][2] = {t,u,v,w} {n.xyz, tri};  t == FLT_MAX: no hit
     int neePerPath;                 // 0: extension rays; K > 0: the K shadow rays of every queued slot
     int numPrims;                   // walked primitives (1..7)
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     {
                         const float4* np = job.nee + (size_t)(k*2u)*job.neeStride + slot;
                         ro = np[0]; rd = np[job.neeStride];
-                        time = job.neeMeta[slot].y;
+                        time = job.neeTime[slot];
                     }
                     else
                     {
