@@ -261,6 +261,7 @@ struct ArenaBuilder
 };
 
 constexpr size_t kSmallMeshBytes = 4096;        // meshes up to this size ride inside the arena
+constexpr int kInlineMaxTris = 7;               // ... of a scene that has a mesh in HBM, only up to this many triangles
 constexpr int kWalkTopNodes = 2048;             // internal nodes of a mesh in HBM numbered breadth-first (128 KB: more than LDS can take)
 constexpr size_t kArenaLdsLimit = 32768;        // arenas up to this size are staged into LDS by the kernels
 
@@ -1367,6 +1368,26 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
 
     bool ok = true;
 
+    // Where meshes live.  A scene all of whose meshes are small (<= 4 KB each; cornell's boxes) keeps them in the arena,
+    // is staged whole into LDS and runs the fused kernel.  Once ONE mesh has to live in HBM the scene runs the split
+    // pipeline, and there only meshes of a few triangles are worth walking inline from the arena: the others go to HBM
+    // too and are walked by k_walk (glass.tin's 12-triangle cube: k_extend + k_shadow + k_walk 34.7 -> 31.3 ms; its
+    // 2-triangle lamp stays inline -- every shadow ray enters its box).
+    auto mesh_bytes_estimate = [](const tinsel_mesh_geometry& g) {
+        return (size_t)g.num_nodes*32 + (size_t)(g.num_indices/3)*52 + (size_t)g.num_vertices*12;
+    };
+    bool sceneHasBigMesh = false;
+    for (int i = 0; i < P; ++i)
+        if (desc->primitives[i].type == TINSEL_GEOM_MESH && mesh_bytes_estimate(desc->primitives[i].geo.mesh) > kSmallMeshBytes)
+            sceneHasBigMesh = true;
+    const int inlineMaxTris = getenv("TINSEL_HIP_INLINE_MAX_TRIS") ? atoi(getenv("TINSEL_HIP_INLINE_MAX_TRIS")) : kInlineMaxTris;
+    auto lives_in_arena = [&](size_t meshBytes, int numTris) {
+        // TINSEL_HIP_SMALL_MESH_BYTES: test / A-B knob (0 = every mesh lives in HBM, so the queue sort and k_walk see them all)
+        if (getenv("TINSEL_HIP_SMALL_MESH_BYTES"))
+            return meshBytes <= (size_t)atoll(getenv("TINSEL_HIP_SMALL_MESH_BYTES"));
+        return sceneHasBigMesh ? numTris <= inlineMaxTris && meshBytes <= kSmallMeshBytes : meshBytes <= kSmallMeshBytes;
+    };
+
     for (int i = 0; i < P && ok; ++i)
     {
         const tinsel_primitive& p = desc->primitives[i];
@@ -1438,9 +1459,8 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                     break;
                 }
                 ConvertedBvh cb;
-                const size_t roughBytes = (size_t)g.num_nodes*32 + (size_t)numTris*48 + (size_t)g.num_vertices*12 + (size_t)numTris*4;
                 // meshes that will live in HBM: the upper levels breadth-first (k_walk's LDS-resident top, tn_walk.h)
-                if (!convert_bvh(g.nodes, g.num_nodes, numTris, roughBytes > kSmallMeshBytes ? kWalkTopNodes : 0, cb))
+                if (!convert_bvh(g.nodes, g.num_nodes, numTris, lives_in_arena(mesh_bytes_estimate(g), numTris) ? 0 : kWalkTopNodes, cb))
                 {
                     fail("create: malformed mesh BVH");
                     ok = false;
@@ -1471,9 +1491,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 dm.stackNeed = cb.maxLeafDepth + 1;
                 dm.topCount = cb.topCount;
                 const size_t meshBytes = cb.nodes.size()*sizeof(Node64) + tris.size()*sizeof(Tri48) + (size_t)g.num_vertices*12 + (size_t)numTris*4;
-                // TINSEL_HIP_SMALL_MESH_BYTES: test / A-B knob (0 = every mesh lives in HBM, so the queue sort and k_walk see them all)
-                const size_t smallLimit = getenv("TINSEL_HIP_SMALL_MESH_BYTES") ? (size_t)atoll(getenv("TINSEL_HIP_SMALL_MESH_BYTES")) : kSmallMeshBytes;
-                if (meshBytes <= smallLimit)
+                if (lives_in_arena(meshBytes, numTris))
                 {
                     // offsets for now; turned into pointers once the arena has its device address
                     dm.inArena = 1;
@@ -1558,11 +1576,11 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         const bool flatScan = everyPrimHasALeaf && P <= 64 && !getenv("TINSEL_HIP_NO_FLAT_SCAN");
 
         // primitives whose mesh lives in HBM (flat-scan scenes, the first 7): their leaf-box test sorts the ray queues
-        // (k_generate, k_shade).  Of those, the ones with at least 256 triangles are walked by k_walk ahead of the scan kernels
-        // (tn_walk.h).  That includes trees that stay in L1/L2 (glass.tin's 1280-triangle sphere: 80 KB of nodes): what the
-        // lean kernel buys there is ray replacement for incoherent bounces (glass, maxDepth 12: 924 -> 1001 Msamples/s; with
-        // k_walk's work list in image order it had lost, 732 inline vs 657-690).
-        const int walkMinTris = getenv("TINSEL_HIP_WALK_MIN_TRIS") ? atoi(getenv("TINSEL_HIP_WALK_MIN_TRIS")) : 256;
+        // (k_generate, k_shade), and they are walked by k_walk ahead of the scan kernels (tn_walk.h).  That includes trees
+        // that stay in L1/L2 (glass.tin's 1280-triangle sphere: 80 KB of nodes; its 12-triangle cube): what the lean kernel
+        // buys there is ray replacement for incoherent bounces (glass, maxDepth 12: 924 -> 1001 Msamples/s with the sphere,
+        // 1050 with the cube too; with k_walk's work list in image order the sphere had lost, 732 inline vs 657-690).
+        const int walkMinTris = getenv("TINSEL_HIP_WALK_MIN_TRIS") ? atoi(getenv("TINSEL_HIP_WALK_MIN_TRIS")) : kInlineMaxTris + 1;
         r->binPrims.count = 0;
         r->walkPrims.count = 0;
         if (flatScan)
@@ -1639,6 +1657,12 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 if (mm.absorption[0] != 0.0f || mm.absorption[1] != 0.0f || mm.absorption[2] != 0.0f)
                     sc.hasMedia = 1;
             sc.flatScan = flatScan ? 1 : 0;
+            {
+                int meshPrimCount = 0;
+                for (int k = 0; k < P; ++k)
+                    meshPrimCount += prims[(size_t)k].type == kPrimMesh ? 1 : 0;
+                sc.deferMeshes = (meshPrimCount >= 2 && !getenv("TINSEL_HIP_NO_DEFER_MESHES")) ? 1 : 0;
+            }
             // Fused kernel: sort the next bounce's queue by "meets the box of a bounded primitive" (tn_isect.h) when the
             // scene is open.  Measured (cornell-sized frames, fused kernel): env_loft (1 plane) +16 %, gloss (1 plane) +4 %;
             // the closed boxes cornell / cornell+probe (5 planes, every NEE ray aimed at the light mesh) -4 %: the test and

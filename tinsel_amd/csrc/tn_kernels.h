@@ -244,8 +244,8 @@ TN_D void wave_add_stat(unsigned long long* stats, int word, uint32_t v)
 //                 kernel-argument pointers are global, and global + delta would be issued as a global
 //                 load of an LDS aperture address.
 // MUST be reached by every thread of the block.
-template <bool LDS, bool WONLY>
-TN_D void stage_scene_lds(SceneT<LDS, WONLY>& sc, const DevScene& in, uint32_t* ldsWords)
+template <bool LDS, bool WONLY, int DEFER>
+TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER>& sc, const DevScene& in, uint32_t* ldsWords)
 {
     static_cast<DevScene&>(sc) = in;
     unsigned char* lds = reinterpret_cast<unsigned char*>(ldsWords);
@@ -448,7 +448,7 @@ TN_D bool begin_path(const CameraParams& cam, const FrameParams& fp, const uint3
 #define TN_CTR_NEE ctr
 #endif
 
-template <bool COUNT, bool FIRST, bool LDS>
+template <bool COUNT, bool FIRST, bool LDS, bool DEFER>
 __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueIn,
                                                    uint32_t* __restrict__ queueOut, int bounce, int stackEntries, CameraParams cam,
                                                    FrameParams fp, const uint32_t* __restrict__ passSeeds)
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
 
     uint32_t* s_scan = s_stack + stackEntries*kBlock;
-    SceneT<LDS> sc;
+    SceneT<LDS, false, DEFER ? 1 : 0> sc;
     stage_scene_lds(sc, scIn, s_scan + kScanWords);
 
     const uint32_t frontCount = FIRST ? 0u : q.activeCount[bounce], backCount = FIRST ? 0u : q.activeBack[bounce];
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
             TN_TICK(0)
             float t;
             V3 n;
-            const int prim = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n, ctr);
+            const int prim = trace<SceneT<LDS, false, DEFER ? 1 : 0>, LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n, ctr);
             rays++;
             TN_TICK(1)
 
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                         TN_TICK(2)
                         float ts;
                         V3 nn;
-                        const int hp = trace<SceneT<LDS>, LdsStack<kBlock>, COUNT>(sc, st, g.o, g.wi, p.time, ts, nn, TN_CTR_NEE);
+                        const int hp = trace<SceneT<LDS, false, DEFER ? 1 : 0>, LdsStack<kBlock>, COUNT>(sc, st, g.o, g.wi, p.time, ts, nn, TN_CTR_NEE);
                         TN_TICK(3)
                         rays++;
                         shadowRays++;

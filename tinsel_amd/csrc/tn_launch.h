@@ -87,17 +87,22 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             hipLaunchKernelGGL((k_shade<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins);
         break;
     case PK_BOUNCE:
-#define TN_LAUNCH_BOUNCE(FIRST)                                                                                        \
+#define TN_LAUNCH_BOUNCE(FIRST, DEFER)                                                                                 \
         do {                                                                                                           \
-            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, FIRST, true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
-                         else hipLaunchKernelGGL((k_bounce<true, FIRST, false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
-            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, FIRST, true>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
-                         else hipLaunchKernelGGL((k_bounce<false, FIRST, false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
+            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, FIRST, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
+                         else hipLaunchKernelGGL((k_bounce<true, FIRST, false, false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
+            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, FIRST, true, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
+                         else hipLaunchKernelGGL((k_bounce<false, FIRST, false, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
         } while (0)
-        if (a.bounce == 0)
-            TN_LAUNCH_BOUNCE(true);
+        // (the detail-counting variants walk the scene BVH: nothing to defer)
+        if (a.scene.deferMeshes)
+        {
+            if (a.bounce == 0) TN_LAUNCH_BOUNCE(true, true); else TN_LAUNCH_BOUNCE(false, true);
+        }
         else
-            TN_LAUNCH_BOUNCE(false);
+        {
+            if (a.bounce == 0) TN_LAUNCH_BOUNCE(true, false); else TN_LAUNCH_BOUNCE(false, false);
+        }
 #undef TN_LAUNCH_BOUNCE
         break;
     case PK_WALK:

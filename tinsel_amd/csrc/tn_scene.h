@@ -161,7 +161,7 @@ struct DevScene
     int32_t flatScan;           // 1: few primitives -> scene level is a wave-uniform scan (trace_flat)
     int32_t hasMedia;           // 0: no material absorbs, rayAbsorption stays 0 -> its 16-B state record is skipped
     int32_t sortQueues;         // 1: the fused kernel sorts the next bounce's queue by ray_meets_bounded_prim (open scenes)
-    int32_t padScene;
+    int32_t deferMeshes;        // 1: trace_flat walks the meshes a ray enters after the scan, all lanes together (>= 2 mesh primitives)
 };
 
 // Compile-time view of where the scene lives.  SceneT<true>: the whole scene (arena incl. every mesh)
@@ -169,11 +169,14 @@ struct DevScene
 // SceneT<false>: generic pointers (HBM, or an LDS copy reached through flat loads).
 // WALKED_ONLY: every mesh primitive of the scene has its closest hits precomputed by k_walk (tn_walk.h), so the scan
 // kernels are compiled without the inline mesh walk (no deep stack, half the registers, twice the waves).
-template <bool LDS, bool WALKED_ONLY = false>
+// DEFER: trace_flat's deferred mesh walks (tn_isect.h) compiled out (0), in (1), or behind DevScene::deferMeshes (2).  The
+// fused kernel is built both ways -- the second loop costs 2 % where there is nothing to defer (cornell).
+template <bool LDS, bool WALKED_ONLY = false, int DEFER = 2>
 struct SceneT : DevScene
 {
     static constexpr bool kLds = LDS;
     static constexpr bool kWalkedOnly = WALKED_ONLY;
+    static constexpr int kDefer = DEFER;
     const unsigned char* ldsBase;
     // closest-hit records of the walked primitives for the ray being traced (tn_walk.h): record lane kb of the ray
     // lives at walkRec[(walkItem + kb)*2 .. +1]; null = walk the mesh inline (ray_mesh)
