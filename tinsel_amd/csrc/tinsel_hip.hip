@@ -693,7 +693,7 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
         auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
         while (step > 1 && gcd(step, ss.numRegions) != 1)
             step -= 1;
-        if (step >= ss.numRegions)
+        if (step >= ss.numRegions || ss.numRegions > 65535u)       // k_seg_prefix multiplies in 32 bits
             step = 1;
     }
     {

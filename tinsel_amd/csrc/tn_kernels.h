@@ -1195,7 +1195,8 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
     const uint32_t end = (begin + piece) < numRegions ? (begin + piece) : numRegions;
 
     // the list visits the regions `step` apart (coprime to their number): entry i of the scan is region i*step mod numRegions
-    auto region = [&](uint32_t i) -> uint32_t { return (uint32_t)(((unsigned long long)i*step) % numRegions); };
+    // (numRegions <= 65535, checked by the host: the product fits 32 bits)
+    auto region = [&](uint32_t i) -> uint32_t { return (i*step) % numRegions; };
     uint32_t sum = 0;
     for (uint32_t i = begin + lane; i < end; i += kWave)
         sum += counts[region(i)];
