@@ -355,7 +355,8 @@ int tinsel_hip_nee_per_path(tinsel_hip* r);
  * split pipeline; tn_walk.h).  0: every mesh is walked inline, as IntersectRayMesh is called in the reference. */
 int tinsel_hip_walked_prims(tinsel_hip* r);
 /* Queue lengths of the LAST batch of the wavefront pipelines: out[b] = paths alive at the start of bounce b (entries of the
- * extension queue), out[max_bounces + b] = paths with shadow rays at bounce b (split pipeline; 0 otherwise).  Synchronises.
+ * extension queue; bounce 0: the paths generated, tile padding of a shard included), out[max_bounces + b] = paths with
+ * shadow rays at bounce b (split pipeline; 0 otherwise).  Synchronises.
  * Returns the number of bounces written (<= max_bounces), or -1. */
 int tinsel_hip_queue_counts(tinsel_hip* r, uint32_t* out, int max_bounces);
 

@@ -2456,8 +2456,9 @@ int tinsel_hip_queue_counts(tinsel_hip* r, uint32_t* out, int max_bounces)
     const size_t D = (size_t)r->batchDepth + 1;
     for (int b = 0; b < n; ++b)
     {
-        out[b] = ctl[(size_t)b] + ctl[5*D + (size_t)b];
-        out[max_bounces + b] = ctl[D + (size_t)b] + ctl[6*D + (size_t)b];
+        // the fused kernel generates bounce 0's paths itself: there is no queue 0
+        out[b] = b == 0 ? r->lastFp.genCount : ctl[(size_t)b] + ctl[5*D + (size_t)b];
+        out[max_bounces + b] = 0;
     }
     return n;
 }
