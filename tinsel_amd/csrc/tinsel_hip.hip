@@ -343,12 +343,10 @@ struct tinsel_hip
     std::vector<void*> batchAllocs;
     PathState ps;
     QueueCtl ctl;
-    uint32_t* ctlBase = nullptr;
-    size_t ctlWords = 0;
-    uint32_t* queues[2] = { nullptr, nullptr };
-    // the split pipeline's dense state (SplitState, tn_kernels.h), allocated when that pipeline first runs
+    // the wavefront pipelines' dense state (SplitState, tn_kernels.h); the split pipeline's hit / shadow-ray arrays only when
+    // that is the pipeline in force
     SplitState ss;
-    bool batchSplit = false;            // ss is allocated for the current batch buffers
+    int batchPipeline = -1;             // the pipeline the current batch buffers were allocated for
     size_t splitCap = 0;                // positions per SplitState array: the batch slots + one wave of padding per region
     uint32_t splitMaxRegions = 0;
     uint32_t* walkList = nullptr;       // k_walk's work list (k_seg_expand) and the prefix of the regions' front counts behind it
@@ -410,7 +408,7 @@ void free_batch(tinsel_hip* r)
         (void)hipFree(p);
     r->batchAllocs.clear();
     r->walkRec = nullptr;
-    r->batchSplit = false;
+    r->batchPipeline = -1;
     r->batchSlots = 0;
     r->batchNee = -1;
     r->batchDepth = -1;
@@ -445,10 +443,11 @@ int resolve_pipeline(const tinsel_hip* r)
     return r->scene.allInArena ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
 }
 
-// The split pipeline's state (SplitState, tn_kernels.h): by POSITION, two buffers of everything a bounce rewrites
-int alloc_split(tinsel_hip* r, size_t slots, int maxDepth)
+// The wavefront pipelines' state (SplitState, tn_kernels.h): by POSITION, two buffers of everything a bounce rewrites; for the
+// split pipeline also what its kernels hand to each other (hit, shadow rays and their results, k_walk's records and list)
+int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
 {
-    const size_t K = (size_t)r->neePerPath;
+    const size_t K = split ? (size_t)r->neePerPath : 0;
     const size_t maxRegions = (size_t)r->numCUs*(size_t)grid_mult()*(kBlock/kWave);
     const size_t cap = slots + maxRegions*kWave;        // a region is a whole number of waves long
     SplitState& ss = r->ss;
@@ -457,21 +456,25 @@ int alloc_split(tinsel_hip* r, size_t slots, int maxDepth)
         if (batch_alloc(r, &ss.rayO[b], cap) || batch_alloc(r, &ss.rayD[b], cap) || batch_alloc(r, &ss.thr[b], cap) ||
             batch_alloc(r, &ss.rad[b], cap) || batch_alloc(r, &ss.absorb[b], r->scene.hasMedia ? cap : 1) || batch_alloc(r, &ss.rngId[b], cap))
             return -1;
-    if (batch_alloc(r, &ss.hit, cap) || batch_alloc(r, &ss.hitPrim, cap) || batch_alloc(r, &ss.pathNee, K ? cap : 1) ||
-        batch_alloc(r, &ss.neeRay, cap*K*2) || batch_alloc(r, &ss.neeSky, r->scene.probe.valid ? cap : 1) ||
-        batch_alloc(r, &ss.neeTime, K ? cap : 1) || batch_alloc(r, &ss.neeRes, cap*K) ||
-        batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)) ||
-        batch_alloc(r, &ss.neeFront, maxRegions*(size_t)maxDepth) || batch_alloc(r, &ss.neeBack, maxRegions*(size_t)maxDepth))
+    if (batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)))
         return -1;
     ss.radOut = r->ps.rad;
-    ss.neePerPath = (int32_t)K;
     ss.capacity = (uint32_t)cap;
     r->splitCap = cap;
     r->splitMaxRegions = (uint32_t)maxRegions;
-    // k_walk: one 32-B closest hit per (ray, walked primitive), by position; extension and shadow rays share the buffer
     r->walkRec = nullptr;
     r->walkList = nullptr;
     r->segPrefix = nullptr;
+    if (!split)
+        return 0;
+
+    if (batch_alloc(r, &ss.hit, cap) || batch_alloc(r, &ss.hitPrim, cap) || batch_alloc(r, &ss.pathNee, K ? cap : 1) ||
+        batch_alloc(r, &ss.neeRay, cap*K*2) || batch_alloc(r, &ss.neeSky, r->scene.probe.valid ? cap : 1) ||
+        batch_alloc(r, &ss.neeTime, K ? cap : 1) || batch_alloc(r, &ss.neeRes, cap*K) ||
+        batch_alloc(r, &ss.neeFront, maxRegions*(size_t)maxDepth) || batch_alloc(r, &ss.neeBack, maxRegions*(size_t)maxDepth))
+        return -1;
+    ss.neePerPath = (int32_t)K;
+    // k_walk: one 32-B closest hit per (ray, walked primitive), by position; extension and shadow rays share the buffer
     if (r->walkPrims.count > 0 && r->walkEnabled && (double)cap*(K > 1 ? K : 1)*r->walkPrims.count < 2147483648.0)
         if (batch_alloc(r, &r->walkRec, cap*(size_t)(K > 1 ? K : 1)*(size_t)r->walkPrims.count*2) || batch_alloc(r, &r->walkList, cap) ||
             batch_alloc(r, &r->segPrefix, maxRegions + 1))
@@ -482,47 +485,27 @@ int alloc_split(tinsel_hip* r, size_t slots, int maxDepth)
 int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
 {
     const int K = r->neePerPath;
-    const bool split = resolve_pipeline(r) == TINSEL_PIPELINE_WAVEFRONT_SPLIT;
-    if (r->batchSlots >= slots && r->batchNee == K && r->batchDepth >= maxDepth && r->batchSplit == split)
+    const int pipeline = resolve_pipeline(r);
+    if (r->batchSlots >= slots && r->batchNee == K && r->batchDepth >= maxDepth && r->batchPipeline == pipeline)
         return 0;
     free_batch(r);
 
-    // the radiance of finished paths by slot is what every pipeline hands to the accumulate kernels; the rest of the
-    // by-slot state belongs to the fused and megakernel pipelines
+    // the radiance of finished paths by slot is what every pipeline hands to the accumulate kernels
     PathState& ps = r->ps;
     memset(&ps, 0, sizeof(ps));
     if (batch_alloc(r, &ps.rad, slots))
         return -1;
-    if (split)
-    {
-        if (alloc_split(r, slots, maxDepth))
-            return -1;
-    }
-    else if (batch_alloc(r, &ps.rayO, slots) || batch_alloc(r, &ps.rayD, slots) || batch_alloc(r, &ps.thr, slots) ||
-             batch_alloc(r, &ps.absorb, slots) || batch_alloc(r, &ps.rngRaster, slots) ||
-             batch_alloc(r, &r->queues[0], slots) || batch_alloc(r, &r->queues[1], slots))
+    if (pipeline != TINSEL_PIPELINE_MEGAKERNEL && alloc_dense(r, slots, maxDepth, pipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT))
         return -1;
 
     // slots of other shards are never written (gen_slot): keep their radiance at zero for the test hook
     HIP_TRY(hipMemset(ps.rad, 0, sizeof(float4)*slots));
 
-    const size_t D = (size_t)maxDepth + 1;
-    r->ctlWords = D*7;
-    if (batch_alloc(r, &r->ctlBase, r->ctlWords))
-        return -1;
-    r->ctl.activeCount = r->ctlBase;
-    r->ctl.neeCount = r->ctlBase + D;
-    r->ctl.cursorExtend = r->ctlBase + 2*D;
-    r->ctl.cursorShade = r->ctlBase + 3*D;
-    r->ctl.cursorShadow = r->ctlBase + 4*D;
-    r->ctl.activeBack = r->ctlBase + 5*D;
-    r->ctl.neeBack = r->ctlBase + 6*D;
     r->ctl.stats = r->statsDev;
-
     r->batchSlots = slots;
     r->batchNee = K;
     r->batchDepth = maxDepth;
-    r->batchSplit = split;
+    r->batchPipeline = pipeline;
     return 0;
 }
 
@@ -800,13 +783,13 @@ int accumulate_tile_list(tinsel_hip* r, const FrameParams& fp)
     return 0;
 }
 
-// Paths resident per batch.  Default 8 Mi (1 GB of state): best for scenes that live in LDS.  Scenes with meshes
-// in HBM run the split pipeline, whose trace launches end in a long tail (the slowest block of a deep traversal):
-// fewer, larger launches amortise it -- 524k-triangle config 765 / 941 / 992 Msamples/s at 8 / 32 / 64 Mi -- so
-// those default to 64 Mi (13 GB of 288).  An explicit setting always wins.
+// Paths resident per batch: 64 Mi for the wavefront pipelines (11 GB of path state of 288), 8 Mi for the megakernel arm.
+// The split pipeline's trace launches end in a long tail (the slowest block of a deep traversal) and fewer, larger launches
+// amortise it -- 524k-triangle config 765 / 941 / 992 Msamples/s at 8 / 32 / 64 Mi (round 1); the fused kernel wants its
+// regions long (set_regions): cornell 2302 / 2803 Msamples/s at 8 / 64 Mi.  An explicit setting always wins.
 size_t batch_slots(const tinsel_hip* r)
 {
-    if (!r->batchSlotsExplicit && !r->scene.allInArena && r->pipeline != TINSEL_PIPELINE_MEGAKERNEL)
+    if (!r->batchSlotsExplicit && r->pipeline != TINSEL_PIPELINE_MEGAKERNEL)
         return (size_t)64u << 20;
     return r->maxBatchSlots;
 }
@@ -853,6 +836,32 @@ int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, floa
     return 0;
 }
 
+// Blocks of the streaming kernels' grid = a quarter of the regions the batch is cut into (one region per wave, SplitState,
+// tn_kernels.h).  A wave works through its region 64 entries at a time and a round is as long as its slowest lane, so
+// regions should stay long as paths die (the last round of a region is the ragged one), yet there must be enough of them to
+// balance: ~1024 positions per region, between 2 and 32 blocks per CU.  Fused kernel, cornell: a 1 M-path batch 1417 / 1520 /
+// 1655 / 1747 Msamples/s at 16 / 8 / 4 / 2 blocks per CU (regions of 64 ... 512); a 64 Mi batch 2644 / 2735 / 2803 at 8 / 16 /
+// 32 (regions of 8192 / 4096 / 2048).
+int streaming_grid(const tinsel_hip* r, size_t slots)
+{
+    static const size_t regionTarget = getenv("TINSEL_HIP_REGION_LEN") ? (size_t)std::max(64, atoi(getenv("TINSEL_HIP_REGION_LEN"))) : 1024;
+    const size_t perBlock = regionTarget*(kBlock/kWave);
+    const size_t blocks = (slots + perBlock - 1)/perBlock;
+    const size_t lo = std::min<size_t>((size_t)r->numCUs*2, (slots + kBlock - 1)/kBlock), hi = (size_t)r->numCUs*(size_t)grid_mult();
+    return (int)std::max<size_t>(1, std::min(hi, std::max(lo, blocks)));
+}
+
+int set_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int gridPersist)
+{
+    a.ss = r->ss;
+    a.ss.numRegions = (uint32_t)gridPersist*(kBlock/kWave);
+    a.ss.regionLen = (uint32_t)(((slots + a.ss.numRegions - 1)/a.ss.numRegions + kWave - 1)/kWave*kWave);
+    if (a.ss.numRegions > r->splitMaxRegions || (size_t)a.ss.numRegions*a.ss.regionLen > r->splitCap)
+        return fail("render: path buffers too small for this batch");
+    r->lastRegions = a.ss.numRegions;
+    return 0;
+}
+
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp, bool accumulate = true)
 {
     const size_t npix = (size_t)fp.width*fp.height;
@@ -866,17 +875,15 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     fp.accBegin = 0;
     fp.accEnd = fp.numPasses;
     fp.rrStart = r->rrStart;
-    fp.queueCapacity = (uint32_t)r->batchSlots;
     const int gridFlat = (int)std::max<size_t>(1, (slots + kBlock - 1)/kBlock);
-    const int gridMult = grid_mult();
-    const int gridPersist = (int)std::max<size_t>(1, std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMult));
-    static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : gridMult;
-    const int gridTrace = (int)std::max<size_t>(1, std::min<size_t>((size_t)((slots + kBlock - 1)/kBlock), (size_t)r->numCUs*(size_t)gridMultTrace));
-    HIP_TRY(hipMemsetAsync(r->ctlBase, 0, r->ctlWords*sizeof(uint32_t), st));
+    const int gridPersist = streaming_grid(r, slots);
+    // the trace kernels stride over the regions: by default one block per four regions like the others
+    static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : 0;
+    const int gridTrace = gridMultTrace > 0 ? std::max(1, std::min(gridPersist, r->numCUs*gridMultTrace)) : gridPersist;
     r->lastBatchSlots = slots;
 
     const int pipeline = resolve_pipeline(r);
-    if ((pipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT) != r->batchSplit)
+    if (pipeline != r->batchPipeline)
         return fail("render: path buffers were reserved for another pipeline");
     r->lastPipeline = pipeline;
 
@@ -889,13 +896,13 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     }
     else if (pipeline == TINSEL_PIPELINE_WAVEFRONT)
     {
+        if (set_regions(r, a, slots, gridPersist))
+            return -1;
         a.grid = gridPersist;
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
             ScopedTimer t(r, KN_BOUNCE, st);
             a.bounce = bounce;
-            a.queueIn = r->queues[bounce & 1];
-            a.queueOut = r->queues[(bounce + 1) & 1];
             launch_path(r, PK_BOUNCE, a, st);
         }
     }
@@ -914,13 +921,8 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         a.walkedOnly = walkedOnly ? 1 : 0;
         // the lean k_extend draws the light samples itself (tn_launch.h launches it when walkedOnly and not counting)
         const bool lightsInExtend = walkedOnly && !r->countDetail;
-        // one region per wave of the streaming grid (SplitState, tn_kernels.h)
-        a.ss = r->ss;
-        a.ss.numRegions = (uint32_t)gridPersist*(kBlock/kWave);
-        a.ss.regionLen = (uint32_t)(((slots + a.ss.numRegions - 1)/a.ss.numRegions + kWave - 1)/kWave*kWave);
-        if (a.ss.numRegions > r->splitMaxRegions || (size_t)a.ss.numRegions*a.ss.regionLen > r->splitCap)
-            return fail("render: split-pipeline buffers too small for this batch");
-        r->lastRegions = a.ss.numRegions;
+        if (set_regions(r, a, slots, gridPersist))
+            return -1;
         const size_t W = a.ss.numRegions;
         {
             ScopedTimer t(r, KN_GENERATE, st);
@@ -2425,40 +2427,31 @@ int tinsel_hip_queue_counts(tinsel_hip* r, uint32_t* out, int max_bounces)
 {
     if (!r || !out || max_bounces < 1)
         return fail("queue_counts: bad arguments");
-    if (!r->ctlBase || r->batchDepth < 1)
+    if (r->batchPipeline < 0 || r->batchDepth < 1)
         return fail("queue_counts: nothing rendered yet");
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipDeviceSynchronize());
     const int n = std::min(max_bounces, std::min(r->batchDepth, r->lastFp.maxDepth));
-    if (r->lastPipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT && r->batchSplit)
-    {
-        // the split pipeline keeps its counts per region
-        const size_t W = r->lastRegions;
-        std::vector<uint32_t> seg(W*(size_t)n*4);
-        uint32_t* const src[4] = { r->ss.segFront, r->ss.segBack, r->ss.neeFront, r->ss.neeBack };
-        for (int a = 0; a < 4; ++a)
-            HIP_TRY(hipMemcpy(seg.data() + (size_t)a*W*n, src[a], W*(size_t)n*sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (int b = 0; b < n; ++b)
-        {
-            unsigned long long live = 0, nee = 0;
-            for (size_t g = 0; g < W; ++g)
-            {
-                live += seg[(size_t)b*W + g] + seg[W*n + (size_t)b*W + g];
-                nee += seg[2*W*n + (size_t)b*W + g] + seg[3*W*n + (size_t)b*W + g];
-            }
-            out[b] = (uint32_t)live;
-            out[max_bounces + b] = r->neePerPath > 0 ? (uint32_t)nee : 0u;
-        }
-        return n;
-    }
-    std::vector<uint32_t> ctl(r->ctlWords);
-    HIP_TRY(hipMemcpy(ctl.data(), r->ctlBase, r->ctlWords*sizeof(uint32_t), hipMemcpyDeviceToHost));
-    const size_t D = (size_t)r->batchDepth + 1;
+    if (r->lastPipeline == TINSEL_PIPELINE_MEGAKERNEL || r->batchPipeline != r->lastPipeline)
+        return fail("queue_counts: the last batch did not run a wavefront pipeline");
+    // the counts are kept per region
+    const bool split = r->lastPipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT && r->neePerPath > 0;
+    const size_t W = r->lastRegions;
+    std::vector<uint32_t> seg(W*(size_t)n*4, 0u);
+    uint32_t* const src[4] = { r->ss.segFront, r->ss.segBack, r->ss.neeFront, r->ss.neeBack };
+    for (int a = 0; a < (split ? 4 : 2); ++a)
+        HIP_TRY(hipMemcpy(seg.data() + (size_t)a*W*n, src[a], W*(size_t)n*sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int b = 0; b < n; ++b)
     {
-        // the fused kernel generates bounce 0's paths itself: there is no queue 0
-        out[b] = b == 0 ? r->lastFp.genCount : ctl[(size_t)b] + ctl[5*D + (size_t)b];
-        out[max_bounces + b] = 0;
+        unsigned long long live = 0, nee = 0;
+        for (size_t g = 0; g < W; ++g)
+        {
+            live += seg[(size_t)b*W + g] + seg[W*n + (size_t)b*W + g];
+            nee += seg[2*W*n + (size_t)b*W + g] + seg[3*W*n + (size_t)b*W + g];
+        }
+        // the fused kernel generates bounce 0's paths itself
+        out[b] = (b == 0 && r->lastPipeline == TINSEL_PIPELINE_WAVEFRONT) ? r->lastFp.genCount : (uint32_t)live;
+        out[max_bounces + b] = (uint32_t)nee;
     }
     return n;
 }

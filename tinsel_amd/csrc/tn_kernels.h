@@ -51,28 +51,16 @@ constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
 // ---------------------------------------------------------------------------
-// per-batch path state (SoA of 16-B records, one per path slot)
+// What every pipeline hands to the accumulate kernels: the radiance of the batch's finished paths, by path slot
+// (slot <-> (pass, pixel): slot_pixel / slot_of below).  The path state of the wavefront pipelines is SplitState (below).
 
 struct PathState
 {
-    float4* rayO;       // origin.xyz, time
-    float4* rayD;       // dir.xyz, bsdfPdf
-    float4* thr;        // throughput.xyz, rayEta
-    float4* rad;        // radiance.xyz, rayType (int bits)
-    float4* absorb;     // rayAbsorption.xyz, -
-    float4* rngRaster;  // rng.s1, rng.s2 (bits), rasterX, rasterY     (rasterX < -1e29: slot not owned by this shard)
+    float4* rad;        // radiance.xyz, -
 };
 
 struct QueueCtl
 {
-    // all indexed by bounce; zeroed once per batch
-    uint32_t* activeCount;  // [maxDepth+1]   entries at the FRONT of queue[bounce]
-    uint32_t* activeBack;   // [maxDepth+1]   entries at the BACK (fused pipeline: rays that meet no bounded primitive)
-    uint32_t* neeCount;     // [maxDepth]     front of the shadow queue of the bounce
-    uint32_t* neeBack;      // [maxDepth]     back of it
-    uint32_t* cursorExtend; // [maxDepth]
-    uint32_t* cursorShade;  // [maxDepth]
-    uint32_t* cursorShadow; // [maxDepth]
     unsigned long long* stats;  // [0]=rays traced [1]=samples [2]=internal visits [3]=tri tests [4]=prim tests [5]=shadow rays
 };
 
@@ -94,7 +82,6 @@ struct FrameParams
     int shardTilesX, shardOwnedTiles;   // tiles per frame row; tiles this shard owns (t % world == rank)
     uint32_t shardPerPass;              // path slots per pass of this shard (owned tiles x tile^2; W*H for one shard)
     uint32_t genCount;                  // camera paths the generation kernels enumerate per batch (gen_slot)
-    uint32_t queueCapacity;             // entries per ray queue (= path slots of the batch)
     int rrStart;                        // > 0: Russian roulette from this bounce on (opt-in, not the reference's behaviour)
     int filterType;
     float filterWidth, filterFalloff, filterOffset;
@@ -104,127 +91,16 @@ struct FrameParams
 // ---------------------------------------------------------------------------
 // wave-level helpers
 //
-// Single-address atomics retire at ~88 M/s on this chip (MI355X_MICROARCH.md, "dequeue" row): one
-// atomic per 64 rays caps a kernel at ~5.6 Grays/s per counter, one per 128 still costs ~0.4 ms per
-// 4 Mi rays (profiles/r01_a, r01_b).  So the queue is cut STATICALLY into contiguous per-block
-// ranges (blocks are handed to CUs dynamically by the dispatcher, which is all the load balancing
-// a 2048-block grid needs) and a block appends its survivors with ONE atomic per queue per
-// kMaxItems x 256 entries, after a wave64-ballot + LDS scan.
+// Single-address atomics retire at ~88 M/s on this chip (MI355X_MICROARCH.md, "dequeue" row): one atomic per 64 rays
+// caps a kernel at ~5.6 Grays/s per counter (round 1's first queues were atomic-bound, profiles/r01_a, r01_b).  The
+// wavefront pipelines now append without any: positions come from a wave64 ballot inside a region the wave owns
+// (RegionAppend, below); what is left is one atomic per wave per counter for the statistics.
 
-constexpr int kMaxItems = 8;
 constexpr int kStatShards = 2048;       // stats[kStatShards][8]
 constexpr int kStatWords = 8;
-constexpr int kScanWords = 16;           // LDS words behind the traversal stacks used by block_append
+constexpr int kScanWords = 16;           // LDS words kept between the traversal stacks and the staged arena
 
 TN_D int lane_id() { return (int)__lane_id(); }
-
-// rounds of kBlock entries this block must make over a queue of `count` entries
-TN_D uint32_t block_rounds(uint32_t count)
-{
-    return (count + gridDim.x*kBlock - 1u)/(gridDim.x*kBlock);
-}
-
-// Appends this block's survivors of up to kMaxItems rounds.  bits: thread-private mask, bit i =
-// the entry this thread handled in round i survives; slot(i) returns the value to append for it.
-// One atomic per block.  MUST be reached by every thread of the block (it synchronises).
-// `last` != 0: entries are placed from index `last` DOWNWARDS (queue[last - position]) -- used to fill one array from
-// both ends.
-template <class SlotFn>
-TN_D void block_append(uint32_t bits, uint32_t* counter, uint32_t* __restrict__ queue, uint32_t* s_scan, SlotFn slot, uint32_t last = 0u)
-{
-    const int lane = lane_id();
-    const int wave = (int)threadIdx.x/kWave;
-    unsigned long long masks[kMaxItems];
-    uint32_t waveTotal = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxItems; ++i)
-    {
-        masks[i] = __ballot((bits >> i) & 1u);
-        waveTotal += (uint32_t)__popcll(masks[i]);
-    }
-    if (lane == 0)
-        s_scan[wave] = waveTotal;
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        const uint32_t total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-        s_scan[4] = total ? atomicAdd(counter, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = s_scan[4];
-    for (int w = 0; w < wave; ++w)
-        base += s_scan[w];
-#pragma unroll
-    for (int i = 0; i < kMaxItems; ++i)
-    {
-        if ((bits >> i) & 1u)
-        {
-            const uint32_t pos = base + (uint32_t)__popcll(masks[i] & ((1ull << lane) - 1ull));
-            queue[last ? last - pos : pos] = slot(i);
-        }
-        base += (uint32_t)__popcll(masks[i]);
-    }
-    __syncthreads();        // s_scan is reused by the next call
-}
-
-// A queue filled from both ends: entries [0, front) and [capacity - back, capacity).  Item `idx` of the front + back
-// items, front ones first.
-TN_D uint32_t two_ended(uint32_t idx, uint32_t front, uint32_t back, uint32_t capacity)
-{
-    return idx < front ? idx : capacity - back + (idx - front);
-}
-
-// Both ends of a two-ended queue in one go (same synchronisation cost as one block_append): `front` bits are placed
-// upwards from counterFront's cursor, `back` bits downwards from `last`.  s_scan needs 10 words.
-template <class SlotFn>
-TN_D void block_append2(uint32_t front, uint32_t back, uint32_t* counterFront, uint32_t* counterBack, uint32_t* __restrict__ queue,
-                        uint32_t* s_scan, SlotFn slot, uint32_t last)
-{
-    const int lane = lane_id();
-    const int wave = (int)threadIdx.x/kWave;
-    unsigned long long mf[kMaxItems], mb[kMaxItems];
-    uint32_t totalF = 0, totalB = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxItems; ++i)
-    {
-        mf[i] = __ballot((front >> i) & 1u);
-        mb[i] = __ballot((back >> i) & 1u);
-        totalF += (uint32_t)__popcll(mf[i]);
-        totalB += (uint32_t)__popcll(mb[i]);
-    }
-    if (lane == 0)
-    {
-        s_scan[wave] = totalF;
-        s_scan[5 + wave] = totalB;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        const uint32_t tf = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-        const uint32_t tb = s_scan[5] + s_scan[6] + s_scan[7] + s_scan[8];
-        s_scan[4] = tf ? atomicAdd(counterFront, tf) : 0u;
-        s_scan[9] = tb ? atomicAdd(counterBack, tb) : 0u;
-    }
-    __syncthreads();
-    uint32_t baseF = s_scan[4], baseB = s_scan[9];
-    for (int w = 0; w < wave; ++w)
-    {
-        baseF += s_scan[w];
-        baseB += s_scan[5 + w];
-    }
-    const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int i = 0; i < kMaxItems; ++i)
-    {
-        if ((front >> i) & 1u)
-            queue[baseF + (uint32_t)__popcll(mf[i] & below)] = slot(i);
-        if ((back >> i) & 1u)
-            queue[last - (baseB + (uint32_t)__popcll(mb[i] & below))] = slot(i);
-        baseF += (uint32_t)__popcll(mf[i]);
-        baseB += (uint32_t)__popcll(mb[i]);
-    }
-    __syncthreads();        // s_scan is reused by the next call
-}
 
 // statistics: wave reduction, then one atomic per wave into this block's shard (distinct addresses)
 TN_D void wave_add_stat(unsigned long long* stats, int word, uint32_t v)
@@ -375,34 +251,6 @@ TN_D void camera_sample(const CameraParams& cam, const FrameParams& fp, int i, i
     generate_ray(cam, rx, ry, o, d);
 }
 
-// ---------------------------------------------------------------------------
-// path-state load/store
-
-TN_D void load_path(const PathState& ps, uint32_t slot, PathRegs& p, float& rasterX, float& rasterY, bool hasMedia)
-{
-    const float4 ro = ps.rayO[slot], rd = ps.rayD[slot], th = ps.thr[slot], ra = ps.rad[slot];
-    const float4 ab = hasMedia ? ps.absorb[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float4 rr = ps.rngRaster[slot];
-    p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
-    p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
-    p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
-    p.rad = V3(ra.x, ra.y, ra.z); p.rayType = __float_as_int(ra.w);
-    p.absorption = V3(ab.x, ab.y, ab.z);
-    p.rng.s1 = __float_as_uint(rr.x); p.rng.s2 = __float_as_uint(rr.y);
-    rasterX = rr.z; rasterY = rr.w;
-}
-
-TN_D void store_path(const PathState& ps, uint32_t slot, const PathRegs& p, float rasterX, float rasterY, bool hasMedia)
-{
-    ps.rayO[slot] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
-    ps.rayD[slot] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
-    ps.thr[slot] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
-    ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
-    if (hasMedia)
-        ps.absorb[slot] = make_float4(p.absorption.x, p.absorption.y, p.absorption.z, 0.0f);
-    ps.rngRaster[slot] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), rasterX, rasterY);
-}
-
 // Slot -> (pass, pixel); generates the camera sample.  Returns false for tile padding.
 TN_D bool begin_path(const CameraParams& cam, const FrameParams& fp, const uint32_t* __restrict__ passSeeds, uint32_t slot,
                      PathRegs& p, float& rx, float& ry)
@@ -419,250 +267,15 @@ TN_D bool begin_path(const CameraParams& cam, const FrameParams& fp, const uint3
 }
 
 // ---------------------------------------------------------------------------
-// k_bounce: the streaming pipeline's per-bounce kernel (the product path).
-//
-// One launch per bounce.  Each lane takes ONE live path from queue[bounce] (bounce 0: straight
-// from the camera), runs one iteration of the oracle's loop (render.cpp:250-385: closest hit,
-// emission/MIS, every NEE shadow ray, BSDF sample) and either retires the path or writes its
-// 96-B state back and appends it to queue[bounce+1].  Lanes are therefore always full at the
-// start of a bounce, and a path costs one state read + one state write per bounce.
-
-// Developer-only section timer (-DTN_PROFILE_SECTIONS, never in the shipped library): per-wave s_memtime
-// deltas of the k_bounce sections, summed into the stats words 2..7 instead of the traversal counters.
-#ifdef TN_PROFILE_SECTIONS
-#define TN_PROF_DECL uint32_t prof[6] = { 0, 0, 0, 0, 0, 0 }; long long tprev = clock64();
-#define TN_TICK(k) { const long long _t = clock64(); prof[k] += (uint32_t)(_t - tprev); tprev = _t; }
-#define TN_PROF_FLUSH if (lane_id() == 0) { for (int k = 0; k < 6; ++k) atomicAdd(q.stats + (size_t)(blockIdx.x % kStatShards)*kStatWords + 2 + k, (unsigned long long)prof[k]); } if (true) return;
-#else
-#define TN_TICK(k)
-#ifdef TN_PROFILE_TRACE
-#define TN_PROF_DECL TraceCounters ctrN = { 0, 0, 0 };
-#define TN_CTR_NEE ctrN
-#define TN_PROF_FLUSH if (lane_id() == 0) { for (int k = 0; k < 6; ++k) atomicAdd(q.stats + (size_t)(blockIdx.x % kStatShards)*kStatWords + 2 + k, (unsigned long long)(TN_PROFILE_TRACE == 2 ? ctrN.cyc[k] : ctr.cyc[k])); } if (true) return;
-#else
-#define TN_PROF_DECL
-#define TN_PROF_FLUSH
-#endif
-#endif
-#ifndef TN_CTR_NEE
-#define TN_CTR_NEE ctr
-#endif
-
-template <bool COUNT, bool FIRST, bool LDS, bool DEFER>
-__global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scIn, PathState ps, QueueCtl q, const uint32_t* __restrict__ queueIn,
-                                                   uint32_t* __restrict__ queueOut, int bounce, int stackEntries, CameraParams cam,
-                                                   FrameParams fp, const uint32_t* __restrict__ passSeeds)
-{
-    extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
-    LdsStack<kBlock> st = { s_stack + threadIdx.x };
-
-    uint32_t* s_scan = s_stack + stackEntries*kBlock;
-    SceneT<LDS, false, DEFER ? 1 : 0> sc;
-    stage_scene_lds(sc, scIn, s_scan + kScanWords);
-
-    const uint32_t frontCount = FIRST ? 0u : q.activeCount[bounce], backCount = FIRST ? 0u : q.activeBack[bounce];
-    const uint32_t count = FIRST ? fp.genCount : frontCount + backCount;
-    const uint32_t rounds = block_rounds(count);
-    const uint32_t first = blockIdx.x*rounds*kBlock;       // this block's contiguous range
-    uint32_t rays = 0, shadowRays = 0, samples = 0;
-    TraceCounters ctr = { 0, 0, 0 };
-    TN_PROF_DECL
-
-    for (uint32_t r0 = 0; r0 < rounds; r0 += kMaxItems)
-    {
-        const uint32_t base = first + r0*kBlock;
-        const uint32_t groups = (rounds - r0) < (uint32_t)kMaxItems ? (rounds - r0) : (uint32_t)kMaxItems;
-
-        uint32_t keep = 0, keepBack = 0;
-        for (uint32_t g = 0; g < groups; ++g)
-        {
-            const uint32_t idx = base + g*kBlock + threadIdx.x;
-            if (idx >= count)
-                continue;
-            uint32_t slot;
-            if (FIRST)
-            {
-                if (!gen_slot(fp, idx, slot))
-                    continue;
-            }
-            else
-                slot = queueIn[two_ended(idx, frontCount, backCount, fp.queueCapacity)];
-
-            TN_TICK(4)
-            PathRegs p;
-            float rx, ry;
-            if (FIRST)
-            {
-                if (!begin_path(cam, fp, passSeeds, slot, p, rx, ry))
-                {
-                    ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    ps.rngRaster[slot] = make_float4(0.0f, 0.0f, -1e30f, -1e30f);
-                    continue;
-                }
-                samples++;
-            }
-            else
-            {
-                load_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
-            }
-
-            TN_TICK(0)
-            float t;
-            V3 n;
-            const int prim = trace<SceneT<LDS, false, DEFER ? 1 : 0>, LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n, ctr);
-            rays++;
-            TN_TICK(1)
-
-            bool alive = false;
-            if (prim < 0)
-            {
-                on_miss(sc, p, bounce);
-            }
-            else
-            {
-                const Mat mat = load_mat(sc.mats, prim);
-                HitCtx h;
-                on_hit_begin(p, mat, t, n, bounce, h);
-
-                if (sc.totalLightSamples > 0)
-                {
-                    const V3 thrAtNee = p.thr;
-                    LightCursor lights;
-                    V3 sum = nee_sum(sc, [&](int k) -> V3 {
-                        NeeGeo g;
-                        V3 skyColor;
-                        float skyPdf = 0.0f;
-                        int light = -1;
-                        if (sc.probe.valid && k == 0)
-                            nee_sample_probe(sc, h.p, h.n, p.rng, g, skyColor, skyPdf);
-                        else
-                        {
-                            light = lights.next(sc);
-                            nee_sample_light(sc, h.p, h.n, p.time, light, p.rng, g);
-                        }
-                        TN_TICK(2)
-                        float ts;
-                        V3 nn;
-                        const int hp = trace<SceneT<LDS, false, DEFER ? 1 : 0>, LdsStack<kBlock>, COUNT>(sc, st, g.o, g.wi, p.time, ts, nn, TN_CTR_NEE);
-                        TN_TICK(3)
-                        rays++;
-                        shadowRays++;
-                        // the BSDF terms only for the samples that arrive; the 28-register material record is re-read here
-                        // instead of living across the shadow trace
-                        if (light < 0)
-                            return (hp < 0) ? nee_contrib_probe(load_mat(sc.mats, prim), h, g.wi, skyColor, skyPdf) : V3(0.0f);
-                        if (!nee_light_reached(g, hp, ts))
-                            return V3(0.0f);
-                        return nee_contrib_light(sc, load_mat(sc.mats, prim), h, g.wi, g.nl, light, hp, ts);
-                    });
-                    p.rad = p.rad + thrAtNee*sum;
-                }
-
-                // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
-                TN_TICK(2)
-                if (bounce + 1 < fp.maxDepth)
-                {
-                    // the material is read again rather than kept in 28 registers across the shadow traces
-                    const Mat matAgain = load_mat(sc.mats, prim);
-                    alive = (bsdf_step(p, matAgain, h) == kContinue);
-                    if (alive && fp.rrStart > 0 && bounce + 1 >= fp.rrStart)
-                        alive = roulette_survives(p);
-                }
-            }
-
-            TN_TICK(5)
-            if (alive)
-            {
-                store_path(ps, slot, p, rx, ry, sc.hasMedia != 0);
-                // next bounce's queue, sorted: rays that meet a bounded primitive's box in front, plane-only rays at the back
-                if (!sc.sortQueues || ray_meets_bounded_prim(sc, p.o, p.d))
-                    keep |= 1u << g;
-                else
-                    keepBack |= 1u << g;
-            }
-            else
-            {
-                ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
-                if (FIRST)
-                    ps.rngRaster[slot] = make_float4(0.0f, 0.0f, rx, ry);
-            }
-        }
-
-        auto slotOf = [&](int i) -> uint32_t {
-            const uint32_t idx = base + (uint32_t)i*kBlock + threadIdx.x;
-            uint32_t slot = 0;
-            if (FIRST)
-                (void)gen_slot(fp, idx, slot);
-            else
-                slot = queueIn[two_ended(idx, frontCount, backCount, fp.queueCapacity)];
-            return slot;
-        };
-        if (sc.sortQueues)
-            block_append2(keep, keepBack, q.activeCount + bounce + 1, q.activeBack + bounce + 1, queueOut, s_scan, slotOf, fp.queueCapacity - 1u);
-        else
-            block_append(keep, q.activeCount + bounce + 1, queueOut, s_scan, slotOf);
-    }
-
-    wave_add_stat(q.stats, 0, rays);
-    wave_add_stat(q.stats, 1, samples);
-#if !defined(TN_PROFILE_SECTIONS) && !defined(TN_PROFILE_TRACE)
-    wave_add_stat(q.stats, 5, shadowRays);
-#endif
-    TN_PROF_FLUSH
-    if (COUNT)
-    {
-        wave_add_stat(q.stats, 2, ctr.internal);
-        wave_add_stat(q.stats, 3, ctr.tris);
-        wave_add_stat(q.stats, 4, ctr.prims);
-    }
-}
-
-// ===========================================================================
-// The SPLIT variant of the pipeline (TINSEL_PIPELINE_WAVEFRONT_SPLIT): the same bounce cut into k_extend / k_lights /
-// k_shadow / k_shade with hit and shadow-ray records parked in HBM in between: lean trace kernels (and k_walk ahead of
-// them) for scenes with meshes in HBM or many shadow rays per bounce.
-
-// ---------------------------------------------------------------------------
-// Queues sorted by "enters a big mesh" (split pipeline, scenes with a mesh in HBM).  k_shade, which produces the next
-// bounce's extension queue and this bounce's shadow queue, fills each from both ends: in front the rays whose leaf-box
-// test against one of the LARGE meshes succeeds, at the back all others.  trace() is unchanged and results do not
-// depend on queue order; what changes is that a wave of k_extend / k_shadow is either full of rays that walk the big
-// mesh's BVH or has none (measured on the 524k-triangle config: 60 % of the rays enter the mesh, and unsorted,
-// practically every wave paid for the walk with 23 % of its lanes active).
-struct BinPrims
-{
-    int count;
-    int prim[7];
-};
-
-TN_D bool ray_enters_big_mesh(const PrimBox* __restrict__ primBoxes, const BinPrims& bp, V3 o, V3 d)
-{
-    const V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
-    bool hit = !ray_sane(o);        // rays the flat scan refuses reach the mesh without a box test (trace, tn_isect.h)
-    // fully unrolled with constant indices: bp lives in kernel-argument SGPRs, a dynamic index would spill it to scratch
-#pragma unroll
-    for (int k = 0; k < 7; ++k)
-    {
-        if (k < bp.count && !hit)
-        {
-            const float4* b = reinterpret_cast<const float4*>(primBoxes + bp.prim[k]);
-            const float4 b0 = b[0], b1 = b[1];
-            float tb;
-            hit = ray_aabb(o, rcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tb);
-        }
-    }
-    return hit;
-}
-
-// ---------------------------------------------------------------------------
-// Path state of the split pipeline: DENSE.  What bounds its kernels is HBM traffic, and the L2 fetches 128-B lines: a 16-B
-// record read through a queue of sparse (or sorted) slots costs a whole line -- measured on glass, maxDepth 12, the
-// light-sampling kernel went from 25 ps per path at bounce 0 (4.8 TB/s) to 157 ps at bounce 11, 6.6 % of the slots alive.
-// So nothing here is indexed by a path's slot: the batch is cut into one REGION of `regionLen` positions per wave of the
+// Path state of the wavefront pipelines: DENSE.  What bounds the split pipeline's kernels is HBM traffic, and the L2 fetches
+// 128-B lines: a 16-B record read through a queue of sparse (or sorted) slots costs a whole line -- measured on glass,
+// maxDepth 12, the light-sampling kernel went from 25 ps per path at bounce 0 (4.8 TB/s) to 157 ps at bounce 11, 6.6 % of the
+// slots alive.  So nothing is indexed by a path's slot: the batch is cut into one REGION of `regionLen` positions per wave of the
 // grid, and the live paths of a region are PACKED at its two ends -- in front the paths whose ray enters the box of a
-// mesh in HBM (k_walk's work, and waves of the scan kernels that are all-mesh or no-mesh), at the back all others.
-// k_shade reads a path's state at its position in buffer `bounce & 1` and writes the survivor to its new position in the
-// other buffer; positions come from a wave64 ballot, so there is no queue, no atomic and no barrier, and every load and
+// mesh in HBM (k_walk's work, and waves of the scan kernels that are all-mesh or no-mesh; fused kernel, open scenes: the
+// rays that meet a bounded primitive's box), at the back all others.  The kernel that ends a bounce (k_shade, k_bounce)
+// reads a path's state at its position in buffer `bounce & 1` and writes the survivor to its new position in the other
+// buffer; positions come from a wave64 ballot, so there is no queue, no atomic and no barrier, and every load and
 // store of every kernel is a run of consecutive 16-B records.  A path carries its slot (the pixel/pass it belongs to)
 // to write its radiance where the accumulate kernels look for it.  A path never leaves its region, so that write stays
 // local too.
@@ -741,6 +354,234 @@ TN_D void store_state(const SplitState& ss, int buf, uint32_t pos, const PathReg
     if (hasMedia)
         ss.absorb[buf][pos] = make_float4(p.absorption.x, p.absorption.y, p.absorption.z, 0.0f);
     ss.rngId[buf][pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), 0.0f);
+}
+
+// ---------------------------------------------------------------------------
+// k_bounce: the streaming pipeline's per-bounce kernel (the product path).
+//
+// One launch per bounce.  Each lane takes ONE live path from queue[bounce] (bounce 0: straight
+// from the camera), runs one iteration of the oracle's loop (render.cpp:250-385: closest hit,
+// emission/MIS, every NEE shadow ray, BSDF sample) and either retires the path or writes its
+// 96-B state back and appends it to queue[bounce+1].  Lanes are therefore always full at the
+// start of a bounce, and a path costs one state read + one state write per bounce.
+
+// Developer-only section timer (-DTN_PROFILE_SECTIONS, never in the shipped library): per-wave s_memtime
+// deltas of the k_bounce sections, summed into the stats words 2..7 instead of the traversal counters.
+#ifdef TN_PROFILE_SECTIONS
+#define TN_PROF_DECL uint32_t prof[6] = { 0, 0, 0, 0, 0, 0 }; long long tprev = clock64();
+#define TN_TICK(k) { const long long _t = clock64(); prof[k] += (uint32_t)(_t - tprev); tprev = _t; }
+#define TN_PROF_FLUSH if (lane_id() == 0) { for (int k = 0; k < 6; ++k) atomicAdd(q.stats + (size_t)(blockIdx.x % kStatShards)*kStatWords + 2 + k, (unsigned long long)prof[k]); } if (true) return;
+#else
+#define TN_TICK(k)
+#ifdef TN_PROFILE_TRACE
+#define TN_PROF_DECL TraceCounters ctrN = { 0, 0, 0 };
+#define TN_CTR_NEE ctrN
+#define TN_PROF_FLUSH if (lane_id() == 0) { for (int k = 0; k < 6; ++k) atomicAdd(q.stats + (size_t)(blockIdx.x % kStatShards)*kStatWords + 2 + k, (unsigned long long)(TN_PROFILE_TRACE == 2 ? ctrN.cyc[k] : ctr.cyc[k])); } if (true) return;
+#else
+#define TN_PROF_DECL
+#define TN_PROF_FLUSH
+#endif
+#endif
+#ifndef TN_CTR_NEE
+#define TN_CTR_NEE ctr
+#endif
+
+template <bool COUNT, bool FIRST, bool LDS, bool DEFER>
+__global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries, CameraParams cam,
+                                                   FrameParams fp, const uint32_t* __restrict__ passSeeds)
+{
+    extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
+    LdsStack<kBlock> st = { s_stack + threadIdx.x };
+
+    SceneT<LDS, false, DEFER ? 1 : 0> sc;
+    stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
+
+    const uint32_t lane = __lane_id();
+    const int cur = bounce & 1, nxt = cur ^ 1;
+    const bool hasMedia = sc.hasMedia != 0;
+    uint32_t rays = 0, shadowRays = 0, samples = 0;
+    TraceCounters ctr = { 0, 0, 0 };
+    TN_PROF_DECL
+
+    // a wave takes a region: bounce 0 generates its camera paths, the others read what the previous bounce packed there
+    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
+    {
+        const uint32_t base = r*ss.regionLen;
+        uint32_t nFront = 0, n;
+        if (FIRST)
+        {
+            const uint32_t end = (base + ss.regionLen) < fp.genCount ? (base + ss.regionLen) : fp.genCount;
+            n = base < end ? end - base : 0u;
+        }
+        else
+        {
+            nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
+            n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
+        }
+        RegionAppend out = { base, ss.regionLen, 0u, 0u };
+
+        for (uint32_t j0 = 0; j0 < n; j0 += kWave)
+        {
+            const uint32_t j = j0 + lane;
+            bool have = false, alive = false, front = true;
+            PathRegs p;
+            uint32_t slot = 0;
+
+            TN_TICK(4)
+            if (j < n)
+            {
+                if (FIRST)
+                {
+                    if (gen_slot(fp, base + j, slot))
+                    {
+                        float rx, ry;
+                        have = begin_path(cam, fp, passSeeds, slot, p, rx, ry);
+                        if (!have)
+                            ss.radOut[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        else
+                            samples++;
+                    }
+                }
+                else
+                {
+                    load_state(ss, cur, region_pos(base, ss.regionLen, nFront, j), p, slot, hasMedia);
+                    have = true;
+                }
+            }
+
+            if (have)
+            {
+                TN_TICK(0)
+                float t;
+                V3 n3;
+                const int prim = trace<SceneT<LDS, false, DEFER ? 1 : 0>, LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n3, ctr);
+                rays++;
+                TN_TICK(1)
+
+                if (prim < 0)
+                {
+                    on_miss(sc, p, bounce);
+                }
+                else
+                {
+                    const V3 n = n3;
+                    const Mat mat = load_mat(sc.mats, prim);
+                    HitCtx h;
+                    on_hit_begin(p, mat, t, n, bounce, h);
+
+                    if (sc.totalLightSamples > 0)
+                    {
+                        const V3 thrAtNee = p.thr;
+                        LightCursor lights;
+                        V3 sum = nee_sum(sc, [&](int k) -> V3 {
+                            NeeGeo g;
+                            V3 skyColor;
+                            float skyPdf = 0.0f;
+                            int light = -1;
+                            if (sc.probe.valid && k == 0)
+                                nee_sample_probe(sc, h.p, h.n, p.rng, g, skyColor, skyPdf);
+                            else
+                            {
+                                light = lights.next(sc);
+                                nee_sample_light(sc, h.p, h.n, p.time, light, p.rng, g);
+                            }
+                            TN_TICK(2)
+                            float ts;
+                            V3 nn;
+                            const int hp = trace<SceneT<LDS, false, DEFER ? 1 : 0>, LdsStack<kBlock>, COUNT>(sc, st, g.o, g.wi, p.time, ts, nn, TN_CTR_NEE);
+                            TN_TICK(3)
+                            rays++;
+                            shadowRays++;
+                            // the BSDF terms only for the samples that arrive; the 28-register material record is re-read here
+                            // instead of living across the shadow trace
+                            if (light < 0)
+                                return (hp < 0) ? nee_contrib_probe(load_mat(sc.mats, prim), h, g.wi, skyColor, skyPdf) : V3(0.0f);
+                            if (!nee_light_reached(g, hp, ts))
+                                return V3(0.0f);
+                            return nee_contrib_light(sc, load_mat(sc.mats, prim), h, g.wi, g.nl, light, hp, ts);
+                        });
+                        p.rad = p.rad + thrAtNee*sum;
+                    }
+
+                    // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
+                    TN_TICK(2)
+                    if (bounce + 1 < fp.maxDepth)
+                    {
+                        // the material is read again rather than kept in 28 registers across the shadow traces
+                        const Mat matAgain = load_mat(sc.mats, prim);
+                        alive = (bsdf_step(p, matAgain, h) == kContinue);
+                        if (alive && fp.rrStart > 0 && bounce + 1 >= fp.rrStart)
+                            alive = roulette_survives(p);
+                    }
+                }
+
+                TN_TICK(5)
+                if (alive)
+                    // the next bounce, sorted: rays that meet a bounded primitive's box in front, plane-only rays at the back
+                    front = !sc.sortQueues || ray_meets_bounded_prim(sc, p.o, p.d);
+                else
+                    ss.radOut[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
+            }
+            const uint32_t np = out.push(alive, front);
+            if (alive)
+                store_state(ss, nxt, np, p, slot, hasMedia);
+        }
+        if (lane == 0)
+        {
+            ss.segFront[(size_t)(bounce + 1)*ss.numRegions + r] = out.nFront;
+            ss.segBack[(size_t)(bounce + 1)*ss.numRegions + r] = out.nBack;
+        }
+    }
+
+    wave_add_stat(q.stats, 0, rays);
+    wave_add_stat(q.stats, 1, samples);
+#if !defined(TN_PROFILE_SECTIONS) && !defined(TN_PROFILE_TRACE)
+    wave_add_stat(q.stats, 5, shadowRays);
+#endif
+    TN_PROF_FLUSH
+    if (COUNT)
+    {
+        wave_add_stat(q.stats, 2, ctr.internal);
+        wave_add_stat(q.stats, 3, ctr.tris);
+        wave_add_stat(q.stats, 4, ctr.prims);
+    }
+}
+
+// ===========================================================================
+// The SPLIT variant of the pipeline (TINSEL_PIPELINE_WAVEFRONT_SPLIT): the same bounce cut into k_extend / k_lights /
+// k_shadow / k_shade with hit and shadow-ray records parked in HBM in between: lean trace kernels (and k_walk ahead of
+// them) for scenes with meshes in HBM or many shadow rays per bounce.
+
+// ---------------------------------------------------------------------------
+// Queues sorted by "enters a big mesh" (split pipeline, scenes with a mesh in HBM).  k_shade, which produces the next
+// bounce's extension queue and this bounce's shadow queue, fills each from both ends: in front the rays whose leaf-box
+// test against one of the LARGE meshes succeeds, at the back all others.  trace() is unchanged and results do not
+// depend on queue order; what changes is that a wave of k_extend / k_shadow is either full of rays that walk the big
+// mesh's BVH or has none (measured on the 524k-triangle config: 60 % of the rays enter the mesh, and unsorted,
+// practically every wave paid for the walk with 23 % of its lanes active).
+struct BinPrims
+{
+    int count;
+    int prim[7];
+};
+
+TN_D bool ray_enters_big_mesh(const PrimBox* __restrict__ primBoxes, const BinPrims& bp, V3 o, V3 d)
+{
+    const V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    bool hit = !ray_sane(o);        // rays the flat scan refuses reach the mesh without a box test (trace, tn_isect.h)
+    // fully unrolled with constant indices: bp lives in kernel-argument SGPRs, a dynamic index would spill it to scratch
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+    {
+        if (k < bp.count && !hit)
+        {
+            const float4* b = reinterpret_cast<const float4*>(primBoxes + bp.prim[k]);
+            const float4 b0 = b[0], b1 = b[1];
+            float tb;
+            hit = ray_aabb(o, rcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tb);
+        }
+    }
+    return hit;
 }
 
 // ---------------------------------------------------------------------------
@@ -1329,7 +1170,6 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene scIn, 
             }
 
             ps.rad[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
-            ps.rngRaster[slot] = make_float4(0.0f, 0.0f, rx, ry);
         }
     }
 

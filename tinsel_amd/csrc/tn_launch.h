@@ -24,13 +24,11 @@ struct LaunchArgs
 {
     DevScene scene;
     PathState ps;
-    SplitState ss;                  // the split pipeline's dense state (PK_GENERATE .. PK_SHADE)
+    SplitState ss;                  // the wavefront pipelines' dense state (PK_BOUNCE; PK_GENERATE .. PK_SHADE)
     QueueCtl ctl;
     CameraParams cam;
     FrameParams fp;
     const uint32_t* passSeeds;
-    const uint32_t* queueIn;        // PK_BOUNCE: input queue
-    uint32_t* queueOut;             // PK_BOUNCE: next bounce's queue
     const float4* walkRec;          // k_walk's records (null: meshes are walked inline)
     uint32_t walkPrims;
     BinPrims bins;                  // primitives whose leaf-box test sorts the queues
@@ -89,10 +87,10 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
     case PK_BOUNCE:
 #define TN_LAUNCH_BOUNCE(FIRST, DEFER)                                                                                 \
         do {                                                                                                           \
-            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, FIRST, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
-                         else hipLaunchKernelGGL((k_bounce<true, FIRST, false, false>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
-            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, FIRST, true, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
-                         else hipLaunchKernelGGL((k_bounce<false, FIRST, false, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.queueIn, a.queueOut, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
+            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, FIRST, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
+                         else hipLaunchKernelGGL((k_bounce<true, FIRST, false, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
+            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, FIRST, true, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
+                         else hipLaunchKernelGGL((k_bounce<false, FIRST, false, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
         } while (0)
         // (the detail-counting variants walk the scene BVH: nothing to defer)
         if (a.scene.deferMeshes)
