@@ -18,7 +18,7 @@ def _render(scene, cam, opt, passes, pipeline, batch=None):
         r.set_batch_paths(batch)
     r.init(opt.width, opt.height)
     out = r.render(cam, opt, passes=passes)
-    counts = r.queue_counts()
+    counts = r.queue_counts() if pipeline != abi.PIPELINE_MEGAKERNEL else None      # the megakernel arm has no bounces to count
     st = r.stats()
     r.close()
     return out, counts, st

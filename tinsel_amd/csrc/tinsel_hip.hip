@@ -349,6 +349,7 @@ struct tinsel_hip
     int batchPipeline = -1;             // the pipeline the current batch buffers were allocated for
     size_t splitCap = 0;                // positions per SplitState array: the batch slots + one wave of padding per region
     uint32_t splitMaxRegions = 0;
+    uint32_t* regionOrder = nullptr;    // region groups, longest first (k_region_order)
     uint32_t* walkList = nullptr;       // k_walk's work list (k_seg_expand) and the prefix of the regions' front counts behind it
     uint32_t* segPrefix = nullptr;
     BinPrims binPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };
@@ -456,7 +457,8 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
         if (batch_alloc(r, &ss.rayO[b], cap) || batch_alloc(r, &ss.rayD[b], cap) || batch_alloc(r, &ss.thr[b], cap) ||
             batch_alloc(r, &ss.rad[b], cap) || batch_alloc(r, &ss.absorb[b], r->scene.hasMedia ? cap : 1) || batch_alloc(r, &ss.rngId[b], cap))
             return -1;
-    if (batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)))
+    if (batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)) ||
+        batch_alloc(r, &r->regionOrder, maxRegions/(kBlock/kWave)))
         return -1;
     ss.radOut = r->ps.rad;
     ss.capacity = (uint32_t)cap;
@@ -899,10 +901,21 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         if (set_regions(r, a, slots, gridPersist))
             return -1;
         a.grid = gridPersist;
+        static const bool noOrder = getenv("TINSEL_HIP_NO_REGION_ORDER") != nullptr;
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
-            ScopedTimer t(r, KN_BOUNCE, st);
             a.bounce = bounce;
+            a.order = nullptr;
+            if (bounce > 0 && !noOrder && gridPersist > r->numCUs*2)
+            {
+                // longest regions first (k_region_order, tn_kernels.h); bounce 0's regions are all full
+                ScopedTimer t(r, KN_SEG, st);
+                const size_t W = a.ss.numRegions;
+                hipLaunchKernelGGL(k_region_order, dim3(1), dim3(kOrderBlock), 0, st, (const uint32_t*)(r->ss.segFront + (size_t)bounce*W),
+                                   (const uint32_t*)(r->ss.segBack + (size_t)bounce*W), a.ss.numRegions, r->regionOrder);
+                a.order = r->regionOrder;
+            }
+            ScopedTimer t(r, KN_BOUNCE, st);
             launch_path(r, PK_BOUNCE, a, st);
         }
     }

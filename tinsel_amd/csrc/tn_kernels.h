@@ -357,6 +357,46 @@ TN_D void store_state(const SplitState& ss, int buf, uint32_t pos, const PathReg
 }
 
 // ---------------------------------------------------------------------------
+// Longest regions first.  A workgroup takes four consecutive regions, the dispatcher hands workgroups to CUs in index order,
+// and paths die in patches of the image (sky): launched in image order, a bounce ends with a few waves still working through
+// full regions while the rest of the chip idles.  k_region_order sorts the workgroups' region groups by the power of two of
+// their live entries, largest first (one workgroup, LDS histogram; the order inside a class is whatever the atomics made
+// it: order never changes a result), and the kernels that read `order` take group order[blockIdx.x].
+constexpr int kOrderBlock = 1024;
+constexpr int kOrderClasses = 33;
+
+__global__ __launch_bounds__(kOrderBlock) void k_region_order(const uint32_t* __restrict__ front, const uint32_t* __restrict__ back, uint32_t numRegions,
+                                                              uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_count[kOrderClasses], s_start[kOrderClasses];
+    const uint32_t groups = numRegions/kRegionsPerBlock;
+    if (threadIdx.x < kOrderClasses)
+        s_count[threadIdx.x] = 0;
+    __syncthreads();
+    auto cls = [&](uint32_t g) -> uint32_t {
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < kRegionsPerBlock; ++k)
+            n += front[g*kRegionsPerBlock + k] + back[g*kRegionsPerBlock + k];
+        return n ? 32u - (uint32_t)__clz((int)n) : 0u;         // 0: empty, else 1 + floor(log2 n)
+    };
+    for (uint32_t g = threadIdx.x; g < groups; g += kOrderBlock)
+        atomicAdd(&s_count[cls(g)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t run = 0;
+        for (int c = kOrderClasses - 1; c >= 0; --c)
+        {
+            s_start[c] = run;
+            run += s_count[c];
+        }
+    }
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < groups; g += kOrderBlock)
+        order[atomicAdd(&s_start[cls(g)], 1u)] = g;
+}
+
+// ---------------------------------------------------------------------------
 // k_bounce: the streaming pipeline's per-bounce kernel (the product path).
 //
 // One launch per bounce.  Each lane takes ONE live path from queue[bounce] (bounce 0: straight
@@ -388,7 +428,7 @@ TN_D void store_state(const SplitState& ss, int buf, uint32_t pos, const PathReg
 
 template <bool COUNT, bool FIRST, bool LDS, bool DEFER>
 __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries, CameraParams cam,
-                                                   FrameParams fp, const uint32_t* __restrict__ passSeeds)
+                                                   FrameParams fp, const uint32_t* __restrict__ passSeeds, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
@@ -404,8 +444,10 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
     TN_PROF_DECL
 
     // a wave takes a region: bounce 0 generates its camera paths, the others read what the previous bounce packed there
-    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
+    // (one workgroup per group of four regions; `order`: the groups with the most live entries first, k_region_order)
+    for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t base = r*ss.regionLen;
         uint32_t nFront = 0, n;
         if (FIRST)

@@ -31,6 +31,7 @@ struct LaunchArgs
     const uint32_t* passSeeds;
     const float4* walkRec;          // k_walk's records (null: meshes are walked inline)
     uint32_t walkPrims;
+    const uint32_t* order;          // PK_BOUNCE: region groups, longest first (k_region_order; null: in index order)
     BinPrims bins;                  // primitives whose leaf-box test sorts the queues
     WalkJob walk;                   // PK_WALK
     int walkBig;                    // PK_WALK: 1024-thread workgroups with an LDS-resident tree top, else 256-thread ones
@@ -87,10 +88,10 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
     case PK_BOUNCE:
 #define TN_LAUNCH_BOUNCE(FIRST, DEFER)                                                                                 \
         do {                                                                                                           \
-            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, FIRST, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
-                         else hipLaunchKernelGGL((k_bounce<true, FIRST, false, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
-            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, FIRST, true, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); \
-                         else hipLaunchKernelGGL((k_bounce<false, FIRST, false, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds); } \
+            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, FIRST, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); \
+                         else hipLaunchKernelGGL((k_bounce<true, FIRST, false, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); } \
+            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, FIRST, true, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); \
+                         else hipLaunchKernelGGL((k_bounce<false, FIRST, false, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); } \
         } while (0)
         // (the detail-counting variants walk the scene BVH: nothing to defer)
         if (a.scene.deferMeshes)
