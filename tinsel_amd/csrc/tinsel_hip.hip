@@ -349,7 +349,8 @@ struct tinsel_hip
     int batchPipeline = -1;             // the pipeline the current batch buffers were allocated for
     size_t splitCap = 0;                // positions per SplitState array: the batch slots + one wave of padding per region
     uint32_t splitMaxRegions = 0;
-    uint32_t* regionOrder = nullptr;    // region groups, longest first (k_region_order)
+    uint32_t* regionOrder = nullptr;    // region groups, longest first (k_region_order): by live paths, by shadow-ray bundles
+    uint32_t* regionOrderNee = nullptr;
     uint32_t* walkList = nullptr;       // k_walk's work list (k_seg_expand) and the prefix of the regions' front counts behind it
     uint32_t* segPrefix = nullptr;
     BinPrims binPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };
@@ -458,7 +459,7 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
             batch_alloc(r, &ss.rad[b], cap) || batch_alloc(r, &ss.absorb[b], r->scene.hasMedia ? cap : 1) || batch_alloc(r, &ss.rngId[b], cap))
             return -1;
     if (batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)) ||
-        batch_alloc(r, &r->regionOrder, maxRegions/(kBlock/kWave)))
+        batch_alloc(r, &r->regionOrder, maxRegions/(kBlock/kWave)) || batch_alloc(r, &r->regionOrderNee, maxRegions/(kBlock/kWave)))
         return -1;
     ss.radOut = r->ps.rad;
     ss.capacity = (uint32_t)cap;
@@ -942,9 +943,26 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             a.grid = gridPersist;
             launch_path(r, PK_GENERATE, a, st);
         }
+        static const bool noOrder = getenv("TINSEL_HIP_NO_REGION_ORDER") != nullptr;
+        // (not where k_walk does the walking: what is left for the scan kernels is too short for the two extra launches per
+        // bounce to pay -- glass 1087 -> 1077, config 3 1891 -> 1881; many_spheres, scene BVH walked inline, 1168 -> 1290)
+        const bool ordered = !noOrder && !walk && gridPersist > r->numCUs*2;
+        auto order_regions = [&](const uint32_t* front, const uint32_t* back, uint32_t* out) {
+            ScopedTimer t(r, KN_SEG, st);
+            hipLaunchKernelGGL(k_region_order, dim3(1), dim3(kOrderBlock), 0, st, front, back, a.ss.numRegions, out);
+        };
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
             a.bounce = bounce;
+            // longest regions first (k_region_order, tn_kernels.h): the paths' order serves k_extend, k_lights and k_shade,
+            // the shadow-ray bundles' order k_shadow; bounce 0's regions are all full
+            a.order = nullptr;
+            if (ordered && bounce > 0)
+            {
+                order_regions(r->ss.segFront + (size_t)bounce*W, r->ss.segBack + (size_t)bounce*W, r->regionOrder);
+                a.order = r->regionOrder;
+            }
+            const uint32_t* const pathOrder = a.order;
             if (walk)
             {
                 a.grid = gridPersist;
@@ -971,11 +989,17 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                     a.grid = gridPersist;
                     launch_walk(r, st, a, r->ss.neeFront + (size_t)bounce*W, true);
                 }
+                if (ordered && bounce > 0)
+                {
+                    order_regions(r->ss.neeFront + (size_t)bounce*W, r->ss.neeBack + (size_t)bounce*W, r->regionOrderNee);
+                    a.order = r->regionOrderNee;
+                }
                 ScopedTimer t(r, KN_SHADOW, st);
                 a.grid = gridTrace;
                 a.ldsBytes = ldsTrace;
                 a.stackEntries = stackScan;
                 launch_path(r, PK_SHADOW, a, st);
+                a.order = pathOrder;
             }
             {
                 ScopedTimer t(r, KN_SHADE, st);

@@ -747,7 +747,7 @@ TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& b
 // walk it is the other way round (the fused kernel needs 170 VGPRs: glass 21.2 + 7.9 apart, 31.5 together at 3 waves).
 template <bool COUNT, bool LDS, bool WONLY = false>
 __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : TN_WAVES_TRACE) void k_extend(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
-                                                                  const float4* __restrict__ walkRec, uint32_t walkPrims, BinPrims bp)
+                                                                  const float4* __restrict__ walkRec, uint32_t walkPrims, BinPrims bp, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
@@ -761,8 +761,9 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : TN_WAVES_TRA
     TraceCounters ctr = { 0, 0, 0 };
     sc.walkRec = walkRec;           // k_walk's records of the front rays (null: meshes are walked inline)
 
-    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
+    for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : TN_WAVES_TRA
 
 // k_lights: the light samples of a bounce as a kernel of its own (scenes whose k_extend walks meshes inline)
 template <bool LDS>
-__global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scIn, SplitState ss, int bounce, BinPrims bp)
+__global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scIn, SplitState ss, int bounce, BinPrims bp, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_arena[];
     SceneT<LDS> sc;
@@ -818,8 +819,9 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
     const uint32_t lane = __lane_id();
     const int cur = bounce & 1;
 
-    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
+    for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
@@ -875,7 +877,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
 // lane per path traces its K shadow rays and leaves, per ray, the primitive whose emission arrives (or -1) and its t.
 template <bool COUNT, bool LDS, bool WONLY = false>
 __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_shadow(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
-                                                                  const float4* __restrict__ walkRec, uint32_t walkPrims)
+                                                                  const float4* __restrict__ walkRec, uint32_t walkPrims, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
@@ -888,8 +890,9 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
     sc.walkRec = walkRec;
     const int K = ss.neePerPath;
 
-    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
+    for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t nFront = wave_uniform(ss.neeFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.neeBack[(size_t)bounce*ss.numRegions + r]);
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
@@ -964,7 +967,7 @@ struct ShadeFetch
 };
 
 template <bool LDS>
-__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp)
+__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_arena[];
     SceneT<LDS> sc;
@@ -974,8 +977,9 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
     const int K = ss.neePerPath;
     const bool hasMedia = sc.hasMedia != 0;
 
-    for (uint32_t r = blockIdx.x*kRegionsPerBlock + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*kRegionsPerBlock)
+    for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };

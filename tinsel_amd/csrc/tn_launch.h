@@ -31,7 +31,7 @@ struct LaunchArgs
     const uint32_t* passSeeds;
     const float4* walkRec;          // k_walk's records (null: meshes are walked inline)
     uint32_t walkPrims;
-    const uint32_t* order;          // PK_BOUNCE: region groups, longest first (k_region_order; null: in index order)
+    const uint32_t* order;          // region groups, longest first (k_region_order; null: in index order)
     BinPrims bins;                  // primitives whose leaf-box test sorts the queues
     WalkJob walk;                   // PK_WALK
     int walkBig;                    // PK_WALK: 1024-thread workgroups with an LDS-resident tree top, else 256-thread ones
@@ -59,15 +59,15 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             else       { if (lds) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); } \
         } while (0)
         if (a.walkedOnly && !count && !lds)
-            hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins);
+            hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         else
-            TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins);
+            TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         break;
     case PK_SHADOW:
         if (a.walkedOnly && !count && !lds)
-            hipLaunchKernelGGL((k_shadow<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims);
+            hipLaunchKernelGGL((k_shadow<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
         else
-            TN_LAUNCH2(k_shadow, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims);
+            TN_LAUNCH2(k_shadow, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
         break;
     case PK_MEGA:
         TN_LAUNCH2(k_mega, grid, block, a.ldsBytes, st, a.scene, a.ps, a.ctl, a.cam, a.fp, a.passSeeds, a.stackEntries);
@@ -75,15 +75,15 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
 #undef TN_LAUNCH2
     case PK_LIGHTS:
         if (lds)
-            hipLaunchKernelGGL((k_lights<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins);
+            hipLaunchKernelGGL((k_lights<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins, a.order);
         else
-            hipLaunchKernelGGL((k_lights<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins);
+            hipLaunchKernelGGL((k_lights<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins, a.order);
         break;
     case PK_SHADE:
         if (lds)
-            hipLaunchKernelGGL((k_shade<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins);
+            hipLaunchKernelGGL((k_shade<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order);
         else
-            hipLaunchKernelGGL((k_shade<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins);
+            hipLaunchKernelGGL((k_shade<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order);
         break;
     case PK_BOUNCE:
 #define TN_LAUNCH_BOUNCE(FIRST, DEFER)                                                                                 \
