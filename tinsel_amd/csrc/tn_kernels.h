@@ -447,13 +447,32 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
     // (one workgroup per group of four regions; `order`: the groups with the most live entries first, k_region_order)
     for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
-        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
+        const uint32_t r0 = (order ? order[b] : b)*kRegionsPerBlock;
+        const uint32_t r = r0 + threadIdx.x/kWave;            // the region this wave generates / appends to
         const uint32_t base = r*ss.regionLen;
         uint32_t nFront = 0, n;
+        // bounces > 0 of scenes with several shadow rays per bounce: the live entries of the workgroup's four regions form ONE
+        // stream, dealt to its waves round by round.  A workgroup holds its LDS and its wave slots until its last wave ends;
+        // where a round is long (veach: 4 shadow traces, features: 9) its waves drift apart unless they share (veach 1409 ->
+        // 1457 Msamples/s, features 685 -> 712); where rounds are short the dealing costs more than it gives (env_loft, gloss -2 %)
+        const bool share = !FIRST && sc.totalLightSamples >= 3;
+        uint32_t gF[kRegionsPerBlock], gStart[kRegionsPerBlock];
         if (FIRST)
         {
             const uint32_t end = (base + ss.regionLen) < fp.genCount ? (base + ss.regionLen) : fp.genCount;
             n = base < end ? end - base : 0u;
+        }
+        else if (share)
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kRegionsPerBlock; ++k)
+            {
+                gF[k] = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r0 + k]);
+                gStart[k] = run;
+                run += gF[k] + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r0 + k]);
+            }
+            n = run;
         }
         else
         {
@@ -462,7 +481,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         }
         RegionAppend out = { base, ss.regionLen, 0u, 0u };
 
-        for (uint32_t j0 = 0; j0 < n; j0 += kWave)
+        for (uint32_t j0 = share ? threadIdx.x/kWave*kWave : 0u; j0 < n; j0 += share ? kBlock : kWave)
         {
             const uint32_t j = j0 + lane;
             bool have = false, alive = false, front = true;
@@ -486,7 +505,18 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                 }
                 else
                 {
-                    load_state(ss, cur, region_pos(base, ss.regionLen, nFront, j), p, slot, hasMedia);
+                    uint32_t pos;
+                    if (share)
+                    {
+                        uint32_t k = 0, f = gF[0], s0 = 0;
+#pragma unroll
+                        for (uint32_t q2 = 1; q2 < kRegionsPerBlock; ++q2)
+                            if (j >= gStart[q2]) { k = q2; f = gF[q2]; s0 = gStart[q2]; }
+                        pos = region_pos((r0 + k)*ss.regionLen, ss.regionLen, f, j - s0);
+                    }
+                    else
+                        pos = region_pos(base, ss.regionLen, nFront, j);
+                    load_state(ss, cur, pos, p, slot, hasMedia);
                     have = true;
                 }
             }
