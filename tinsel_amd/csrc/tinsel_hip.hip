@@ -845,9 +845,12 @@ int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, floa
 // balance: ~1024 positions per region, between 2 and 32 blocks per CU.  Fused kernel, cornell: a 1 M-path batch 1417 / 1520 /
 // 1655 / 1747 Msamples/s at 16 / 8 / 4 / 2 blocks per CU (regions of 64 ... 512); a 64 Mi batch 2644 / 2735 / 2803 at 8 / 16 /
 // 32 (regions of 8192 / 4096 / 2048).
-int streaming_grid(const tinsel_hip* r, size_t slots)
+int streaming_grid(const tinsel_hip* r, size_t slots, int pipeline)
 {
-    static const size_t regionTarget = getenv("TINSEL_HIP_REGION_LEN") ? (size_t)std::max(64, atoi(getenv("TINSEL_HIP_REGION_LEN"))) : 1024;
+    // (where the fused kernel's waves share their workgroup's regions -- three or more shadow rays per bounce, k_bounce -- the
+    // regions may be twice as long: features 707 -> 740, features + probe 595 -> 622, veach +-0)
+    static const int regionEnv = getenv("TINSEL_HIP_REGION_LEN") ? std::max(64, atoi(getenv("TINSEL_HIP_REGION_LEN"))) : 0;
+    const size_t regionTarget = regionEnv ? (size_t)regionEnv : (pipeline == TINSEL_PIPELINE_WAVEFRONT && r->neePerPath >= 3) ? 2048 : 1024;
     const size_t perBlock = regionTarget*(kBlock/kWave);
     const size_t blocks = (slots + perBlock - 1)/perBlock;
     const size_t lo = std::min<size_t>((size_t)r->numCUs*2, (slots + kBlock - 1)/kBlock), hi = (size_t)r->numCUs*(size_t)grid_mult();
@@ -879,7 +882,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     fp.accEnd = fp.numPasses;
     fp.rrStart = r->rrStart;
     const int gridFlat = (int)std::max<size_t>(1, (slots + kBlock - 1)/kBlock);
-    const int gridPersist = streaming_grid(r, slots);
+    const int gridPersist = streaming_grid(r, slots, resolve_pipeline(r));
     // the trace kernels stride over the regions: by default one block per four regions like the others
     static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : 0;
     const int gridTrace = gridMultTrace > 0 ? std::max(1, std::min(gridPersist, r->numCUs*gridMultTrace)) : gridPersist;
