@@ -191,6 +191,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     int sp = 0;
     V3 o, d, rcp;
     float closestT = kFltMax;
+    float tStop = -kFltMax;             // shadow rays: an accepted hit closer than this ends the walk (never, for extension rays)
     float hu = 0.0f, hv = 0.0f, hw = 0.0f;
     int htri = -1;
     V3 hn;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         const float4* np = job.nee + (size_t)(k*2u)*job.neeStride + slot;
                         ro = np[0]; rd = np[job.neeStride];
                         time = job.neeTime[slot];
+                        tStop = shadow_stop(ro.w);      // the record's .w is the sample's distance (< 0: probe sample)
                     }
                     else
                     {
@@ -403,6 +405,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         hu = u; hv = v; hw = w;
                         htri = i;
                         hn = n*sign;
+                        if (t < tStop)
+                            sp = 0;     // shadow ray decided (shadow_stop, tn_isect.h): drop what is left on the stack
                     }
                 }
                 pop = true;
