@@ -690,7 +690,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(SplitState ss, QueueCtl 
             }
             const uint32_t pos = out.push(live, front);
             if (live)
-                store_state(ss, 0, pos, p, slot, hasMedia != 0);
+            {
+                // ray and RNG only: the rest of a fresh path's state is constant and k_shade knows it (ShadeFetch::issue)
+                ss.rayO[0][pos] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
+                ss.rayD[0][pos] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
+                ss.rngId[0][pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), 0.0f);
+            }
         }
         if (lane == 0)
         {
@@ -974,12 +979,24 @@ struct ShadeFetch
     int prim;
     uint32_t qn;
 
-    TN_D void issue(const SplitState& ss, int buf, uint32_t pos, bool valid, bool hasMedia, bool hasNee)
+    // `fresh`: bounce 0 -- throughput, radiance, medium and ray type are path_begin's constants (render.cpp:233-248), which
+    // k_generate therefore does not write
+    TN_D void issue(const SplitState& ss, int buf, uint32_t pos, bool valid, bool hasMedia, bool hasNee, bool fresh)
     {
         if (!valid)
             return;
-        ro = ss.rayO[buf][pos]; rd = ss.rayD[buf][pos]; th = ss.thr[buf][pos]; ra = ss.rad[buf][pos];
-        ab = hasMedia ? ss.absorb[buf][pos] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        ro = ss.rayO[buf][pos]; rd = ss.rayD[buf][pos];
+        if (fresh)
+        {
+            th = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            ra = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(kReflected));
+            ab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        else
+        {
+            th = ss.thr[buf][pos]; ra = ss.rad[buf][pos];
+            ab = hasMedia ? ss.absorb[buf][pos] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
         rr = ss.rngId[buf][pos];
         hh = ss.hit[pos];
         prim = ss.hitPrim[pos];
@@ -1018,14 +1035,14 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
         // The kernel runs two waves per SIMD, too few to hide a round's loads behind another wave's arithmetic: the records
         // of round i + 1 are requested before round i is shaded (they are reads of buffer `cur`, which nothing here writes).
         ShadeFetch next;
-        next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, lane < n ? lane : 0u), lane < n, hasMedia, K > 0);
+        next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, lane < n ? lane : 0u), lane < n, hasMedia, K > 0, bounce == 0);
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
             const ShadeFetch f = next;
             {
                 const uint32_t jn = j + kWave;
-                next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, jn < n ? jn : 0u), jn < n, hasMedia, K > 0);
+                next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, jn < n ? jn : 0u), jn < n, hasMedia, K > 0, bounce == 0);
             }
             bool alive = false, front = true;
             PathRegs p;
