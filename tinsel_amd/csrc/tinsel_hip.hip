@@ -934,7 +934,14 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         const bool walkedOnly = walk && !noLeanScan && meshPrims == r->walkPrims.count && !r->scene.allInArena;
         const int stackScan = walkedOnly ? std::max(1, pick_stack(r->sceneStackNeed)) : r->stackNeed;
         const uint32_t ldsTrace = walkedOnly ? (uint32_t)(((size_t)stackScan*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes) : a.ldsBytes;
-        const uint32_t ldsShade = r->scene.allInArena ? r->scene.arenaBytes : r->scene.arenaLdsBytes;
+        // k_shade has no traversal stacks in LDS and reads a material per path: an arena too large to sit beside the stacks of the
+        // trace kernels (32 KB) is still staged by it up to 60 KB (many_spheres, 39 KB of primitive and material records: k_shade
+        // 7.8 -> 6.7 ms; staged in the trace kernels too it costs them their fourth wave per SIMD, 1380 -> 1280 Msamples/s, and
+        // k_lights reads too little of it to repay the copy, 2.7 -> 3.1 ms)
+        static const bool noShadeArena = getenv("TINSEL_HIP_NO_SHADE_ARENA") != nullptr;
+        const uint32_t arenaLdsTrace = r->scene.arenaLdsBytes;
+        const uint32_t arenaLdsShade = (arenaLdsTrace == 0 && !noShadeArena && r->scene.arenaBytes <= 61440u && !getenv("TINSEL_HIP_NO_LDS_SCENE")) ? r->scene.arenaBytes : arenaLdsTrace;
+        const uint32_t ldsShade = r->scene.allInArena ? r->scene.arenaBytes : arenaLdsShade;
         a.walkedOnly = walkedOnly ? 1 : 0;
         // the lean k_extend draws the light samples itself (tn_launch.h launches it when walkedOnly and not counting)
         const bool lightsInExtend = walkedOnly && !r->countDetail;
@@ -984,7 +991,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 {
                     ScopedTimer t(r, KN_LIGHTS, st);
                     a.grid = gridPersist;
-                    a.ldsBytes = ldsShade;
+                    a.ldsBytes = r->scene.allInArena ? r->scene.arenaBytes : arenaLdsTrace;
                     launch_path(r, PK_LIGHTS, a, st);
                 }
                 if (walk)
@@ -1008,7 +1015,9 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 ScopedTimer t(r, KN_SHADE, st);
                 a.grid = gridPersist;
                 a.ldsBytes = ldsShade;
+                a.scene.arenaLdsBytes = arenaLdsShade;
                 launch_path(r, PK_SHADE, a, st);
+                a.scene.arenaLdsBytes = arenaLdsTrace;
             }
         }
     }
