@@ -29,8 +29,9 @@ namespace tn {
 #define TN_WAVES_FUSED 2
 #endif
 // k_bounce alone: the tolerance arm's k_bounce needs ~205 VGPRs and is faster squeezed to 168 (3 waves per SIMD, ~100 B of
-// scratch: cornell 3203 -> 3827 Msamples/s); its k_shade is not (veach 1698 -> 1563), and the exact arm's k_bounce (256 VGPRs
-// + scratch already) is 1.4-1.8x slower when squeezed.
+// scratch: cornell 3203 -> 3827 Msamples/s); its k_shade (split pipeline) needs ~180 and runs at 168 / 3 waves with 16-20 B of
+// scratch (glass 15.9 -> 15.0 ms); the exact arm's k_bounce (256 VGPRs + scratch already: 364-416 B at 168) and k_shade
+// (222 + the next round's records) stay at two waves.
 #ifndef TN_WAVES_BOUNCE
 #define TN_WAVES_BOUNCE TN_WAVES_FUSED
 #endif
