@@ -870,7 +870,6 @@ int set_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int gridPersist)
 
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp, bool accumulate = true)
 {
-    const size_t npix = (size_t)fp.width*fp.height;
     // path slots of this shard per pass and per batch (slot_pixel / slot_of, tn_kernels.h): rank-local numbering
     const size_t perPass = slots_per_pass(r, fp.width, fp.height, &fp.shardTilesX, &fp.shardOwnedTiles);
     const size_t slots = perPass*(size_t)fp.numPasses;

@@ -661,7 +661,7 @@ TN_D bool ray_enters_big_mesh(const PrimBox* __restrict__ primBoxes, const BinPr
 // k_generate: camera paths of the batch into buffer 0; region r takes the generation indices [r*regionLen, (r+1)*regionLen)
 
 __global__ __launch_bounds__(kBlock, 4) void k_generate(SplitState ss, QueueCtl q, CameraParams cam, FrameParams fp,
-                                                     const uint32_t* __restrict__ passSeeds, const PrimBox* __restrict__ primBoxes, BinPrims bp, int hasMedia)
+                                                     const uint32_t* __restrict__ passSeeds, const PrimBox* __restrict__ primBoxes, BinPrims bp)
 {
     const uint32_t lane = __lane_id();
     uint32_t samples = 0;
@@ -1396,7 +1396,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
     const int reachHi = (int)ceilf(fw);
     const int side = kAccTile + reachLo + reachHi;
     const int ox = tx*kAccTile - reachLo, oy = ty*kAccTile - reachLo;     // frame coordinates of LDS entry (0,0)
-    const int npix = fp.width*fp.height;
     const bool gauss = fp.filterType != 0;
 
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

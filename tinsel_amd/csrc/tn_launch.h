@@ -50,7 +50,7 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
     switch (which)
     {
     case PK_GENERATE:
-        hipLaunchKernelGGL(k_generate, grid, block, 0, st, a.ss, a.ctl, a.cam, a.fp, a.passSeeds, a.scene.primBoxes, a.bins, a.scene.hasMedia);
+        hipLaunchKernelGGL(k_generate, grid, block, 0, st, a.ss, a.ctl, a.cam, a.fp, a.passSeeds, a.scene.primBoxes, a.bins);
         break;
     case PK_EXTEND:
 #define TN_LAUNCH2(KERNEL, ...)                                                                                        \
