@@ -1540,6 +1540,9 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 dm.numTris = numTris;
                 dm.stackNeed = cb.maxLeafDepth + 1;
                 dm.topCount = cb.topCount;
+                // one internal node over two one-triangle leaves (a quad): walked without stack or loop (ray_mesh_two_leaves)
+                dm.twoLeaves = (cb.nodes.size() == 1 && !(cb.root & kLeafBit) && (cb.nodes[0].left & kLeafBit) && (cb.nodes[0].right & kLeafBit) &&
+                                !getenv("TINSEL_HIP_NO_TWO_LEAVES")) ? 1 : 0;
                 const size_t meshBytes = cb.nodes.size()*sizeof(Node64) + tris.size()*sizeof(Tri48) + (size_t)g.num_vertices*12 + (size_t)numTris*4;
                 if (lives_in_arena(meshBytes, numTris))
                 {

@@ -161,6 +161,54 @@ struct MeshHit
 };
 
 // IntersectRayMesh + MeshQuery (intersection.h:629-749).  `sp` = first free stack slot.
+// ray_mesh for a tree that is ONE internal node over two one-triangle leaves (quads: cornell's lamp, veach's plates -- meshes
+// every shadow ray or every ray enters).  The loop below unrolled for that tree: the same box tests on the same record, the
+// near child first exactly as the stack would pop it, both leaves tested when their boxes are hit (the `tChild < tmax` cull is
+// evaluated before any triangle is: tmax is still FLT_MAX), strict `<` between the two hits.  No stack, no loop.
+template <bool COUNT>
+TN_D bool ray_mesh_two_leaves(const Node64* mnodes, const Tri48* mtris, uint32_t mroot, V3 o, V3 d, MeshHit& hit, TraceCounters& ctr)
+{
+    const V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    const Node64 nd = load_node(mnodes, mroot);
+    if (COUNT) ctr.internal++;
+
+    float tL, tR;
+    const bool hL = ray_aabb(o, rcp, nd.lminx, nd.lminy, nd.lminz, nd.lmaxx, nd.lmaxy, nd.lmaxz, tL) && tL < kFltMax;
+    const bool hR = ray_aabb(o, rcp, nd.rminx, nd.rminy, nd.rminz, nd.rmaxx, nd.rmaxy, nd.rmaxz, tR) && tR < kFltMax;
+
+    // ray_mesh pushes `first` (if the left box is hit) then `second` (if the right one is) and pops the last pushed first
+    uint32_t first = nd.left, second = nd.right;
+    if (hL && hR && (tL < tR))
+    {
+        first = nd.right;
+        second = nd.left;
+    }
+    float closestT = kFltMax;
+    auto leaf = [&](uint32_t ref) {
+        const int i = (int)(ref & ~kLeafBit);
+        const float4* tp = reinterpret_cast<const float4*>(mtris + i);
+        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+        if (COUNT) ctr.tris++;
+        float t, u, v, w, sign;
+        V3 n;
+        if (ray_tri(o, d, V3(ta.x, ta.y, ta.z), V3(tb.x, tb.y, tb.z), V3(tc.x, tc.y, tc.z), t, u, v, w, sign, n))
+        {
+            if (t > 0.0f && t < closestT)
+            {
+                closestT = t;
+                hit.t = t; hit.u = u; hit.v = v; hit.w = w;
+                hit.tri = i;
+                hit.n = n*sign;
+            }
+        }
+    };
+    if (hR)
+        leaf(second);
+    if (hL)
+        leaf(first);
+    return closestT < kFltMax;
+}
+
 // ANYHIT / tStop (shadow rays, shadow_stop below): the walk may stop at the first accepted hit with t < tStop.
 template <class Stack, bool COUNT, bool ANYHIT = false>
 TN_D bool ray_mesh(const Node64* mnodes, const Tri48* mtris, uint32_t mroot, Stack& st, int sp, V3 o, V3 d, MeshHit& hit, TraceCounters& ctr, float tStop = 0.0f)
@@ -300,7 +348,14 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
         h.n = V3(rb.x, rb.y, rb.z);
         h.tri = __float_as_int(rb.w);
     }
-    else if (SC::kWalkedOnly || !ray_mesh<Stack, COUNT, ANYHIT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, h, ctr, tStop))
+    else if (SC::kWalkedOnly)
+        return false;
+    else if (m.twoLeaves)
+    {
+        if (!ray_mesh_two_leaves<COUNT>(mesh_nodes(sc, m), mtris, m.root, lo, ld, h, ctr))
+            return false;
+    }
+    else if (!ray_mesh<Stack, COUNT, ANYHIT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, h, ctr, tStop))
         return false;
 
     // interpolate vertex normals (intersection.h:996-1012)

@@ -116,7 +116,7 @@ struct DevMesh
     int32_t inArena;            // 1: nodes/tris/normals/cdf live inside DevScene::arena (and follow it into LDS)
     uint32_t offNodes, offTris, offNormals, offCdf;     // byte offsets inside the arena (inArena only)
     int32_t topCount;           // nodes [0, topCount) are the top of the tree in breadth-first order (k_walk stages a prefix into LDS)
-    int32_t padMesh;
+    int32_t twoLeaves;          // 1: the tree is one internal node over two one-triangle leaves (a quad): ray_mesh_two_leaves
 };
 
 struct DevProbe
