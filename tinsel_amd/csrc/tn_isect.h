@@ -305,11 +305,26 @@ TN_D Prim64 load_prim(const Prim64* prims, int idx)
     return p;
 }
 
+// the same record through the constant-address-space pointer, at a wave-uniform index (scalar loads)
+TN_D Prim64 load_prim_uniform(ConstF4 prims, int idx)
+{
+    ConstF4 pp = prims + (size_t)idx*4;
+    const ConstF4V a = pp[0], b = pp[1], c = pp[2], d = pp[3];
+    Prim64 p;
+    p.px = a.x; p.py = a.y; p.pz = a.z; p.s = a.w;
+    p.rx = b.x; p.ry = b.y; p.rz = b.z; p.rw = b.w;
+    p.g0 = c.x; p.g1 = c.y; p.g2 = c.z; p.g3 = c.w;
+    p.type = __float_as_uint(d.x); p.flags = __float_as_uint(d.y);
+    p.mesh = __float_as_uint(d.z); p.moving = __float_as_uint(d.w);
+    return p;
+}
+
 // PrimitiveIntersect (intersection.h:951-1020)
-template <class SC, class Stack, bool COUNT, bool ANYHIT = false>
+// UNIFORM: `index` is the same in every lane (the flat scan's loop counter)
+template <class SC, class Stack, bool COUNT, bool ANYHIT = false, bool UNIFORM = false>
 TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f)
 {
-    const Prim64 p = load_prim(sc.prims, index);
+    const Prim64 p = UNIFORM ? load_prim_uniform(sc.kPrims, index) : load_prim(sc.prims, index);
     if (COUNT) ctr.prims++;
 
     if (p.type == kPrimPlane)
@@ -422,8 +437,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
     for (int i = 0; i < sc.numPrims; ++i)
     {
         TN_TTICK(ctr, 4)
-        const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + i);
-        const float4 b0 = bp[0], b1 = bp[1];
+        const ConstF4V b0 = sc.kBoxes[i*2], b1 = sc.kBoxes[i*2 + 1];
         if (__float_as_uint(b1.z) == 0u)
         {
             float tb;
@@ -431,14 +445,14 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
                 continue;
         }
         TN_TTICK(ctr, 0)
-        if (SC::kDefer != 0 && (SC::kDefer == 1 || sc.deferMeshes) && __float_as_uint(reinterpret_cast<const float4*>(sc.prims + i)[3].x) == (uint32_t)kPrimMesh)
+        if (SC::kDefer != 0 && (SC::kDefer == 1 || sc.deferMeshes) && __float_as_uint(sc.kPrims[i*4 + 3].x) == (uint32_t)kPrimMesh)
         {
             meshes |= 1ull << i;
             continue;
         }
         float t;
         V3 n;
-        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, i, st, 0, o, d, time, t, n, ctr, tStop);
+        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop);
 #ifdef TN_PROFILE_TRACE
         { const uint32_t ty = __builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float4*>(sc.prims + i)[3].x)); TN_TTICK(ctr, ty == kPrimPlane ? 1 : ty == kPrimSphere ? 2 : 3) }
 #endif

@@ -129,6 +129,8 @@ TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER>& sc, const DevScene& in, uin
     sc.ldsBase = lds;
     sc.walkRec = nullptr;
     sc.walkItem = 0u;
+    sc.kPrims = (ConstF4)(uintptr_t)in.prims;
+    sc.kBoxes = (ConstF4)(uintptr_t)in.primBoxes;
     if (!LDS && in.arenaLdsBytes == 0)
         return;
 

@@ -171,6 +171,9 @@ struct DevScene
 // kernels are compiled without the inline mesh walk (no deep stack, half the registers, twice the waves).
 // DEFER: trace_flat's deferred mesh walks (tn_isect.h) compiled out (0), in (1), or behind DevScene::deferMeshes (2).  The
 // fused kernel is built both ways -- the second loop costs 2 % where there is nothing to defer (cornell).
+typedef float ConstF4V __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) ConstF4V* ConstF4;
+
 template <bool LDS, bool WALKED_ONLY = false, int DEFER = 2>
 struct SceneT : DevScene
 {
@@ -178,6 +181,9 @@ struct SceneT : DevScene
     static constexpr bool kWalkedOnly = WALKED_ONLY;
     static constexpr int kDefer = DEFER;
     const unsigned char* ldsBase;
+    // The flat scan reads primitive records and leaf boxes at a wave-uniform index: through these pointers (the arena's copy
+    // in HBM, constant address space) they are scalar loads into SGPRs instead of 64 lanes reading the same LDS words
+    ConstF4 kPrims, kBoxes;
     // closest-hit records of the walked primitives for the ray being traced (tn_walk.h): record lane kb of the ray
     // lives at walkRec[(walkItem + kb)*2 .. +1]; null = walk the mesh inline (ray_mesh)
     const float4* walkRec;
