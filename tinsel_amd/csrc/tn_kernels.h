@@ -121,8 +121,8 @@ TN_D void wave_add_stat(unsigned long long* stats, int word, uint32_t v)
 //                 kernel-argument pointers are global, and global + delta would be issued as a global
 //                 load of an LDS aperture address.
 // MUST be reached by every thread of the block.
-template <bool LDS, bool WONLY, int DEFER>
-TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER>& sc, const DevScene& in, uint32_t* ldsWords)
+template <bool LDS, bool WONLY, int DEFER, bool MIXED>
+TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER, MIXED>& sc, const DevScene& in, uint32_t* ldsWords)
 {
     static_cast<DevScene&>(sc) = in;
     unsigned char* lds = reinterpret_cast<unsigned char*>(ldsWords);
@@ -783,13 +783,13 @@ TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& b
 // kernel is the flat scan + record reads) also draws the light samples, the hit still in registers: there a kernel of its
 // own for them costs more than it saves (524k-triangle config: 2.1 + 2.9 ms apart, 3.9 together); behind the inline mesh
 // walk it is the other way round (the fused kernel needs 170 VGPRs: glass 21.2 + 7.9 apart, 31.5 together at 3 waves).
-template <bool COUNT, bool LDS, bool WONLY = false>
+template <bool COUNT, bool LDS, bool WONLY = false, bool MIXED = false>
 __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : TN_WAVES_TRACE) void k_extend(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
                                                                   const float4* __restrict__ walkRec, uint32_t walkPrims, BinPrims bp, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
-    SceneT<LDS, WONLY> sc;
+    SceneT<LDS, WONLY, 2, MIXED> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
     const uint32_t lane = __lane_id();
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : TN_WAVES_TRA
                 sc.walkItem = pos*walkPrims;        // only front rays ever reach a walked primitive
 
                 float t;
-                const int prim = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, hitN, ctr);
+                const int prim = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, hitN, ctr);
 
                 ss.hit[pos] = make_float4(t, hitN.x, hitN.y, hitN.z);
                 ss.hitPrim[pos] = prim;
@@ -848,11 +848,11 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : TN_WAVES_TRA
 }
 
 // k_lights: the light samples of a bounce as a kernel of its own (scenes whose k_extend walks meshes inline)
-template <bool LDS>
+template <bool LDS, bool MIXED = false>
 __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scIn, SplitState ss, int bounce, BinPrims bp, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_arena[];
-    SceneT<LDS> sc;
+    SceneT<LDS, false, 2, MIXED> sc;
     stage_scene_lds(sc, scIn, s_arena);
     const uint32_t lane = __lane_id();
     const int cur = bounce & 1;
@@ -913,13 +913,13 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
 
 // k_shadow: the Trace() calls of SampleLights (render.cpp:117, 172) and the tests that follow them (:118, :175-196): one
 // lane per path traces its K shadow rays and leaves, per ray, the primitive whose emission arrives (or -1) and its t.
-template <bool COUNT, bool LDS, bool WONLY = false>
+template <bool COUNT, bool LDS, bool WONLY = false, bool MIXED = false>
 __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_shadow(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
                                                                   const float4* __restrict__ walkRec, uint32_t walkPrims, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
-    SceneT<LDS, WONLY> sc;
+    SceneT<LDS, WONLY, 2, MIXED> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
 
     const uint32_t lane = __lane_id();
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
                 sc.walkItem = (qn*(uint32_t)K + (uint32_t)k)*walkPrims;
                 // the walks of a shadow ray stop at an occluder that decides the sample (shadow_stop, tn_isect.h: the scene BVH here,
                 // meshes in HBM in k_walk; many_spheres 1309 -> 1369 Msamples/s, config 3 1923 -> 1959)
-                const int hp = trace<SceneT<LDS, WONLY>, LdsStack<kBlock>, COUNT, !COUNT>(sc, st, ray.o, ray.wi, time, t, n3, ctr, shadow_stop(ray.dist));
+                const int hp = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT, !COUNT>(sc, st, ray.o, ray.wi, time, t, n3, ctr, shadow_stop(ray.dist));
                 rays++;
                 int arrives;
                 if (ray.dist < 0.0f)
@@ -1018,11 +1018,11 @@ struct ShadeFetch
     }
 };
 
-template <bool LDS>
+template <bool LDS, bool MIXED = false>
 __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_arena[];
-    SceneT<LDS> sc;
+    SceneT<LDS, false, 2, MIXED> sc;
     stage_scene_lds(sc, scIn, s_arena);
     const uint32_t lane = __lane_id();
     const int cur = bounce & 1, nxt = cur ^ 1;

@@ -47,6 +47,8 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
 {
     const dim3 grid((unsigned)a.grid), block(kBlock);
     const bool lds = a.scene.allInArena != 0, count = a.countDetail != 0;
+    // the arena is staged whole but some meshes live in HBM: SceneT's MIXED mode (scene records at compile-time LDS addresses)
+    const bool mixed = !lds && !count && a.scene.arenaLdsBytes != 0 && a.scene.arenaLdsBytes == a.scene.arenaBytes;
     switch (which)
     {
     case PK_GENERATE:
@@ -58,14 +60,22 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             if (count) { if (lds) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__); } \
             else       { if (lds) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); } \
         } while (0)
-        if (a.walkedOnly && !count && !lds)
+        if (a.walkedOnly && mixed)
+            hipLaunchKernelGGL((k_extend<false, true, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
+        else if (a.walkedOnly && !count && !lds)
             hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
+        else if (mixed)
+            hipLaunchKernelGGL((k_extend<false, true, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         else
             TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         break;
     case PK_SHADOW:
-        if (a.walkedOnly && !count && !lds)
+        if (a.walkedOnly && mixed)
+            hipLaunchKernelGGL((k_shadow<false, true, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
+        else if (a.walkedOnly && !count && !lds)
             hipLaunchKernelGGL((k_shadow<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
+        else if (mixed)
+            hipLaunchKernelGGL((k_shadow<false, true, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
         else
             TN_LAUNCH2(k_shadow, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
         break;
@@ -74,13 +84,17 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
         break;
 #undef TN_LAUNCH2
     case PK_LIGHTS:
-        if (lds)
+        if (mixed)
+            hipLaunchKernelGGL((k_lights<true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins, a.order);
+        else if (lds)
             hipLaunchKernelGGL((k_lights<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins, a.order);
         else
             hipLaunchKernelGGL((k_lights<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins, a.order);
         break;
     case PK_SHADE:
-        if (lds)
+        if (mixed)
+            hipLaunchKernelGGL((k_shade<true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order);
+        else if (lds)
             hipLaunchKernelGGL((k_shade<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order);
         else
             hipLaunchKernelGGL((k_shade<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order);

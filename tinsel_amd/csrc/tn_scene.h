@@ -174,10 +174,14 @@ struct DevScene
 typedef float ConstF4V __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) ConstF4V* ConstF4;
 
-template <bool LDS, bool WALKED_ONLY = false, int DEFER = 2>
+// MIXED (with LDS): the arena is staged whole and every scene record resolves to LDS at compile time, but some meshes live in
+// HBM -- the split pipeline's scenes (glass, the 524k-triangle config).  Only the mesh accessors below then choose per mesh;
+// without it those kernels reach everything through generic pointers (flat loads, which wait on both memory counters).
+template <bool LDS, bool WALKED_ONLY = false, int DEFER = 2, bool MIXED = false>
 struct SceneT : DevScene
 {
     static constexpr bool kLds = LDS;
+    static constexpr bool kMixed = MIXED;
     static constexpr bool kWalkedOnly = WALKED_ONLY;
     static constexpr int kDefer = DEFER;
     const unsigned char* ldsBase;
@@ -192,19 +196,23 @@ struct SceneT : DevScene
 
 template <class SC> TN_D const Node64* mesh_nodes(const SC& sc, const DevMesh& m)
 {
-    if constexpr (SC::kLds) return reinterpret_cast<const Node64*>(sc.ldsBase + m.offNodes); else return m.nodes;
+    if constexpr (SC::kLds && SC::kMixed) return m.inArena ? reinterpret_cast<const Node64*>(sc.ldsBase + m.offNodes) : m.nodes;
+    else if constexpr (SC::kLds) return reinterpret_cast<const Node64*>(sc.ldsBase + m.offNodes); else return m.nodes;
 }
 template <class SC> TN_D const Tri48* mesh_tris(const SC& sc, const DevMesh& m)
 {
-    if constexpr (SC::kLds) return reinterpret_cast<const Tri48*>(sc.ldsBase + m.offTris); else return m.tris;
+    if constexpr (SC::kLds && SC::kMixed) return m.inArena ? reinterpret_cast<const Tri48*>(sc.ldsBase + m.offTris) : m.tris;
+    else if constexpr (SC::kLds) return reinterpret_cast<const Tri48*>(sc.ldsBase + m.offTris); else return m.tris;
 }
 template <class SC> TN_D const float* mesh_normals(const SC& sc, const DevMesh& m)
 {
-    if constexpr (SC::kLds) return reinterpret_cast<const float*>(sc.ldsBase + m.offNormals); else return m.normals;
+    if constexpr (SC::kLds && SC::kMixed) return m.inArena ? reinterpret_cast<const float*>(sc.ldsBase + m.offNormals) : m.normals;
+    else if constexpr (SC::kLds) return reinterpret_cast<const float*>(sc.ldsBase + m.offNormals); else return m.normals;
 }
 template <class SC> TN_D const float* mesh_cdf(const SC& sc, const DevMesh& m)
 {
-    if constexpr (SC::kLds) return reinterpret_cast<const float*>(sc.ldsBase + m.offCdf); else return m.cdf;
+    if constexpr (SC::kLds && SC::kMixed) return m.inArena ? reinterpret_cast<const float*>(sc.ldsBase + m.offCdf) : m.cdf;
+    else if constexpr (SC::kLds) return reinterpret_cast<const float*>(sc.ldsBase + m.offCdf); else return m.cdf;
 }
 
 } // namespace tn
