@@ -201,8 +201,12 @@ int tinsel_hip_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_o
  * for (same camera, options and pass count) are traced into a second accumulator; a matching next call only swaps
  * buffers and copies, anything else drops the speculation.  Images are bit-identical to the plain path; the statistics
  * counters and tinsel_hip_read_batch_radiance see one call ahead (every other entry point drops the speculation first).
- * The caller's output array is page-locked in place (hipHostRegister) on first use.  Off by default; the C++ shim
- * turns it on. */
+ * Off by default; the C++ shim turns it on (TINSEL_LOOKAHEAD_ON).
+ * TINSEL_LOOKAHEAD_PIN_OUTPUT additionally page-locks the caller's output array IN PLACE (hipHostRegister) so that the
+ * read-back is an asynchronous DMA: only for callers who guarantee that the array outlives the renderer, the next
+ * tinsel_hip_init or the next tinsel_hip_set_lookahead -- the registration is dropped there, and registered memory must
+ * not be freed before (the reference's own caller frees its array before Init, main.cpp:73-87: it gets plain ON). */
+enum { TINSEL_LOOKAHEAD_OFF = 0, TINSEL_LOOKAHEAD_ON = 1, TINSEL_LOOKAHEAD_PIN_OUTPUT = 2 };
 int tinsel_hip_set_lookahead(tinsel_hip* r, int enable);
 
 /* Same, but never touches host memory: enqueues `passes` passes on `stream`
@@ -389,10 +393,18 @@ int tinsel_hip_group_init(tinsel_hip_group* g, int width, int height);
 /* Renderer::Render: `passes` more samples per pixel of the WHOLE frame (each member its tiles), then -- when out_rgba
  * is not NULL -- reduce + copy the running sum of everything since Init to out_rgba (W*H*4 floats, host). */
 int tinsel_hip_group_render(tinsel_hip_group* g, const tinsel_camera* camera, const tinsel_options* options, float* out_rgba, int passes);
+/* Look-ahead for the reference's call pattern (tinsel_hip_set_lookahead) with N members: after a read-back every member
+ * goes on with the calls that will most probably follow (same camera, options, pass count) -- a batch of up to 16 calls of
+ * ITS shard traced at once, one snapshot accumulator per call -- and the NEXT call's snapshots are reduced (one
+ * ncclReduce, each member from its own thread and stream) while this call's sum crosses PCIe.  A matching call waits
+ * for that reduce (done, as a rule), swaps two buffers and copies; anything else drops the speculation.  Images are
+ * those of the plain path bit for bit.  `enable` as for tinsel_hip_set_lookahead (a group of one forwards to it). */
+int tinsel_hip_group_set_lookahead(tinsel_hip_group* g, int enable);
 /* The display stage (tinsel_hip_present) on the reduced accumulator, run on member 0. */
 int tinsel_hip_group_present(tinsel_hip_group* g, const tinsel_options* options, int nlm_width, float nlm_falloff, float* out_rgba);
 int tinsel_hip_group_size(tinsel_hip_group* g);
-/* Member `rank`'s renderer, for the introspection / statistics entry points (do not render or init through it). */
+/* Member `rank`'s renderer, for the introspection / statistics entry points (do not render or init through it).
+ * Whatever the group had speculated is dropped first (look-ahead starts over with the next read-back). */
 tinsel_hip* tinsel_hip_group_member(tinsel_hip_group* g, int rank);
 
 /* ------------------------------------------------------------------------- */

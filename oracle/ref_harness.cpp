@@ -726,6 +726,14 @@ void ref_pfm_save(const float* rgb, int width, int height, const char* path)
     fflush(NULL);       // PfmSave never closes its FILE (pfm.cpp:70-85)
 }
 
+// the reference's own PrimitiveBounds (intersection.h:906-939): the leaf box Scene::Build gives the scene BVH builder
+void ref_primitive_bounds(void* h, int prim, float* out6)
+{
+    const Bounds b = PrimitiveBounds(((RefScene*)h)->scene.primitives[(size_t)prim]);
+    out6[0] = b.lower.x; out6[1] = b.lower.y; out6[2] = b.lower.z;
+    out6[3] = b.upper.x; out6[4] = b.upper.y; out6[5] = b.upper.z;
+}
+
 int ref_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
 
 } // extern "C"

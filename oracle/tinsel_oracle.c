@@ -1125,6 +1125,50 @@ void port_scene_get(void* h, tinsel_camera* cam, tinsel_options* opt)
 
 uint32_t port_pass_seed(uint32_t i) { return pass_seed(i); }
 
+/* PrimitiveBounds (intersection.h:906-939) with TransformBounds (maths.h:1004-1021) and Union (:1023-1026): the leaf box
+ * Scene::Build (scene.cpp:4-16) hands to the scene-level BVHBuilder.  A mesh reads its local box from its BVH root. */
+static void transform_bounds(xform x, vec3 lower, vec3 upper, vec3* outLower, vec3* outUpper)
+{
+    vec3 c0 = qrotate(x.r, v3(1.0f, 0.0f, 0.0f));                  /* Mat33(Quat), maths.h:654-663 */
+    vec3 c1 = qrotate(x.r, v3(0.0f, 1.0f, 0.0f));
+    vec3 c2 = qrotate(x.r, v3(0.0f, 0.0f, 1.0f));
+    vec3 halfEdgeWidth = vscale(vscale(vsub(upper, lower), x.s), 0.5f);       /* xform.s*bounds.GetEdges()*0.5f */
+    vec3 ax = vscale(v3(absT(c0.x), absT(c0.y), absT(c0.z)), halfEdgeWidth.x);
+    vec3 ay = vscale(v3(absT(c1.x), absT(c1.y), absT(c1.z)), halfEdgeWidth.y);
+    vec3 az = vscale(v3(absT(c2.x), absT(c2.y), absT(c2.z)), halfEdgeWidth.z);
+    vec3 center = xform_point(x, vscale(vadd(lower, upper), 0.5f));           /* GetCenter(): 0.5*(lower+upper), maths.h:949 */
+    *outLower = vsub(vsub(vsub(center, ax), ay), az);
+    *outUpper = vadd(vadd(vadd(center, ax), ay), az);
+}
+
+void port_primitive_bounds(void* h, int prim, float* out6)
+{
+    scene_t* sc = (scene_t*)h;
+    const tinsel_primitive* p = &sc->prims[prim];
+    vec3 lo = v3s(0.0f), hi = v3s(0.0f);
+    if (p->type == TINSEL_GEOM_SPHERE)
+    {
+        lo = v3s(-p->geo.sphere.radius);
+        hi = v3s(p->geo.sphere.radius);
+    }
+    else if (p->type == TINSEL_GEOM_PLANE)
+    {
+        lo = v3s(-1.e+8f);
+        hi = v3s(1.e+8f);
+    }
+    else if (p->type == TINSEL_GEOM_MESH)
+    {
+        const tinsel_bvh_node* root = &p->geo.mesh.nodes[0];
+        lo = v3(root->lower.x, root->lower.y, root->lower.z);
+        hi = v3(root->upper.x, root->upper.y, root->upper.z);
+    }
+    vec3 sl, su, el, eu;
+    transform_bounds(to_xform(&p->start_transform), lo, hi, &sl, &su);
+    transform_bounds(to_xform(&p->end_transform), lo, hi, &el, &eu);
+    out6[0] = minT(sl.x, el.x); out6[1] = minT(sl.y, el.y); out6[2] = minT(sl.z, el.z);
+    out6[3] = maxT(su.x, eu.x); out6[4] = maxT(su.y, eu.y); out6[5] = maxT(su.z, eu.z);
+}
+
 void port_leaf_random(uint32_t seed, int n, uint32_t* outRand, float* outRandf)
 {
     rng_t a = rng_seeded(seed), b = rng_seeded(seed);

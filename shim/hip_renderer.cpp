@@ -51,13 +51,24 @@ struct HipRenderer : public Renderer
         }
         const char* n = getenv("TINSEL_HIP_NUM_GPUS");
         group = tinsel_hip_group_create(&d, n ? atoi(n) : 0, 64);
+        if (!group && !(n && atoi(n) == 1))
+        {
+            // several GPUs visible but no group (RCCL missing, communicator refused, a device busy): one GPU still renders
+            fprintf(stderr, "CreateGpuRenderer: %s -- falling back to one GPU\n", tinsel_hip_last_error());
+            group = tinsel_hip_group_create(&d, 1, 64);
+        }
         if (!group)
             fprintf(stderr, "CreateGpuRenderer: %s\n", tinsel_hip_last_error());
-        else if (tinsel_hip_group_size(group) > 1)
-            fprintf(stderr, "CreateGpuRenderer: %d GPUs\n", tinsel_hip_group_size(group));
-        else if (!getenv("TINSEL_HIP_NO_LOOKAHEAD"))
-            // main.cpp:246-250 calls Render() once per pass with a full-frame read-back: trace the next pass while this one is copied
-            tinsel_hip_set_lookahead(tinsel_hip_group_member(group, 0), 1);
+        else
+        {
+            if (tinsel_hip_group_size(group) > 1)
+                fprintf(stderr, "CreateGpuRenderer: %d GPUs\n", tinsel_hip_group_size(group));
+            // main.cpp:246-250 calls Render() once per pass with a full-frame read-back: the next calls are traced (and, with
+            // several GPUs, reduced) while this one's image is copied out.  The caller's array is NOT page-locked by default:
+            // main.cpp:73-87 frees it before Init.  TINSEL_HIP_PIN_OUTPUT=1 for callers whose array outlives the renderer.
+            if (!getenv("TINSEL_HIP_NO_LOOKAHEAD"))
+                tinsel_hip_group_set_lookahead(group, getenv("TINSEL_HIP_PIN_OUTPUT") ? TINSEL_LOOKAHEAD_PIN_OUTPUT : TINSEL_LOOKAHEAD_ON);
+        }
     }
 
     virtual ~HipRenderer() { tinsel_hip_group_destroy(group); }

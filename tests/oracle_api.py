@@ -226,6 +226,21 @@ class RefOracle(_OracleBase):
         return d, c, pdf, pdf2, ev
 
 
+def _bounds_api():
+    def primitive_bounds(self, h, prim):
+        """PrimitiveBounds (intersection.h:906-939): the leaf box Scene::Build gives the scene BVH builder -> (lower, upper)"""
+        fn = getattr(self.lib, self.prefix + "primitive_bounds")
+        fn.restype = None
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        out = np.zeros(6, np.float32)
+        fn(h, prim, _fp(out))
+        return out[:3].copy(), out[3:].copy()
+    _OracleBase.primitive_bounds = primitive_bounds
+
+
+_bounds_api()
+
+
 class PortOracle(_OracleBase):
     prefix = "port_"
 

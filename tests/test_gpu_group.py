@@ -57,6 +57,73 @@ def test_group_render_is_progressive_and_never_double_counts(monkeypatch):
     assert grp2[..., 3].max() < 0.5*whole[..., 3].max()        # ... (one pass of weight, not four)
 
 
+@pytest.mark.parametrize("n,tile", [(2, 64), (3, 16)])
+def test_group_normals_mode_is_the_image_not_n_times_it(n, tile, monkeypatch):
+    """eNormals has no weights to divide by (main.cpp:256 shows the buffer as it is): every member writes its own pixels and
+    zero elsewhere, so the group's sum is the reference's image exactly (x + 0 + 0 is x)."""
+    scene, cam, opt, g = _load("features")
+    nopt = opt.copy()
+    nopt.mode = abi.MODE_NORMALS
+    grp = _group(scene, n, tile, monkeypatch)
+    grp.init(opt.width, opt.height)
+    out = grp.render(cam, nopt, passes=1)
+    out2 = grp.render(cam, nopt, passes=1)        # overwrite semantics: a second call changes nothing
+    grp.close()
+    assert np.array_equal(out, g["normals"])
+    assert np.array_equal(out2, g["normals"])
+
+
+@pytest.mark.parametrize("n,mode", [(2, abi.LOOKAHEAD_ON), (3, abi.LOOKAHEAD_PIN_OUTPUT)])
+def test_group_lookahead_changes_no_bit(n, mode, monkeypatch):
+    """tinsel_hip_group_set_lookahead: the reference's call pattern (Render = 1 pass + full read-back) at N members -- every
+    member traces batches of future calls of its shard, the next call's snapshots are reduced while this call's image is
+    copied out.  Every returned image must equal the plain group's bit for bit: through hits, misses (options change
+    mid-stream), a present in between, member introspection (drops the speculation) and an Init."""
+    scene, cam, opt, g = _load("features")
+    plain = _group(scene, n, 32, monkeypatch); plain.init(opt.width, opt.height)
+    ahead = _group(scene, n, 32, monkeypatch); ahead.init(opt.width, opt.height)
+    ahead.set_lookahead(mode)
+    out = np.empty((opt.height, opt.width, 4), np.float32)
+    deeper = opt.copy(); deeper.max_depth = opt.max_depth + 2
+    script = [opt, opt, opt, deeper, deeper, opt, opt, opt, opt]          # hits, a miss, hits, a miss, hits
+    for k, o in enumerate(script):
+        want = plain.render(cam, o, passes=1)
+        got = ahead.render(cam, o, output=out, passes=1)
+        assert np.array_equal(got, want), "call %d" % k
+        if k == 2:
+            assert np.array_equal(ahead.present(o), plain.present(o))       # the committed sum only, speculation intact
+        if k == 6:
+            assert ahead.member_stats(0)["samples"] >= plain.member_stats(0)["samples"]     # (counters may run ahead)
+    for _ in range(3):                                                      # two passes per call
+        want = plain.render(cam, opt, passes=2)
+        got = ahead.render(cam, opt, output=out, passes=2)
+        assert np.array_equal(got, want)
+    # a call without read-back in between, then a new frame
+    plain.render(cam, opt, passes=1, readback=False); ahead.render(cam, opt, passes=1, readback=False)
+    assert np.array_equal(ahead.render(cam, opt, output=out, passes=1), plain.render(cam, opt, passes=1))
+    plain.init(opt.width, opt.height); ahead.init(opt.width, opt.height)
+    assert np.array_equal(ahead.render(cam, opt, output=out, passes=1), plain.render(cam, opt, passes=1))
+    assert np.array_equal(ahead.render(cam, opt, output=out, passes=1), plain.render(cam, opt, passes=1))
+    plain.close(); ahead.close()
+
+
+def test_group_lookahead_through_the_one_rank_rccl_arm(monkeypatch):
+    """The look-ahead reduce itself (ncclReduce of a SNAPSHOT into totalNext from the member's thread, ordered behind the
+    snapshot's event) with one participant: bit-identical to the reference."""
+    from tinsel_amd import HipRendererGroup
+    monkeypatch.delenv("TINSEL_HIP_GROUP_ONE_DEVICE", raising=False)
+    monkeypatch.setenv("TINSEL_HIP_GROUP_FORCE_RCCL", "1")
+    scene, cam, opt, g = _load("cornell")
+    grp = HipRendererGroup(scene, 1)
+    grp.init(opt.width, opt.height)
+    grp.set_lookahead(abi.LOOKAHEAD_ON)
+    out = np.empty((opt.height, opt.width, 4), np.float32)
+    for _ in range(int(g["passes"])):
+        grp.render(cam, opt, output=out, passes=1)
+    grp.close()
+    assert np.array_equal(out, g["accum"])
+
+
 def test_group_of_one_is_one_renderer_bit_for_bit():
     from tinsel_amd import HipRendererGroup
     scene, cam, opt, g = _load("cornell")

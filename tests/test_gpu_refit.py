@@ -1,11 +1,15 @@
 """tinsel_hip_refit_mesh: new vertex positions for a mesh whose topology did not change (deforming / animated meshes;
-the reference re-runs its host SAH build for that, mesh.cpp:314-338).  The tree keeps its shape and every box is recomputed
-bottom-up on the device.
+the reference re-runs its host SAH build for that, mesh.cpp:314-338, and Scene::Build, scene.cpp:4-16).  The trees keep their
+shape and every box is recomputed bottom-up: the mesh's own tree on the device, and at the SCENE level the leaf box of every
+instance (PrimitiveBounds, intersection.h:906-939) and its ancestors in the scene BVH.
 
 Oracle: the SAME displaced mesh inside a scene pack whose reference BVH nodes were refitted here on the host with numpy
 (leaf box = min/max of the triangle's vertices, node box = union of the children's: what Bounds::AddPoint / the builder
-store -- min and max do not round) and whose area CDF follows Mesh::RebuildCDF's serial order, rendered by the C oracle on
-the CPU.  Same tree, same boxes, same triangles => the GPU must be bit-identical to it."""
+store -- min and max do not round), whose area CDF follows Mesh::RebuildCDF's serial order and whose SCENE BVH was refitted
+too (leaf box = the oracle's PrimitiveBounds of the refitted mesh -- pinned to the reference's in tests/test_oracle.py --
+ancestors = union of their children), rendered by the C oracle on the CPU.  Same trees, same boxes, same triangles => the
+GPU must be bit-identical to it.  The displacements leave the original bounds: with stale scene-level boxes the mesh would
+be clipped (asserted: the oracle itself renders another image with the stale boxes)."""
 import ctypes as C
 import os
 import struct
@@ -35,8 +39,36 @@ def _mesh_views(blob, prim_index):
     return pos, idx, nodes, cdf, g + 52
 
 
-def _refit_pack(blob, prim_index, new_pos):
-    """Host refit of the reference's own 32-B nodes + CDF/area, in place."""
+NODE = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("left", "<u4"), ("right", "<u4")])
+
+
+def _refit_scene_level(blob, prim_index):
+    """Scene BVH of the pack, in place: the leaf box of the primitive from the oracle's PrimitiveBounds, ancestors = unions."""
+    num_nodes = struct.unpack_from("<I", blob, 16)[0]
+    off_nodes = struct.unpack_from("<Q", blob, 40)[0]
+    nodes = np.frombuffer(blob, NODE, num_nodes, off_nodes)
+    P = oa.PortOracle()
+    h = P.load_pack(bytes(blob))
+    lo, hi = P.primitive_bounds(h, prim_index)
+    P.free(h)
+    leaf = [k for k in range(num_nodes) if nodes["right"][k] >> 31 and nodes["left"][k] == prim_index]
+    assert len(leaf) == 1
+    nodes["lo"][leaf[0]], nodes["hi"][leaf[0]] = lo, hi
+    order, stack = [], [0]
+    while stack:
+        k = stack.pop()
+        order.append(k)
+        if not nodes["right"][k] >> 31:
+            stack.append(int(nodes["left"][k])); stack.append(int(nodes["right"][k] & 0x7fffffff))
+    for k in reversed(order):
+        if not nodes["right"][k] >> 31:
+            l, r = int(nodes["left"][k]), int(nodes["right"][k] & 0x7fffffff)
+            nodes["lo"][k] = np.minimum(nodes["lo"][l], nodes["lo"][r])
+            nodes["hi"][k] = np.maximum(nodes["hi"][l], nodes["hi"][r])
+
+
+def _refit_pack(blob, prim_index, new_pos, scene_level=True):
+    """Host refit of the reference's own 32-B nodes + CDF/area (+ the scene BVH), in place."""
     pos, idx, nodes, cdf, off_area = _mesh_views(blob, prim_index)
     pos[:] = new_pos
     tri_lo = pos[idx].min(axis=1)
@@ -68,12 +100,14 @@ def _refit_pack(blob, prim_index, new_pos):
         run[t] = total
     cdf[:] = (run/total).astype(np.float32)
     struct.pack_into("<f", blob, off_area, float(total))
+    if scene_level:
+        _refit_scene_level(blob, prim_index)
 
 
 def _displace(pos, amount):
     p = pos.astype(np.float32).copy()
     p[:, 1] += (amount*np.sin(7.0*p[:, 0].astype(np.float64) + 3.0*p[:, 2].astype(np.float64))).astype(np.float32)
-    p[:, 0] *= np.float32(1.0 + 0.5*amount)
+    p[:, 0] *= np.float32(1.0 + 4.0*amount)          # 20 % wider: well outside the original leaf box
     return p
 
 
@@ -99,6 +133,13 @@ def test_refit_after_displacement_matches_the_oracle_on_the_refitted_pack(bvh):
     ref_accum, ref_rad, _ = P.render_seeded(h, cam, opt, 0, passes, want_radiance=True)
     P.free(h)
     assert not np.array_equal(ref_rad, g["radiance"][:passes])      # the displacement is visible
+    # ... and it leaves the original bounds: with the scene BVH as loaded (stale leaf box) the oracle itself clips the mesh
+    stale = bytearray(open(os.path.join(oa.GOLDEN, name + ".pack"), "rb").read())
+    _refit_pack(stale, prim, new_pos, scene_level=False)
+    h = P.load_pack(bytes(stale))
+    _, stale_rad, _ = P.render_seeded(h, cam, opt, 0, passes, want_radiance=True)
+    P.free(h)
+    assert not np.array_equal(stale_rad, ref_rad)
 
     r = tinsel_amd.create_gpu_renderer(scene)
     if bvh == abi.BVH_LBVH:
@@ -135,7 +176,7 @@ def test_refit_of_a_light_mesh_updates_cdf_and_area(monkeypatch):
     prim = _mesh_prim(scene)
     pos = _mesh_views(blob, prim)[0].copy()
     new_pos = pos.copy()
-    new_pos[:, 0] *= np.float32(0.6)                 # a narrower light
+    new_pos[:, 0] *= np.float32(1.6)                 # a wider light (it leaves its old box)
     new_pos[0, 2] += np.float32(0.05)                # and no longer a parallelogram: the two triangles differ in area
     _refit_pack(blob, prim, new_pos)
     P = oa.PortOracle()
@@ -152,13 +193,40 @@ def test_refit_of_a_light_mesh_updates_cdf_and_area(monkeypatch):
     assert np.array_equal(out, ref_accum)
 
 
+def test_refit_of_a_mesh_in_the_lds_arena():
+    """cornell as shipped: the quad light rides in the LDS-staged scene arena (fused kernel, the two-leaf walk).  The refit
+    rewrites its records in the arena's copy in HBM, which every launch stages from."""
+    import tinsel_amd
+    scene, cam, opt, g = _load("cornell")
+    blob = bytearray(open(os.path.join(oa.GOLDEN, "cornell.pack"), "rb").read())
+    prim = _mesh_prim(scene)
+    pos = _mesh_views(blob, prim)[0].copy()
+    new_pos = pos.copy()
+    new_pos[:, 0] *= np.float32(1.7)                 # a wider light: leaves its old box
+    new_pos[0, 2] += np.float32(0.05)
+    _refit_pack(blob, prim, new_pos)
+    P = oa.PortOracle()
+    h = P.load_pack(bytes(blob))
+    ref_accum, ref_rad, _ = P.render_seeded(h, cam, opt, 0, 2, want_radiance=True)
+    P.free(h)
+    r = tinsel_amd.create_gpu_renderer(scene)
+    r.refit_mesh(prim, new_pos)
+    r.init(opt.width, opt.height)
+    out = r.render(cam, opt, passes=2)
+    rad = r.batch_radiance(2, opt.height, opt.width)
+    assert np.array_equal(rad, ref_rad), "%d paths differ" % int((rad != ref_rad).any(axis=-1).sum())
+    assert np.array_equal(out, ref_accum)
+    r.refit_mesh(prim, pos)                          # and back
+    r.init(opt.width, opt.height); r.set_pass_index(0)
+    assert np.array_equal(r.render(cam, opt, passes=int(g["passes"])), g["accum"])
+    r.close()
+
+
 def test_refit_refuses_what_it_cannot_do():
     import tinsel_amd
-    scene, cam, opt, g = _load("cornell")                      # the light mesh rides in the LDS arena here
+    scene, cam, opt, g = _load("cornell")
     r = tinsel_amd.create_gpu_renderer(scene)
     prim = _mesh_prim(scene)
-    with pytest.raises(tinsel_amd.TinselHipError, match="arena"):
-        r.refit_mesh(prim, np.zeros((4, 3), np.float32))
     with pytest.raises(tinsel_amd.TinselHipError):
         r.refit_mesh(0 if prim != 0 else 1, np.zeros((4, 3), np.float32))      # not a mesh
     r.close()

@@ -115,6 +115,7 @@ MODE_NORMALS, MODE_COMPLEXITY, MODE_PATHTRACE = 0, 1, 2
 BVH_REFERENCE, BVH_LBVH = 0, 1
 ARITH_EXACT, ARITH_FAST = 0, 1
 PROBE_CDF, PROBE_ALIAS = 0, 1
+LOOKAHEAD_OFF, LOOKAHEAD_ON, LOOKAHEAD_PIN_OUTPUT = 0, 1, 2
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 GEOM_SPHERE, GEOM_PLANE, GEOM_MESH = 0, 1, 2
 PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT_SPLIT, PIPELINE_AUTO = 0, 1, 2, 3

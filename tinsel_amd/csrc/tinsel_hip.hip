@@ -234,6 +234,31 @@ void make_material(const tinsel_primitive& p, Mat128& m)
     m.lightSamples = p.light_samples;
 }
 
+// the leaf box of a primitive as the flat scan reads it
+PrimBox make_prim_box(const tinsel_bvh_node& nd)
+{
+    PrimBox b;
+    memset(&b, 0, sizeof(b));
+    b.minx = nd.lower.x; b.miny = nd.lower.y; b.minz = nd.lower.z;
+    b.maxx = nd.upper.x; b.maxy = nd.upper.y; b.maxz = nd.upper.z;
+    b.alwaysHit = (nd.lower.x <= -1e7f && nd.lower.y <= -1e7f && nd.lower.z <= -1e7f &&
+                   nd.upper.x >= 1e7f && nd.upper.y >= 1e7f && nd.upper.z >= 1e7f) ? 1u : 0u;
+    return b;
+}
+
+// TransformBounds (maths.h:1004-1021), in the reference's operation order
+void transform_bounds(const Xform& x, V3 lower, V3 upper, V3& outLower, V3& outUpper)
+{
+    const V3 c0 = qrotate(x.r, V3(1.0f, 0.0f, 0.0f)), c1 = qrotate(x.r, V3(0.0f, 1.0f, 0.0f)), c2 = qrotate(x.r, V3(0.0f, 0.0f, 1.0f));    // Mat33(Quat), maths.h:654-663
+    const V3 halfEdgeWidth = (x.s*(upper - lower))*0.5f;
+    const V3 ax = V3(absf(c0.x), absf(c0.y), absf(c0.z))*halfEdgeWidth.x;
+    const V3 ay = V3(absf(c1.x), absf(c1.y), absf(c1.z))*halfEdgeWidth.y;
+    const V3 az = V3(absf(c2.x), absf(c2.y), absf(c2.z))*halfEdgeWidth.z;
+    const V3 center = xform_point(x, 0.5f*(lower + upper));
+    outLower = center - ax - ay - az;
+    outUpper = center + ax + ay + az;
+}
+
 Xform to_xform(const tinsel_transform& t)
 {
     Xform x;
@@ -317,6 +342,12 @@ struct tinsel_hip
     std::vector<std::vector<int32_t>> meshIndices;
     std::vector<int> primMesh;
     std::vector<float> primEndScale;
+    // ... and to follow a refitted mesh at the SCENE level (its primitives' leaf boxes and their ancestors in the scene BVH):
+    // the primitives' start / end transforms, the reference's scene BVH as handed in, where its device form and the leaf boxes
+    // sit in the arena
+    std::vector<Xform> primStart, primEnd;
+    std::vector<tinsel_bvh_node> sceneBvhHost;
+    size_t arenaOffNodes = 0, arenaOffBoxes = 0;
     int sceneStackNeed = 1;
     int bvhMode = TINSEL_BVH_REFERENCE;
     int rrStart = 0;                    // > 0: Russian roulette from this bounce on (opt-in)
@@ -382,7 +413,7 @@ struct tinsel_hip
 
     // look-ahead (tinsel_hip_set_lookahead): the NEXT call's passes are traced speculatively into accumSpec while this
     // call's running sum travels to the host
-    bool lookahead = false;
+    int lookahead = 0;                  // 0 off, 1 on, 2 on + the caller's output array page-locked in place (TINSEL_LOOKAHEAD_PIN_OUTPUT)
     FrameParams lastFp;                 // of the most recent batch (its paths' radiance is still in ps.rad)
     struct SpecShot { float4* buf; hipEvent_t ready; };
     std::vector<float4*> specFree;      // accumulator-sized buffers not in use
@@ -1195,28 +1226,54 @@ int lookahead_extend(tinsel_hip* r, const tinsel_camera* camera, const tinsel_op
     return 0;
 }
 
-int lookahead_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, float* out_rgba, int passes)
+// calls per speculated batch: half a batch per speculation (two are in flight), at most 16 calls -- 4 at 1024^2, 16 for the
+// small interactive frames; 0: one call's passes do not fit a batch
+int lookahead_depth(const tinsel_hip* r, int passes)
+{
+    const size_t perPass = slots_per_pass(r, r->width, r->height);
+    if (batch_slots(r) < perPass*(size_t)passes)
+        return 0;
+    const int fit = (int)std::max<size_t>(1, batch_slots(r)/(perPass*(size_t)passes));
+    return r->lookaheadDepth > 0 ? std::max(1, std::min(r->lookaheadDepth, fit)) : std::max(1, std::min(16, fit/2));
+}
+
+int lookahead_streams(tinsel_hip* r)
 {
     HIP_TRY(hipSetDevice(r->device));
-    const size_t bytes = sizeof(float4)*(size_t)r->width*r->height;
     if (!r->workStream)
     {
         HIP_TRY(hipStreamCreateWithFlags(&r->workStream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&r->copyStream, hipStreamNonBlocking));
     }
+    return 0;
+}
+
+// the front of the speculation queue becomes the running sum (the caller has checked that it is this call's)
+int lookahead_commit(tinsel_hip* r, int passes)
+{
+    tinsel_hip::SpecShot shot = r->specQueue.front();
+    r->specQueue.pop_front();
+    HIP_TRY(hipEventSynchronize(shot.ready));
+    r->eventPool.push_back(shot.ready);
+    r->specFree.push_back(r->accum);        // the previous running sum: copied out by the previous call, copied from by this shot
+    r->accum = shot.buf;
+    r->passIndex += (uint32_t)passes;
+    return 0;
+}
+
+int lookahead_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options* options, float* out_rgba, int passes)
+{
+    if (lookahead_streams(r))
+        return -1;
+    const size_t bytes = sizeof(float4)*(size_t)r->width*r->height;
 
     // 1. this call's passes: already traced (the front of the speculation queue) or traced now
     const bool hit = !r->specQueue.empty() && passes == r->specPasses && memcmp(camera, &r->specCamera, sizeof(*camera)) == 0 &&
                      memcmp(options, &r->specOptions, sizeof(*options)) == 0;
     if (hit)
     {
-        tinsel_hip::SpecShot shot = r->specQueue.front();
-        r->specQueue.pop_front();
-        HIP_TRY(hipEventSynchronize(shot.ready));
-        r->eventPool.push_back(shot.ready);
-        r->specFree.push_back(r->accum);        // the previous running sum: copied out by the previous call, copied from by this shot
-        r->accum = shot.buf;
-        r->passIndex += (uint32_t)passes;
+        if (lookahead_commit(r, passes))
+            return -1;
     }
     else
     {
@@ -1227,13 +1284,23 @@ int lookahead_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_op
         r->specNextPass = r->passIndex;
     }
 
-    // 2. the running sum starts towards the host (page-locked in place once: the caller hands the same array every call)
-    if (r->pinnedPtr != (void*)out_rgba || r->pinnedBytes != bytes)
+    // 2. / 3. the running sum travels to the host while the speculation queue is kept between `depth` and 2 x depth calls deep
+    //    (a batch of `depth` calls is traced while the previous batch's running sums are copied out one call at a time).
+    //    The caller's array is NOT page-locked by default: the reference's caller frees and re-allocates it on every reshape
+    //    (main.cpp:73-87: delete[] g_pixels, then Renderer::Init), and a registration must not outlive the memory it names.
+    //    A copy to pageable memory blocks this thread while it runs, so the next batch is launched FIRST (it is needed `depth`
+    //    calls from now; the launches cost the copy ~0.1 ms of delay every `depth` calls).  TINSEL_LOOKAHEAD_PIN_OUTPUT (the
+    //    caller guarantees the array outlives the renderer or the next Init): registered in place, the copy is asynchronous
+    //    and starts first.
+    const bool pin = r->lookahead == TINSEL_LOOKAHEAD_PIN_OUTPUT;
+    if (r->pinnedPtr && (!pin || r->pinnedPtr != (void*)out_rgba || r->pinnedBytes != bytes))
     {
-        if (r->pinnedPtr)
-            (void)hipHostUnregister(r->pinnedPtr);
+        (void)hipHostUnregister(r->pinnedPtr);
         r->pinnedPtr = nullptr;
         r->pinnedBytes = 0;
+    }
+    if (pin && !r->pinnedPtr)
+    {
         if (hipHostRegister(out_rgba, bytes, hipHostRegisterDefault) == hipSuccess)
         {
             r->pinnedPtr = out_rgba;
@@ -1242,17 +1309,14 @@ int lookahead_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_op
         else
             (void)hipGetLastError();        // pageable copy below: still correct
     }
-    HIP_TRY(hipMemcpyAsync(out_rgba, r->accum, bytes, hipMemcpyDeviceToHost, r->copyStream));
+    const bool asyncCopy = r->pinnedPtr != nullptr;
+    if (asyncCopy)
+        HIP_TRY(hipMemcpyAsync(out_rgba, r->accum, bytes, hipMemcpyDeviceToHost, r->copyStream));
 
-    // 3. meanwhile keep the speculation queue between `depth` and 2 x depth calls deep: a batch of `depth` calls is traced
-    //    while the previous batch's running sums are being copied out one call at a time
     if (options->mode == TINSEL_MODE_PATHTRACE && options->max_depth >= 1)
     {
-        const size_t perPass = slots_per_pass(r, r->width, r->height);
-        const int fit = (int)std::max<size_t>(1, batch_slots(r)/(perPass*(size_t)passes));
-        // half a batch per speculation (two are in flight), at most 16 calls: 4 at 1024^2, 16 for the small interactive frames
-        const int depth = r->lookaheadDepth > 0 ? std::max(1, std::min(r->lookaheadDepth, fit)) : std::max(1, std::min(16, fit/2));
-        if ((int)r->specQueue.size() <= depth && batch_slots(r) >= perPass*(size_t)passes)
+        const int depth = lookahead_depth(r, passes);
+        if (depth > 0 && (int)r->specQueue.size() <= depth)
         {
             r->specCamera = *camera;
             r->specOptions = *options;
@@ -1262,6 +1326,8 @@ int lookahead_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_op
         }
     }
 
+    if (!asyncCopy)
+        HIP_TRY(hipMemcpyAsync(out_rgba, r->accum, bytes, hipMemcpyDeviceToHost, r->copyStream));
     HIP_TRY(hipStreamSynchronize(r->copyStream));
     return 0;
 }
@@ -1460,6 +1526,8 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
 
         const bool isStatic = memcmp(&p.start_transform, &p.end_transform, sizeof(tinsel_transform)) == 0;
         const Xform xs = to_xform(p.start_transform), xe = to_xform(p.end_transform);
+        r->primStart.push_back(xs);
+        r->primEnd.push_back(xe);
         if (isStatic)
         {
             // InterpolateTransform(a, a, t) is t-independent: evaluate it once, with the same function
@@ -1615,12 +1683,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             const tinsel_bvh_node& nd = desc->bvh_nodes[k];
             if (!ref_is_leaf(nd) || nd.left_index >= (uint32_t)P)
                 continue;
-            PrimBox& b = boxes[nd.left_index];
-            memset(&b, 0, sizeof(b));
-            b.minx = nd.lower.x; b.miny = nd.lower.y; b.minz = nd.lower.z;
-            b.maxx = nd.upper.x; b.maxy = nd.upper.y; b.maxz = nd.upper.z;
-            b.alwaysHit = (nd.lower.x <= -1e7f && nd.lower.y <= -1e7f && nd.lower.z <= -1e7f &&
-                           nd.upper.x >= 1e7f && nd.upper.y >= 1e7f && nd.upper.z >= 1e7f) ? 1u : 0u;
+            boxes[nd.left_index] = make_prim_box(nd);
             seen[nd.left_index] = 1;
         }
         bool everyPrimHasALeaf = true;
@@ -1705,6 +1768,9 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             sc.numMeshes = (int)meshes.size();
             r->sceneStackNeed = sceneBvh.maxLeafDepth + 1;
             sc.primBoxes = reinterpret_cast<const PrimBox*>(arenaDev + offBoxes);
+            r->sceneBvhHost.assign(desc->bvh_nodes, desc->bvh_nodes + desc->num_bvh_nodes);
+            r->arenaOffNodes = offNodes;
+            r->arenaOffBoxes = offBoxes;
             sc.hasMedia = 0;
             for (const Mat128& mm : mats)
                 if (mm.absorption[0] != 0.0f || mm.absorption[1] != 0.0f || mm.absorption[2] != 0.0f)
@@ -1892,7 +1958,16 @@ int tinsel_hip_set_lookahead(tinsel_hip* r, int enable)
         return fail("set_lookahead: null");
     if (!enable)
         lookahead_cancel(r);
-    r->lookahead = enable != 0;
+    if (enable != TINSEL_LOOKAHEAD_PIN_OUTPUT && r->pinnedPtr)
+    {
+        (void)hipSetDevice(r->device);
+        if (r->copyStream)
+            (void)hipStreamSynchronize(r->copyStream);
+        (void)hipHostUnregister(r->pinnedPtr);
+        r->pinnedPtr = nullptr;
+        r->pinnedBytes = 0;
+    }
+    r->lookahead = enable == TINSEL_LOOKAHEAD_PIN_OUTPUT ? TINSEL_LOOKAHEAD_PIN_OUTPUT : (enable ? TINSEL_LOOKAHEAD_ON : TINSEL_LOOKAHEAD_OFF);
     if (const char* e = getenv("TINSEL_HIP_LOOKAHEAD_DEPTH"))
         r->lookaheadDepth = std::max(0, atoi(e));
     return 0;
@@ -2083,8 +2158,7 @@ int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_x
         return fail("refit_mesh: bad arguments (a mesh primitive and its new positions)");
     const int mi = r->primMesh[(size_t)primitive];
     DevMesh& dm = r->meshesNow[(size_t)mi];
-    if (dm.inArena)
-        return fail("refit_mesh: this mesh is small enough to live in the LDS-staged scene arena; create a new renderer for it");
+    // (a mesh of the LDS-staged arena is refitted in the arena's copy in HBM, which every launch stages from)
     if (num_vertices != r->meshNumVertices[(size_t)mi])
         return fail("refit_mesh: the topology must not change (vertex count differs)");
     HIP_TRY(hipSetDevice(r->device));
@@ -2158,6 +2232,72 @@ int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_x
             const float area = totalArea*r->primEndScale[(size_t)p];          // intersection.h:843-847
             HIP_TRY(hipMemcpy((void*)&r->scene.mats[p].area, &area, sizeof(float), hipMemcpyHostToDevice));
         }
+
+    // The scene level follows: Scene::Build (scene.cpp:4-16) gives the scene BVH builder PrimitiveBounds(p) (intersection.h:906-939)
+    // = the mesh root's box under the start and end transforms.  The tree keeps its shape here too: the leaf box of every
+    // instance is recomputed with the reference's expressions and its ancestors become the union of their children (what the
+    // builder stores for that shape: min and max do not round).  Without this a deformation that leaves the old box is
+    // clipped: the flat scan, the queue sort and k_walk's `enters` test all start from the leaf box.
+    V3 lo(kFltMax, kFltMax, kFltMax), hi(-kFltMax, -kFltMax, -kFltMax);     // the root's box: the union of the triangles' (Bounds::AddPoint)
+    for (size_t k = 0; k < (size_t)numTris*3; ++k)
+    {
+        const float* v = positions_xyz + (size_t)idx[k]*3;
+        lo = V3(minT(lo.x, v[0]), minT(lo.y, v[1]), minT(lo.z, v[2]));
+        hi = V3(maxT(hi.x, v[0]), maxT(hi.y, v[1]), maxT(hi.z, v[2]));
+    }
+    std::vector<tinsel_bvh_node>& sb = r->sceneBvhHost;
+    std::vector<int> leafOf((size_t)r->scene.numPrims, -1);
+    for (size_t k = 0; k < sb.size(); ++k)
+        if (ref_is_leaf(sb[k]) && sb[k].left_index < (uint32_t)r->scene.numPrims)
+            leafOf[sb[k].left_index] = (int)k;
+    std::vector<PrimBox> newBoxes;
+    std::vector<int> newBoxPrim;
+    for (int p = 0; p < r->scene.numPrims; ++p)
+    {
+        if (r->primMesh[(size_t)p] != mi || leafOf[(size_t)p] < 0)
+            continue;
+        V3 sl, su, el, eu;
+        transform_bounds(r->primStart[(size_t)p], lo, hi, sl, su);
+        transform_bounds(r->primEnd[(size_t)p], lo, hi, el, eu);
+        tinsel_bvh_node& leaf = sb[(size_t)leafOf[(size_t)p]];
+        leaf.lower.x = minT(sl.x, el.x); leaf.lower.y = minT(sl.y, el.y); leaf.lower.z = minT(sl.z, el.z);      // Union, maths.h:1023-1026
+        leaf.upper.x = maxT(su.x, eu.x); leaf.upper.y = maxT(su.y, eu.y); leaf.upper.z = maxT(su.z, eu.z);
+        newBoxes.push_back(make_prim_box(leaf));
+        newBoxPrim.push_back(p);
+    }
+    {
+        // ancestors: post-order over the reference's tree (validated acyclic by convert_bvh at create)
+        std::vector<uint32_t> order, stack(1, 0u);
+        while (!stack.empty())
+        {
+            const uint32_t k = stack.back();
+            stack.pop_back();
+            order.push_back(k);
+            if (!ref_is_leaf(sb[k]))
+            {
+                stack.push_back(sb[k].left_index);
+                stack.push_back(ref_right(sb[k]));
+            }
+        }
+        for (size_t q = order.size(); q-- > 0; )
+        {
+            tinsel_bvh_node& n = sb[order[q]];
+            if (ref_is_leaf(n))
+                continue;
+            const tinsel_bvh_node& a = sb[n.left_index];
+            const tinsel_bvh_node& b = sb[ref_right(n)];
+            n.lower.x = minT(a.lower.x, b.lower.x); n.lower.y = minT(a.lower.y, b.lower.y); n.lower.z = minT(a.lower.z, b.lower.z);
+            n.upper.x = maxT(a.upper.x, b.upper.x); n.upper.y = maxT(a.upper.y, b.upper.y); n.upper.z = maxT(a.upper.z, b.upper.z);
+        }
+    }
+    ConvertedBvh sceneBvh;
+    if (!convert_bvh(sb.data(), (int)sb.size(), r->scene.numPrims, 0, sceneBvh))
+        return fail("refit_mesh: the scene BVH could not be refitted");
+    unsigned char* arenaDev = const_cast<unsigned char*>(r->scene.arena);
+    if (!sceneBvh.nodes.empty())
+        HIP_TRY(hipMemcpy(arenaDev + r->arenaOffNodes, sceneBvh.nodes.data(), sizeof(Node64)*sceneBvh.nodes.size(), hipMemcpyHostToDevice));
+    for (size_t k = 0; k < newBoxes.size(); ++k)
+        HIP_TRY(hipMemcpy(arenaDev + r->arenaOffBoxes + sizeof(PrimBox)*(size_t)newBoxPrim[k], &newBoxes[k], sizeof(PrimBox), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -2650,7 +2790,7 @@ __global__ void k_sum_accums(SumSources s, float4* __restrict__ total, size_t co
     total[i] = a;
 }
 
-enum { GJ_NONE = 0, GJ_INIT, GJ_RENDER, GJ_REDUCE, GJ_QUIT };
+enum { GJ_NONE = 0, GJ_INIT, GJ_RENDER, GJ_REDUCE, GJ_AHEAD, GJ_QUIT };
 
 struct GroupMember
 {
@@ -2672,6 +2812,21 @@ struct tinsel_hip_group
     bool solo = true;               // one member used directly: no threads, no reduce, total aliases its accumulator
     int width = 0, height = 0;
     float4* total = nullptr;        // on member 0's device; == member 0's accumulator when there is one member
+
+    // Look-ahead for the reference's call pattern at N members (tinsel_hip_group_set_lookahead): after a read-back every
+    // member keeps a queue of speculated calls (lookahead_extend: one batch of `depth` calls of ITS shard, one snapshot per
+    // call) and the NEXT call's snapshots are reduced into `totalNext` while this call's `total` crosses PCIe.  A matching
+    // call then only waits for that job, swaps the buffers and copies.
+    int lookahead = TINSEL_LOOKAHEAD_OFF;
+    float4* totalNext = nullptr;
+    bool aheadInFlight = false;     // a GJ_AHEAD job has been posted and not yet waited for
+    bool aheadValid = false;        // every member holds a snapshot of the call described below (and totalNext its reduced sum)
+    tinsel_camera aheadCamera;
+    tinsel_options aheadOptions;
+    int aheadPasses = 0;
+    hipStream_t copyStream = nullptr;   // on member 0's device
+    void* pinnedPtr = nullptr;
+    size_t pinnedBytes = 0;
 
     // job hand-off: the caller posts (job, epoch), every worker runs it for its member and reports
     std::mutex mu;
@@ -2721,6 +2876,39 @@ void group_worker(tinsel_hip_group* g, int rank)
             else if (hipStreamSynchronize(m.stream) != hipSuccess)
                 rc = fail("group: the reduce failed on the device");
         }
+        else if (job == GJ_AHEAD)
+        {
+            // the NEXT call, speculated: keep this member's queue of traced calls deep enough, then reduce the snapshot
+            // the next call will swap in (the members' queues advance in lockstep: the same calls, the same depth rule)
+            tinsel_hip* r = m.r;
+            rc = lookahead_streams(r);
+            const int depth = rc ? 0 : lookahead_depth(r, g->aheadPasses);
+            if (!rc && depth <= 0)
+                rc = fail("group: one call does not fit a batch");
+            if (!rc && (int)r->specQueue.size() <= depth)
+            {
+                if (r->specQueue.empty())
+                    r->specNextPass = r->passIndex;
+                r->specCamera = g->aheadCamera;
+                r->specOptions = g->aheadOptions;
+                r->specPasses = g->aheadPasses;
+                rc = lookahead_extend(r, &g->aheadCamera, &g->aheadOptions, g->aheadPasses, depth);
+            }
+            if (!rc && !g->oneDevice)
+            {
+                const tinsel_hip::SpecShot& shot = r->specQueue.front();
+                if (hipStreamWaitEvent(m.stream, shot.ready, 0) != hipSuccess)
+                    rc = fail("group: look-ahead wait failed");
+                else
+                {
+                    const ncclResult_t e = g_rccl.Reduce(shot.buf, g->totalNext, (size_t)g->width*g->height*4, ncclFloat, ncclSum, 0, m.comm, m.stream);
+                    if (e != ncclSuccess)
+                        rc = fail(std::string("group: ncclReduce: ") + g_rccl.GetErrorString(e));
+                    else if (hipStreamSynchronize(m.stream) != hipSuccess)
+                        rc = fail("group: the look-ahead reduce failed on the device");
+                }
+            }
+        }
         m.rc = rc;
         m.error = rc ? g_error : std::string();
         {
@@ -2733,8 +2921,8 @@ void group_worker(tinsel_hip_group* g, int rank)
     }
 }
 
-// posts `job` to every member's thread and waits for all of them; 0 when every member succeeded
-int group_run(tinsel_hip_group* g, int job)
+// posts `job` to every member's thread
+void group_post(tinsel_hip_group* g, int job)
 {
     {
         std::lock_guard<std::mutex> lk(g->mu);
@@ -2743,6 +2931,11 @@ int group_run(tinsel_hip_group* g, int job)
         ++g->epoch;
     }
     g->cvWork.notify_all();
+}
+
+// waits for the posted job; 0 when every member succeeded
+int group_wait(tinsel_hip_group* g)
+{
     {
         std::unique_lock<std::mutex> lk(g->mu);
         g->cvDone.wait(lk, [&] { return g->pending == 0; });
@@ -2753,7 +2946,46 @@ int group_run(tinsel_hip_group* g, int job)
     return 0;
 }
 
-// total = sum of the members' accumulators, on member 0's device
+int group_run(tinsel_hip_group* g, int job)
+{
+    group_post(g, job);
+    return group_wait(g);
+}
+
+// Look-ahead bookkeeping.  group_ahead_join: the job in flight (if any) has ended; the workers are idle afterwards and the
+// caller's thread may touch the members.  group_ahead_drop: ... and nothing speculated survives (Init, another camera,
+// look-ahead switched off).
+void group_ahead_join(tinsel_hip_group* g)
+{
+    if (!g->aheadInFlight)
+        return;
+    g->aheadInFlight = false;
+    if (group_wait(g))
+        g->aheadValid = false;      // a member could not speculate: the plain path still works
+}
+
+void group_ahead_drop(tinsel_hip_group* g)
+{
+    group_ahead_join(g);
+    g->aheadValid = false;
+    if (!g->solo)
+        for (GroupMember& m : g->members)
+            lookahead_cancel(m.r);
+}
+
+void group_unpin(tinsel_hip_group* g)
+{
+    if (!g->pinnedPtr)
+        return;
+    (void)hipSetDevice(g->members[0].device);
+    if (g->copyStream)
+        (void)hipStreamSynchronize(g->copyStream);
+    (void)hipHostUnregister(g->pinnedPtr);
+    g->pinnedPtr = nullptr;
+    g->pinnedBytes = 0;
+}
+
+// total = sum of the members' accumulators, on member 0's device (the workers must be idle: group_ahead_join)
 int group_reduce(tinsel_hip_group* g)
 {
     const size_t n = g->members.size();
@@ -2781,6 +3013,9 @@ void tinsel_hip_group_destroy(tinsel_hip_group* g)
 {
     if (!g)
         return;
+    group_ahead_join(g);
+    if (!g->members.empty() && g->members[0].r)
+        group_unpin(g);
     bool threads = false;
     for (GroupMember& m : g->members)
         threads = threads || m.thread.joinable();
@@ -2799,10 +3034,12 @@ void tinsel_hip_group_destroy(tinsel_hip_group* g)
         if (m.stream)
             (void)hipStreamDestroy(m.stream);
     }
-    if (g->total && !g->solo)
+    if (!g->solo && !g->members.empty())
     {
         (void)hipSetDevice(g->members[0].device);
-        (void)hipFree(g->total);
+        if (g->total) (void)hipFree(g->total);
+        if (g->totalNext) (void)hipFree(g->totalNext);
+        if (g->copyStream) (void)hipStreamDestroy(g->copyStream);
     }
     for (GroupMember& m : g->members)
         tinsel_hip_destroy(m.r);
@@ -2886,6 +3123,8 @@ int tinsel_hip_group_init(tinsel_hip_group* g, int width, int height)
 {
     if (!g || width <= 0 || height <= 0)
         return fail("group_init: bad arguments");
+    group_ahead_drop(g);
+    group_unpin(g);                 // the reference's caller has freed its array by now (main.cpp:73-87)
     g->width = width;
     g->height = height;
     if (g->solo)
@@ -2900,9 +3139,28 @@ int tinsel_hip_group_init(tinsel_hip_group* g, int width, int height)
     HIP_TRY(hipSetDevice(g->members[0].device));
     if (g->total)
         (void)hipFree(g->total);
-    g->total = nullptr;
+    if (g->totalNext)
+        (void)hipFree(g->totalNext);
+    g->total = g->totalNext = nullptr;
     HIP_TRY(hipMalloc((void**)&g->total, sizeof(float4)*(size_t)width*height));
+    HIP_TRY(hipMalloc((void**)&g->totalNext, sizeof(float4)*(size_t)width*height));
     HIP_TRY(hipMemset(g->total, 0, sizeof(float4)*(size_t)width*height));
+    if (!g->copyStream)
+        HIP_TRY(hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking));
+    return 0;
+}
+
+int tinsel_hip_group_set_lookahead(tinsel_hip_group* g, int enable)
+{
+    if (!g)
+        return fail("group_set_lookahead: null");
+    if (g->solo)
+        return tinsel_hip_set_lookahead(g->members[0].r, enable);
+    if (!enable)
+        group_ahead_drop(g);
+    if (enable != TINSEL_LOOKAHEAD_PIN_OUTPUT)
+        group_unpin(g);
+    g->lookahead = enable == TINSEL_LOOKAHEAD_PIN_OUTPUT ? TINSEL_LOOKAHEAD_PIN_OUTPUT : (enable ? TINSEL_LOOKAHEAD_ON : TINSEL_LOOKAHEAD_OFF);
     return 0;
 }
 
@@ -2914,17 +3172,89 @@ int tinsel_hip_group_render(tinsel_hip_group* g, const tinsel_camera* camera, co
         return fail("group_render: Init first");
     if (g->solo)
         return tinsel_hip_render(g->members[0].r, camera, options, out_rgba, passes);
-    g->camera = *camera;
-    g->options = *options;
-    g->passes = passes;
-    if (group_run(g, GJ_RENDER))
-        return -1;
-    if (!out_rgba)
-        return 0;
-    if (group_reduce(g))
-        return -1;
+    const size_t bytes = sizeof(float4)*(size_t)g->width*g->height;
+
+    // 1. this call's passes: speculated by the previous call (every member holds their snapshot, totalNext their reduced sum)
+    //    or traced and reduced now
+    const bool wanted = g->lookahead && out_rgba && passes >= 1 && options->width == g->width && options->height == g->height &&
+                        options->mode == TINSEL_MODE_PATHTRACE && options->max_depth >= 1;
+    group_ahead_join(g);
+    bool hit = wanted && g->aheadValid && passes == g->aheadPasses && memcmp(camera, &g->aheadCamera, sizeof(*camera)) == 0 &&
+               memcmp(options, &g->aheadOptions, sizeof(*options)) == 0;
+    for (const GroupMember& m : g->members)
+        hit = hit && !m.r->specQueue.empty() && m.r->specPasses == passes;
+    if (hit)
+    {
+        for (GroupMember& m : g->members)
+        {
+            HIP_TRY(hipSetDevice(m.device));
+            if (lookahead_commit(m.r, passes))
+                return -1;
+        }
+        if (g->oneDevice)
+        {
+            if (group_reduce(g))        // validation arm: the device-local sum of the snapshots just swapped in
+                return -1;
+        }
+        else
+            std::swap(g->total, g->totalNext);
+    }
+    else
+    {
+        group_ahead_drop(g);
+        g->camera = *camera;
+        g->options = *options;
+        g->passes = passes;
+        if (group_run(g, GJ_RENDER))
+            return -1;
+        if (!out_rgba)
+            return 0;
+        if (group_reduce(g))
+            return -1;
+    }
     HIP_TRY(hipSetDevice(g->members[0].device));
-    HIP_TRY(hipMemcpy(out_rgba, g->total, sizeof(float4)*(size_t)g->width*g->height, hipMemcpyDeviceToHost));
+    if (!wanted)
+    {
+        HIP_TRY(hipMemcpy(out_rgba, g->total, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+
+    // 2. the sum starts towards the host and the members go on with the next call meanwhile: its passes traced (a batch of
+    //    `depth` calls at a time), its snapshots reduced into totalNext -- per call the caller waits for one reduce (already
+    //    done, as a rule) and one copy.  Page-locking the caller's array is an explicit opt-in, as for one device.
+    const bool pin = g->lookahead == TINSEL_LOOKAHEAD_PIN_OUTPUT;
+    if (g->pinnedPtr && (!pin || g->pinnedPtr != (void*)out_rgba || g->pinnedBytes != bytes))
+        group_unpin(g);
+    if (pin && !g->pinnedPtr)
+    {
+        if (hipHostRegister(out_rgba, bytes, hipHostRegisterDefault) == hipSuccess)
+        {
+            g->pinnedPtr = out_rgba;
+            g->pinnedBytes = bytes;
+        }
+        else
+            (void)hipGetLastError();
+    }
+    auto post_ahead = [&] {
+        g->aheadCamera = *camera;
+        g->aheadOptions = *options;
+        g->aheadPasses = passes;
+        g->aheadValid = true;           // unless the job fails (group_ahead_join)
+        g->aheadInFlight = true;
+        group_post(g, GJ_AHEAD);
+    };
+    if (g->pinnedPtr)
+    {
+        HIP_TRY(hipMemcpyAsync(out_rgba, g->total, bytes, hipMemcpyDeviceToHost, g->copyStream));
+        post_ahead();
+        HIP_TRY(hipStreamSynchronize(g->copyStream));
+    }
+    else
+    {
+        post_ahead();                   // a copy to pageable memory blocks this thread: the workers start first
+        HIP_TRY(hipSetDevice(g->members[0].device));
+        HIP_TRY(hipMemcpy(out_rgba, g->total, bytes, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 
@@ -2935,6 +3265,7 @@ int tinsel_hip_group_present(tinsel_hip_group* g, const tinsel_options* options,
     tinsel_hip* r0 = g->members[0].r;
     if (g->solo)
         return tinsel_hip_present(r0, options, nlm_width, nlm_falloff, out_rgba);
+    group_ahead_join(g);                // (what was speculated stays: the members' committed sums are not touched by it)
     if (group_reduce(g))
         return -1;
     // the display stage of member 0 on the reduced frame
@@ -2951,7 +3282,10 @@ int tinsel_hip_group_size(tinsel_hip_group* g) { return g ? (int)g->members.size
 
 tinsel_hip* tinsel_hip_group_member(tinsel_hip_group* g, int rank)
 {
-    return (g && rank >= 0 && rank < (int)g->members.size()) ? g->members[(size_t)rank].r : nullptr;
+    if (!g || rank < 0 || rank >= (int)g->members.size())
+        return nullptr;
+    group_ahead_drop(g);        // the caller may do anything to the member: nothing speculated may be in flight or survive
+    return g->members[(size_t)rank].r;
 }
 
 } // extern "C"

@@ -1521,7 +1521,9 @@ __global__ void k_pass_seeds(uint32_t s1, uint32_t s2, int n, uint32_t* __restri
 }
 
 // ---------------------------------------------------------------------------
-// k_normals: eNormals mode of the CPU renderer (render.cpp:494-515): x=i, y=j, time 1, overwrite.
+// k_normals: eNormals mode of the CPU renderer (render.cpp:494-515): x=i, y=j, time 1, overwrite.  The mode has no weights
+// to divide by (main.cpp:256 shows the buffer as it is), so a shard writes ZERO at the pixels it does not own: the sum over
+// the ranks of a group (one reduce, like the path-traced sum) is then the image, not N times it.
 
 template <bool LDS>
 __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_normals(DevScene scIn, CameraParams cam, FrameParams fp, float4* __restrict__ accum, int stackEntries)
@@ -1537,6 +1539,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_TRACE) void k_normals(DevScene scI
         return;
     const int j = pix/fp.width;
     const int i = pix - j*fp.width;
+    if (!pixel_owned(fp, i, j))
+    {
+        accum[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
 
     V3 o, d;
     generate_ray(cam, float(i), float(j), o, d);

@@ -104,6 +104,7 @@ def load_library():
     L.tinsel_hip_group_size.argtypes = [vp]
     L.tinsel_hip_group_member.restype = vp
     L.tinsel_hip_group_member.argtypes = [vp, ci]
+    L.tinsel_hip_group_set_lookahead.argtypes = [vp, ci]
     L.tinsel_hip_last_error.restype = C.c_char_p
     L.tinsel_pack_open.argtypes = [vp, C.c_size_t, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.Options)]
     _lib = L
@@ -120,7 +121,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_russian_roulette", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
     "tinsel_hip_walked_prims", "tinsel_hip_queue_counts", "tinsel_hip_set_lookahead", "tinsel_hip_set_arithmetic", "tinsel_hip_get_arithmetic", "tinsel_hip_refit_mesh", "tinsel_hip_set_probe_sampling",
     "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
-    "tinsel_hip_group_size", "tinsel_hip_group_member",
+    "tinsel_hip_group_size", "tinsel_hip_group_member", "tinsel_hip_group_set_lookahead",
 ]
 
 
@@ -258,7 +259,8 @@ class HipRenderer:
         _check(self._L.tinsel_hip_set_probe_sampling(self._h, int(mode)), "tinsel_hip_set_probe_sampling")
 
     def set_lookahead(self, on):
-        """Trace the next call's passes while this call's image is copied out (tinsel_hip_set_lookahead); images unchanged."""
+        """Trace the next call's passes while this call's image is copied out (tinsel_hip_set_lookahead); images unchanged.
+        abi.LOOKAHEAD_PIN_OUTPUT also page-locks the output array in place (it must then outlive the renderer / the next init)."""
         _check(self._L.tinsel_hip_set_lookahead(self._h, int(on)), "tinsel_hip_set_lookahead")
 
     def set_russian_roulette(self, start_bounce):
@@ -387,6 +389,11 @@ class HipRendererGroup:
 
     Init = init
     Render = render
+
+    def set_lookahead(self, mode):
+        """Trace and reduce the next calls while this call's image is copied out (tinsel_hip_group_set_lookahead); images unchanged.
+        mode: abi.LOOKAHEAD_OFF / ON / PIN_OUTPUT (or a bool)."""
+        _check(self._L.tinsel_hip_group_set_lookahead(self._h, int(mode)), "tinsel_hip_group_set_lookahead")
 
     def present(self, options, nlm_width=0, nlm_falloff=200.0):
         out = np.empty((self.height, self.width, 4), np.float32)
