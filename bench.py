@@ -2,7 +2,7 @@
 """bench.py -- Msamples/s and Mrays/s of the hot path on N MI355X (one process per GPU).
 
 A "step" is one pass of the hot path over one batch of synthetic input: one sample per pixel.  The default run (N = 1)
-times TWO configurations of BASELINE.json and prints ONE JSON line:
+times the FOUR GPU configurations of BASELINE.json and prints ONE JSON line (`configs`: the headline first):
 
   configs[0] / headline   BASELINE configs[1]: data/cornell.tin 1024x1024 maxDepth 4 (spp 256 <=> --steps 256).  The
                           scene (2.6 KB) lives in LDS: the path is bound by VALU issue, and `roofline` says so
@@ -10,7 +10,10 @@ times TWO configurations of BASELINE.json and prints ONE JSON line:
   configs[1]              BASELINE configs[2]: data/ajax.tin with the 524,288-triangle stand-in mesh (ajax.obj is not in
                           the reference tree) at 1920x1080 maxDepth 4 -- the configuration whose scene lives in HBM / the
                           Infinity Cache.  Its roofline carries BOTH HBM fractions: algorithmic bytes (SURVEY.md 8d's
-                          B_ray model) and counter bytes, each divided by time and by 8 TB/s.
+                          B_ray model) and counter bytes, each divided by time and by 8 TB/s; the node-visit rate of k_walk
+                          next to the record-chase ceilings measured on this GPU in this run (tinsel_hip_ubench).
+  configs[2]              BASELINE configs[3]: data/glass.tin 1920x1080 maxDepth 12.
+  configs[3]              BASELINE configs[4]: data/veach.tin 3840x2160 (one GPU's share of it at N = 1: the whole frame).
 
 Scenes come from scene packs written by the reference's own loader (tests/golden/*.pack); camera rays, RNG seeds and
 everything downstream are generated on the GPU, so inputs are resident in HBM when a timed region starts, and the
@@ -22,11 +25,17 @@ one block / that median (max over ranks for N > 1).
 
 Counters: `roofline.traffic` (HBM bytes per launch of the dominant kernel) and the VALU instruction count behind
 `roofline.achieved` are measured IN THIS RUN, on this box, by re-running the same workload under
-`rocprofv3 --pmc` (separate passes for FETCH_SIZE, WRITE_SIZE and the SQ counters, the gfx950 x2 on FETCH_SIZE of
-MI355X_MICROARCH.md); when rocprofv3 is not available the fields are null -- nothing is read from a stored file.
+`rocprofv3 --pmc` (separate passes for FETCH_SIZE, WRITE_SIZE, the SQ counters and TCC hits / misses).  What one count of
+FETCH_SIZE / WRITE_SIZE stands for is CALIBRATED in the same passes on kernels with a known byte count
+(tinsel_hip_ubench: a float4 stream copy for the streaming kernels -- the guide's gfx950 x2 -- and dependent 64-B record
+chases through a 1 GiB table, beyond the Infinity Cache, for the walking kernels); the factors are in the line
+(`counter_calibration`).  When rocprofv3 is not available the fields are null -- nothing is read from a stored file.
 
 N > 1 (launched by torch.distributed.run): weak scaling -- every rank traces its interleaved pixel tiles for K*N passes
-(same paths per GPU as N = 1), then ONE RCCL sum-reduce of the float4 accumulator to rank 0 inside the timed region.
+(same paths per GPU as N = 1), then ONE RCCL sum-reduce of the float4 accumulator to rank 0 inside the timed region
+(tinsel_amd.distributed.reduce_accum: out of place, the ranks' accumulators keep their own partial sums).  Before the ranks
+meet, rank 0 also times the SAME N devices through the library's own multi-GPU path (`--group`: tinsel_hip_group, what the
+reference's single-process C++ caller gets through the shim) in a child process with a time limit: `group` in the line.
 """
 import argparse
 import csv
@@ -53,6 +62,7 @@ CLOCK_HZ = 2.4e9                # max clock, same guide
 VALU_PEAK = SIMDS*CLOCK_HZ/2    # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (same guide; scratch/ubench/valu_bench.hip: 2.6)
 MIN_TIMED_S = 0.5
 LARGE = "large/ajax_standin"
+YARD = [None]                   # this run's yard-sticks (yard_sticks(): stream copy, record chases), N = 1 only
 
 
 def parse():
@@ -76,6 +86,10 @@ def parse():
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in tolerance-arithmetic leg (fast_msamples_s / fast_l2)")
     ap.add_argument("--no-api", action="store_true", help="skip the API call-pattern legs (pcie_inclusive / api_1pass), e.g. under rocprofv3 --stats")
     ap.add_argument("--arith", choices=["exact", "fast"], default="exact", help="arithmetic arm of the TIMED run (default: the bit-exact parity path)")
+    ap.add_argument("--no-more-configs", action="store_true", help="skip BASELINE configs 4 and 5 (glass depth 12, veach 4K)")
+    ap.add_argument("--no-ubench", action="store_true", help="skip the stream-copy / record-chase yard-sticks (and the counter calibration)")
+    ap.add_argument("--group", action="store_true", help="time the library's own multi-GPU path (tinsel_hip_group over --gpus devices, one process) instead")
+    ap.add_argument("--no-group-leg", action="store_true", help="N > 1: do not time the tinsel_hip_group path from rank 0 before the ranks meet")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)      # the child process the PMC passes profile
     return ap.parse_args()
 
@@ -120,7 +134,15 @@ PMC_SETS = {
     "sq": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
+    "tcc": ["TCC_HIT_sum", "TCC_MISS_sum"],
 }
+# kernels whose memory traffic is random record gathers (BVH walks); every other kernel of the path streams
+GATHER_KERNELS = ("k_walk", "k_extend", "k_shadow")
+UB_COPY_BYTES = 256 << 20           # per buffer
+UB_BIG_TABLE = 1 << 30              # beyond the 256 MiB Infinity Cache
+UB_TREE_TABLE = 32 << 20            # the 524,288-triangle tree: 33.5 MB of Node64
+UB_L2_TABLE = 2 << 20               # inside one XCD's 4 MiB L2
+UB_STEPS = 64
 
 
 def _kernel_key(name):
@@ -129,6 +151,8 @@ def _kernel_key(name):
         return None
     if m.group(2) and m.group(2).startswith("<true"):
         return None                         # detail-counting variants (COUNT = true) are not the product kernels
+    if m.group(1) == "k_ub_gather":
+        return "k_ub_gather" + (m.group(2) or "")
     return "k_accumulate" if m.group(1).startswith("k_accumulate") else m.group(1)
 
 
@@ -142,6 +166,8 @@ def pmc_pass(args, scene, width, height, maxdepth, steps, counters, timeout=150)
         cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["-d", tmp, "-o", "p", "--output-format", "csv", "--",
                sys.executable, os.path.abspath(__file__), "--inner-pmc", "--scene", scene, "--width", str(width), "--height", str(height),
                "--maxdepth", str(maxdepth), "--steps", str(steps), "--pipeline", args.pipeline, "--bvh", args.bvh, "--roulette", str(args.roulette)]
+        if args.no_ubench:
+            cmd.append("--no-ubench")
         env = dict(os.environ, TMPDIR="/tmp")
         p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
         files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
@@ -185,6 +211,56 @@ def inner_pmc(args):
     r.reserve(args.steps, opt.max_depth)
     r.render(cam, opt, passes=args.steps, readback=False)
     r.close()
+    if not args.no_ubench:
+        # the counters' calibration kernels, in the same profiled process: known byte counts
+        tinsel_amd.ubench(tinsel_amd.renderer.UBENCH_COPY, UB_COPY_BYTES)
+        tinsel_amd.ubench(tinsel_amd.renderer.UBENCH_GATHER_BEYOND_CACHE, UB_BIG_TABLE, UB_STEPS)
+
+
+def calibrate(pmc):
+    """Bytes one count of FETCH_SIZE / WRITE_SIZE (KB units) stands for, from the yard-stick kernels of the same passes.
+    k_ub_copy launches twice (warm-up + timed) and reads / writes UB_COPY_BYTES each time; k_ub_gather<0> visits
+    grid*256*UB_STEPS records of 64 B per launch, all of them misses down to HBM (1 GiB table)."""
+    cal = {"stream_bytes_per_fetch_count": None, "gather_bytes_per_fetch_count": None, "bytes_per_write_count": None}
+    f, w = pmc.get("fetch") or {}, pmc.get("write") or {}
+    if "k_ub_copy" in f and f["k_ub_copy"].get("FETCH_SIZE"):
+        cal["stream_bytes_per_fetch_count"] = UB_COPY_BYTES*f["k_ub_copy"]["launches"]/(f["k_ub_copy"]["FETCH_SIZE"]*1024.0)
+    if "k_ub_copy" in w and w["k_ub_copy"].get("WRITE_SIZE"):
+        cal["bytes_per_write_count"] = UB_COPY_BYTES*w["k_ub_copy"]["launches"]/(w["k_ub_copy"]["WRITE_SIZE"]*1024.0)
+    g = f.get("k_ub_gather<0>")
+    if g and g.get("FETCH_SIZE"):
+        cal["gather_bytes_per_fetch_count"] = 64.0*g["launches"]*cal_gather_visits()/(g["FETCH_SIZE"]*1024.0)
+    return cal
+
+
+_GATHER_VISITS = [None]
+
+
+def cal_gather_visits():
+    """records one k_ub_gather launch visits on this GPU (grid = 16 workgroups per CU x 256 lanes x UB_STEPS)"""
+    if _GATHER_VISITS[0] is None:
+        import torch
+        _GATHER_VISITS[0] = torch.cuda.get_device_properties(0).multi_processor_count*16*256*UB_STEPS
+    return _GATHER_VISITS[0]
+
+
+def yard_sticks():
+    """Stream-copy and record-chase rates of THIS GPU, now (N = 1, rank 0): the ceilings the path kernels are quoted against."""
+    import tinsel_amd
+    from tinsel_amd import renderer as R
+    out = {}
+    try:
+        ms, units = tinsel_amd.ubench(R.UBENCH_COPY, 1 << 30)
+        out["stream_copy_GBs"] = units/(ms*1e-3)/1e9
+        for key, kind, table in (("gather_beyond_cache", R.UBENCH_GATHER_BEYOND_CACHE, UB_BIG_TABLE), ("gather_tree_sized", R.UBENCH_GATHER_TREE, UB_TREE_TABLE),
+                                 ("gather_l2_resident", R.UBENCH_GATHER_L2, UB_L2_TABLE)):
+            ms, units = tinsel_amd.ubench(kind, table, 256)
+            out[key + "_Grecords_s"] = units/(ms*1e-3)/1e9
+        out["what"] = ("tinsel_hip_ubench on this GPU in this run: float4 copy of 1 GiB (bytes read + written per second); dependent chases of 64-B records, "
+                       "one chain per lane, 16 waves per CU, through tables of 1 GiB / 32 MiB (a 524k-triangle tree) / 2 MiB (inside one L2)")
+    except Exception as e:
+        out["error"] = str(e)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -220,18 +296,16 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     r.reserve(max(args.steps, args.warmup, 1)*world, opt.max_depth)      # no hipMalloc inside the timed region
 
     passes_per_step = world         # weak scaling: K*N passes over 1/N of the pixels each
+    from tinsel_amd import distributed
+    total_buf = torch.empty_like(accum) if world > 1 else None     # the reduce target: allocated outside the timed region
+    reduced = [accum]
 
     def run(steps):
         r.render_async(cam, opt, passes=steps*passes_per_step, stream=stream)
         if world > 1:
-            if backend == "nccl":
-                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)         # RCCL over xGMI, on the render stream
-            else:
-                torch.cuda.synchronize()
-                host = accum.cpu()
-                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                if rank == 0:
-                    accum.copy_(host)
+            # the ONE collective of the path, out of place: `accum` keeps this rank's own partial sums (a later render + reduce
+            # cannot count a sample twice); RCCL over xGMI on the render stream, or the gloo stand-in through host memory
+            reduced[0] = distributed.reduce_accum(accum, dst=0, out=total_buf)
 
     def sync():
         if world > 1:
@@ -249,7 +323,9 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     I_bar, T_bar, P_bar = c["internal_visits"]/rays_c, c["tri_tests"]/rays_c, c["prim_tests"]/rays_c
     B_ray = 48.0 + 64.0*I_bar + 48.0*T_bar + 84.0*P_bar
     fw = opt.filter.width
-    K_fp = (2*int(fw) + 1)**2
+    # pixels AddSample touches per sample (render.cpp:426-429: [int(x - fw), int(x + fw)] per axis, x uniform in the pixel):
+    # 2 fw + 1 per axis on average away from the frame edge -- 6.25 for the default 0.75 (4..9)
+    K_fp = (2.0*fw + 1.0)**2
     B_fb = 32.0*K_fp
 
     # ---- warmup --------------------------------------------------------------------------------
@@ -309,7 +385,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         chk.set_pass_index(last_first)
         want = chk.render(cam, opt, passes=args.steps*passes_per_step)
         chk.close()
-        got = accum.cpu().numpy()
+        got = reduced[0].cpu().numpy()
         ok = np.allclose(got, want, rtol=1e-4, atol=1e-5)
         print("validation: %d-rank reduced image vs unsharded render of passes [%d, %d): %s (max abs diff %.3e)" % (
             world, last_first, last_first + args.steps*passes_per_step, "ok" if ok else "MISMATCH",
@@ -318,7 +394,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
             raise SystemExit(3)
 
     # ---- the API's own call pattern, N = 1 only -------------------------------------------------
-    pcie = api_1pass = api_1pass_plain = None
+    pcie = api_1pass = api_1pass_plain = api_1pass_pinned = None
     if world == 1 and with_extras and not args.no_api:
         # a renderer of its own, with a library-owned accumulator like the C++ shim's (the timed one renders into a torch tensor)
         ra = tinsel_amd.create_gpu_renderer(scene, local)
@@ -339,13 +415,21 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
             ra.render(cam, opt, output=out, passes=1)
         t3 = time.perf_counter()
         api_1pass_plain = calls*opt.width*opt.height/(t3 - t2)/1e6
-        ra.set_lookahead(True)
-        ra.render(cam, opt, output=out, passes=1)               # pins the host array, starts the pipeline
+        ra.set_lookahead(abi.LOOKAHEAD_ON)                      # what the C++ shim turns on: the caller's array stays pageable
+        ra.render(cam, opt, output=out, passes=1)               # starts the pipeline
         t2 = time.perf_counter()
         for _ in range(calls):
             ra.render(cam, opt, output=out, passes=1)
         t3 = time.perf_counter()
         api_1pass = calls*opt.width*opt.height/(t3 - t2)/1e6
+        ra.set_lookahead(abi.LOOKAHEAD_PIN_OUTPUT)              # opt-in: the caller's array page-locked in place
+        ra.render(cam, opt, output=out, passes=1)
+        t2 = time.perf_counter()
+        for _ in range(calls):
+            ra.render(cam, opt, output=out, passes=1)
+        t3 = time.perf_counter()
+        api_1pass_pinned = calls*opt.width*opt.height/(t3 - t2)/1e6
+        ra.set_lookahead(abi.LOOKAHEAD_OFF)
         ra.close()
 
     # ---- the opt-in tolerance-arithmetic arm (tinsel_hip_set_arithmetic): rate and distance, N = 1 only ---------
@@ -407,15 +491,27 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     alg_gbs = dom_bytes/(dom_ms*1e-3)/1e9 if dom_ms > 0 else 0.0
     job_bytes = rays*B_ray + st["samples"]*B_fb
 
-    pmc = {"sq": None, "fetch": None, "write": None}
+    pmc = {"sq": None, "fetch": None, "write": None, "tcc": None}
     if world == 1 and not args.no_pmc and dom_name:
-        for key in ("sq", "fetch", "write"):
+        for key in ("sq", "fetch", "write", "tcc"):
             pmc[key] = pmc_pass(args, scene_name, width, height, opt.max_depth, args.steps, PMC_SETS[key])
-    traffic = valu_per_launch = lanes = wait = None
-    if pmc["fetch"] and pmc["write"] and dom_name in pmc["fetch"] and dom_name in pmc["write"]:
-        f, w = pmc["fetch"][dom_name], pmc["write"][dom_name]
-        # KB units; x2 on FETCH_SIZE: gfx950 tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section)
-        traffic = (2.0*f["FETCH_SIZE"]/f["launches"] + w["WRITE_SIZE"]/w["launches"])*1024.0
+    cal = calibrate(pmc)
+    # what a count stands for: calibrated on this run's yard-stick kernels; without them the guide's figures (x2 for wide
+    # coalesced streaming reads, MI355X_MICROARCH.md HBM section; everything else taken at face value) -- and the line says which
+    f_stream = cal["stream_bytes_per_fetch_count"] or 2.0
+    f_gather = cal["gather_bytes_per_fetch_count"] or 1.0
+    f_write = cal["bytes_per_write_count"] or 1.0
+
+    def kernel_traffic(name):
+        """counter bytes per launch of one kernel: FETCH_SIZE / WRITE_SIZE (KB) x the calibrated bytes per count of its access shape"""
+        if not (pmc["fetch"] and pmc["write"] and name in pmc["fetch"] and name in pmc["write"]):
+            return None
+        f, w = pmc["fetch"][name], pmc["write"][name]
+        ff = f_gather if name in GATHER_KERNELS else f_stream
+        return (ff*f["FETCH_SIZE"]/f["launches"] + f_write*w["WRITE_SIZE"]/w["launches"])*1024.0
+
+    traffic = kernel_traffic(dom_name) if dom_name else None
+    valu_per_launch = lanes = wait = l2_hit = None
     if pmc["sq"] and dom_name in pmc["sq"]:
         q = pmc["sq"][dom_name]
         valu_per_launch = q.get("SQ_INSTS_VALU", 0.0)/q["launches"]
@@ -423,6 +519,10 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
             lanes = q.get("SQ_THREAD_CYCLES_VALU", 0.0)/(64.0*q["SQ_INSTS_VALU"])
         if q.get("SQ_WAVE_CYCLES"):
             wait = q.get("SQ_WAIT_ANY", 0.0)/q["SQ_WAVE_CYCLES"]
+    if pmc["tcc"] and dom_name in pmc["tcc"]:
+        q = pmc["tcc"][dom_name]
+        if q.get("TCC_HIT_sum", 0.0) + q.get("TCC_MISS_sum", 0.0) > 0:
+            l2_hit = q["TCC_HIT_sum"]/(q["TCC_HIT_sum"] + q["TCC_MISS_sum"])
 
     scene_in_lds = "k_bounce" in ktimes or "k_mega" in ktimes       # the fused arms run only when the whole scene is LDS-resident
     common = {
@@ -430,12 +530,30 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         "algorithmic_GBs": alg_gbs, "frac_hbm_algorithmic": alg_gbs/HBM_PEAK_GBS,
         "counter_GBs": (traffic/avg_launch_s/1e9) if (traffic and avg_launch_s > 0) else None,
         "frac_hbm_counter": (traffic/avg_launch_s/1e9/HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
+        "l2_hit_rate": l2_hit,
         "valu_wave_insts_per_launch": valu_per_launch, "valu_lanes_active": lanes, "wave_cycles_waiting": wait,
-        "B_ray": B_ray, "I": I_bar, "T": T_bar, "P": P_bar, "B_fb": B_fb,
+        "B_ray": B_ray, "I": I_bar, "T": T_bar, "P": P_bar, "B_fb": B_fb, "K_fp": K_fp,
         "job_algorithmic_GBs": job_bytes/(gpu_ms*1e-3)/1e9 if gpu_ms > 0 else 0.0,
         "kernel_ms": {k: round(v[1], 3) for k, v in ktimes.items()},
+        "kernel_traffic_GB": {k: (round(kernel_traffic(k)*v[0]/1e9, 3) if kernel_traffic(k) else None) for k, v in ktimes.items()} if any(pmc.values()) else None,
+        "counter_calibration": dict(cal, source=("k_ub_copy / k_ub_gather<0> in the same rocprofv3 passes" if any(cal.values()) else
+                                                 "none measured: FETCH_SIZE x2 on streaming kernels (the guide), x1 elsewhere"),
+                                    gather_kernels=list(GATHER_KERNELS)),
         "counters": "rocprofv3 --pmc passes of this run (same workload, same passes per launch)" if any(pmc.values()) else None,
     }
+    if YARD[0]:
+        common["stream_copy_GBs"] = YARD[0].get("stream_copy_GBs")
+        if traffic and avg_launch_s > 0 and YARD[0].get("stream_copy_GBs"):
+            common["frac_of_stream_copy"] = traffic/avg_launch_s/1e9/YARD[0]["stream_copy_GBs"]
+    if dom_name == "k_walk" and dom_ms > 0:
+        # what the walk is made of: Node64 visits (and triangle tests) per second, next to the record-chase rates this GPU
+        # sustains on a table of the tree's size and on one that fits an XCD's L2 (tinsel_hip_ubench, this run)
+        common["node_visits_G_s"] = rays*I_bar/(dom_ms*1e-3)/1e9
+        common["triangle_tests_G_s"] = rays*T_bar/(dom_ms*1e-3)/1e9
+        if YARD[0]:
+            common["record_chase_ceilings_G_s"] = {k: YARD[0].get(k) for k in ("gather_beyond_cache_Grecords_s", "gather_tree_sized_Grecords_s", "gather_l2_resident_Grecords_s")}
+            if YARD[0].get("gather_tree_sized_Grecords_s"):
+                common["frac_of_tree_sized_chase"] = (common["node_visits_G_s"] + 0.75*common["triangle_tests_G_s"])/YARD[0]["gather_tree_sized_Grecords_s"]
     if scene_in_lds:
         # the scene never leaves the CU: the HBM model counts bytes that are LDS reads.  What binds is instruction issue.
         ach = (valu_per_launch/avg_launch_s/1e9) if (valu_per_launch and avg_launch_s > 0) else None
@@ -445,7 +563,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         # counter bytes when this run measured them, else the algorithmic figure (never a stored constant)
         ach = common["counter_GBs"] if common["counter_GBs"] else alg_gbs
         roofline = dict({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach/HBM_PEAK_GBS,
-                         "achieved_is": "counter bytes" if common["counter_GBs"] else "algorithmic bytes"}, **common)
+                         "achieved_is": "counter bytes (calibrated)" if common["counter_GBs"] else "algorithmic bytes"}, **common)
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:        # the CPU leg is timed at N = 1 only
@@ -472,6 +590,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         "pcie_inclusive_msamples_s": pcie,
         "api_1pass_msamples_s": api_1pass,
         "api_1pass_plain_msamples_s": api_1pass_plain,
+        "api_1pass_pinned_output_msamples_s": api_1pass_pinned,
         "arithmetic": args.arith,
         "fast_msamples_s": fast["msamples_s"] if fast else None,
         "fast_l2": fast["l2_vs_exact_at_spp"][0] if (fast and fast.get("l2_vs_exact_at_spp")) else None,
@@ -483,10 +602,85 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     return res
 
 
+def group_bench(args):
+    """`--group`: the library's OWN multi-GPU path -- tinsel_hip_group over args.gpus devices inside this one process (what the
+    reference's single-threaded C++ caller gets through shim/hip_renderer.cpp): thread per device, pixel-tile shards, one
+    ncclReduce per read-back, D2H.  Timed the two ways a caller uses it: K*N passes per call with one read-back (the headless
+    driver), and the reference's own pattern -- ONE pass + a full-frame read-back per call (main.cpp:246-250) -- plain and with
+    the group's look-ahead.  Prints one JSON line."""
+    import torch
+    import tinsel_amd
+    from tinsel_amd import abi
+    n = max(1, args.gpus)
+    one_device = torch.cuda.device_count() < n
+    if one_device:
+        os.environ["TINSEL_HIP_GROUP_ONE_DEVICE"] = "1"         # validation of the code path on a smaller box, not a measurement
+    scene = tinsel_amd.Scene.load_pack(os.path.join(ROOT, "tests", "golden", args.scene + ".pack"))
+    cam, opt = scene.camera, scene.options.copy()
+    opt.width, opt.height, opt.mode = args.width, args.height, abi.MODE_PATHTRACE
+    if args.maxdepth > 0:
+        opt.max_depth = args.maxdepth
+    grp = tinsel_amd.HipRendererGroup(scene, n, args.tile)
+    grp.init(opt.width, opt.height)
+    out = np.empty((opt.height, opt.width, 4), np.float32)
+    K = args.steps*n
+    grp.render(cam, opt, output=out, passes=max(1, args.warmup))
+    blocks, total = [], 0.0
+    while total < MIN_TIMED_S and len(blocks) < 1000:
+        t0 = time.perf_counter()
+        grp.render(cam, opt, output=out, passes=K)
+        blocks.append(time.perf_counter() - t0)
+        total += blocks[-1]
+    kpass = K*opt.width*opt.height/statistics.median(blocks)/1e6
+
+    def one_pass_calls(calls):
+        grp.render(cam, opt, output=out, passes=1)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            grp.render(cam, opt, output=out, passes=1)
+        return calls*opt.width*opt.height/(time.perf_counter() - t0)/1e6
+
+    calls = 64
+    plain = one_pass_calls(calls)
+    grp.set_lookahead(abi.LOOKAHEAD_ON)
+    ahead = one_pass_calls(calls)
+    grp.set_lookahead(abi.LOOKAHEAD_PIN_OUTPUT)
+    ahead_pinned = one_pass_calls(calls)
+    grp.close()
+    print(json.dumps({
+        "metric": "Msamples/s through tinsel_hip_group (%s.tin %dx%d maxDepth=%d), read-back to host memory included" % (args.scene, opt.width, opt.height, opt.max_depth),
+        "n_gpus": n, "one_device_validation": one_device, "unit": "Msamples/s",
+        "kpass_msamples_s": kpass, "kpass_passes_per_call": K, "kpass_calls_timed": len(blocks),
+        "api_1pass_plain_msamples_s": plain, "api_1pass_lookahead_msamples_s": ahead, "api_1pass_lookahead_pinned_output_msamples_s": ahead_pinned,
+        "calls": calls}), flush=True)
+
+
+def group_leg(args, world):
+    """N > 1, rank 0, before the ranks meet: the same N devices through tinsel_hip_group in a child process with a time limit
+    (a hung collective must not take the scaling run with it)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
+    if os.environ.get("TINSEL_BENCH_ONE_DEVICE"):
+        env["TINSEL_HIP_GROUP_ONE_DEVICE"] = "1"
+    cmd = [sys.executable, os.path.abspath(__file__), "--group", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--scene", args.scene, "--width", str(args.width), "--height", str(args.height), "--maxdepth", str(args.maxdepth), "--tile", str(args.tile)]
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"unavailable": "exit %d: %s" % (p.returncode, (p.stderr or "").strip().splitlines()[-1:] or "")}
+    except subprocess.TimeoutExpired:
+        return {"unavailable": "timed out after 240 s"}
+    except Exception as e:
+        return {"unavailable": str(e)}
+
+
 def main():
     args = parse()
     if args.inner_pmc:
         return inner_pmc(args)
+    if args.group:
+        return group_bench(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -504,6 +698,11 @@ def main():
     if os.environ.get("TINSEL_BENCH_ONE_DEVICE"):
         local = 0
     torch.cuda.set_device(local)
+    group = None
+    if world > 1 and rank == 0 and not args.no_group_leg:
+        group = group_leg(args, world)
+    if world == 1 and not args.no_ubench:
+        YARD[0] = yard_sticks()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -513,30 +712,45 @@ def main():
 
     head = run_config(args, args.scene, args.width, args.height, args.maxdepth, rank, world, local, dist, backend, torch, with_extras=True)
 
-    second = None
+    more = []
     default_headline = (args.scene, args.width, args.height) == ("cornell", 1024, 1024)
     if world == 1 and default_headline and not args.no_second_config:
+        # BASELINE configs[2]: the scene that lives in HBM
+        what = "ajax stand-in (524,288 triangles) 1920x1080 maxDepth=4"
         if os.path.exists(os.path.join(ROOT, "tests", "golden", LARGE + ".pack")):
             try:
-                second = run_config(args, LARGE, 1920, 1080, 4, rank, world, local, dist, backend, torch, with_extras=False)
+                more.append(run_config(args, LARGE, 1920, 1080, 4, rank, world, local, dist, backend, torch, with_extras=False))
             except Exception as e:
-                second = {"config": {"workload": "ajax stand-in (524,288 triangles) 1920x1080 maxDepth=4"}, "unavailable": "failed: %s" % e}
+                more.append({"config": {"workload": what}, "unavailable": "failed: %s" % e})
         else:
-            second = {"config": {"workload": "ajax stand-in (524,288 triangles) 1920x1080 maxDepth=4"},
-                      "unavailable": "tests/golden/large/ajax_standin.pack is not on this box (72 MB, git-ignored; written by tests/golden/make_large.py "
-                                     "from the reference's data/ajax.tin where /root/reference is mounted)"}
+            more.append({"config": {"workload": what},
+                         "unavailable": "tests/golden/large/ajax_standin.pack is not on this box (72 MB, git-ignored; written by tests/golden/make_large.py "
+                                        "from the reference's data/ajax.tin where /root/reference is mounted)"})
+        # BASELINE configs[3] and [4]: glass depth 12 at 1080p, veach at 4K
+        if not args.no_more_configs:
+            for name, w, h, d in (("glass", 1920, 1080, 12), ("veach", 3840, 2160, 0)):
+                try:
+                    more.append(run_config(args, name, w, h, d, rank, world, local, dist, backend, torch, with_extras=False))
+                except Exception as e:
+                    more.append({"config": {"workload": "%s.tin %dx%d" % (name, w, h)}, "unavailable": "failed: %s" % e})
 
     if rank == 0:
         line = {
             "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32",
+            "data": "synthetic: camera samples, seeds and everything downstream generated on the GPU; scenes are the reference's own files as written by "
+                    "its loader (scene packs), the ajax mesh a procedural 524,288-triangle stand-in (ajax.obj is not in the reference tree)",
         }
         for k, v in head.items():
             if k not in line:
                 line[k] = v
-        if second is not None:
-            line["configs"] = [{k: head[k] for k in ("metric", "value", "unit", "ms_per_step", "mrays_per_s", "config", "roofline", "cpu_baseline", "timed_blocks", "fast_msamples_s", "fast_l2")}, second]
+        if YARD[0]:
+            line["yard_sticks"] = YARD[0]
+        if group is not None:
+            line["group"] = group
+        if more:
+            line["configs"] = [{k: head[k] for k in ("metric", "value", "unit", "ms_per_step", "mrays_per_s", "config", "roofline", "cpu_baseline", "timed_blocks", "fast_msamples_s", "fast_l2")}] + more
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

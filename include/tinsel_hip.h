@@ -407,6 +407,14 @@ int tinsel_hip_group_size(tinsel_hip_group* g);
  * Whatever the group had speculated is dropped first (look-ahead starts over with the next read-back). */
 tinsel_hip* tinsel_hip_group_member(tinsel_hip_group* g, int rank);
 
+/* Yard-sticks measured on the GPU itself, for bench.py's roofline (not part of the render path): kind 0 = a float4 stream
+ * copy of `bytes` bytes (*out_units = bytes read + written); kinds 1..3 = dependent chases through a table of 64-B records
+ * of `bytes` bytes (rounded down to a power of two), `steps` visits per lane, 16 waves per CU (*out_units = records
+ * visited) -- the access pattern of a BVH walk; the kind only names the kernel for the profiler: 1 a table beyond the
+ * Infinity Cache (calibrates FETCH_SIZE for random 64-B gathers), 2 one the size of a walked tree, 3 one inside an L2.
+ * *out_ms = the timed launch (HIP events). */
+int tinsel_hip_ubench(int device_index, int kind, unsigned long long bytes, int steps, double* out_ms, double* out_units);
+
 /* ------------------------------------------------------------------------- */
 /* Scene packs: a relocatable single-blob serialisation of tinsel_scene_desc   */
 /* (+ the scene's camera/options) so that scenes travel to machines without    */

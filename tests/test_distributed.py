@@ -43,13 +43,17 @@ def _worker(rank, world, port, tmp):
         total = distributed.reduce_accum(t, dst=0)
         assert torch.equal(t, mine)                   # the rank's own accumulator is untouched by the reduce ...
         again = distributed.reduce_accum(t, dst=0)    # ... so reducing twice gives the same frame (no double counting)
+        scratch = torch.full_like(t, 7.0)             # a caller-kept target (bench.py keeps one outside its timed region)
+        third = distributed.reduce_accum(t, dst=0, out=scratch)
+        assert torch.equal(t, mine)
         if rank == 0:
             assert torch.equal(total, again)
+            assert third is scratch and torch.equal(third, total)
             whole, _, _ = P.render_seeded(h, cam, opt, 0, 2, threads=2)
             np.save(os.path.join(tmp, "reduced.npy"), total.numpy())
             np.save(os.path.join(tmp, "whole.npy"), whole)
         else:
-            assert total is None and again is None
+            assert total is None and again is None and third is None
         P.free(h)
         dist.barrier()
     finally:

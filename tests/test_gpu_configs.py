@@ -157,3 +157,47 @@ def test_silhouette_window_at_a_late_pass_is_bit_identical(label, pack, W, H, de
     O.free(h)
     exact = (rad == orad[0]).all(axis=-1)
     assert exact.all(), "%s window (%d, %d), pass %d: %d of %d paths differ" % (label, x0, y0, pass_index, (~exact).sum(), exact.size)
+
+
+FULL_FRAMES = [
+    # label, pack, W, H, maxDepth, spp: what the reference's own PathTrace does in seconds on the GPU box's host threads
+    ("cfg2 cornell 1024x1024 spp 256 (the config's own spp)", os.path.join(oa.GOLDEN, "cornell.pack"), 1024, 1024, 4, 256),
+    ("cfg3 ajax stand-in 524288 tris 1920x1080 spp 8", LARGE, 1920, 1080, 4, 8),
+    ("cfg4 glass 1920x1080 depth 12 spp 4", os.path.join(oa.GOLDEN, "glass.pack"), 1920, 1080, 12, 4),
+    ("cfg5 veach 3840x2160 spp 2", os.path.join(oa.GOLDEN, "veach.pack"), 3840, 2160, 4, 2),
+]
+
+
+@pytest.mark.parametrize("label,pack,W,H,depth,spp", FULL_FRAMES, ids=[c[0].split()[0] + "-full" for c in FULL_FRAMES])
+def test_whole_frame_equals_the_reference(label, pack, W, H, depth, spp):
+    """The WHOLE framebuffer of each BASELINE GPU config -- every pixel, frame edges and the accumulate tiles that stick out of
+    a 1080-row frame included -- against the reference's own PathTrace + AddSample on the same seeds: array_equal, and the
+    per-pixel L2 of the resolved images (north_star's bar is 1e-3) printed beside it."""
+    import time
+    import tinsel_amd
+    if not os.path.exists(pack):
+        pytest.skip("%s not on this box" % pack)
+    scene = tinsel_amd.Scene.load_pack(pack)
+    cam, opt = scene.camera, scene.options.copy()
+    opt.width, opt.height, opt.max_depth, opt.mode = W, H, depth, abi.MODE_PATHTRACE
+
+    r = tinsel_amd.create_gpu_renderer(scene)
+    r.init(W, H)
+    t0 = time.perf_counter()
+    out = r.render(cam, opt, passes=spp)
+    t_gpu = time.perf_counter() - t0
+    r.close()
+
+    O = _oracle()
+    h = O.load_pack(pack)
+    t0 = time.perf_counter()
+    want, _, trace_s = O.render_seeded(h, cam, opt, 0, spp)
+    t_cpu = time.perf_counter() - t0
+    O.free(h)
+
+    l2 = oa.image_l2(out, want)
+    same = float((out == want).all(axis=-1).mean())
+    print("%s: per-pixel L2 vs %s = %.3e, %.4f %% of the pixels bit-identical; GPU %.2f s (with read-back), CPU %.1f s (%.1f s tracing, %d threads)" % (
+        label, type(O).__name__, l2, 100.0*same, t_gpu, t_cpu, trace_s, os.cpu_count() or 1))
+    assert np.array_equal(out, want), "%s: %d pixels differ, L2 %.3e" % (label, int((out != want).any(axis=-1).sum()), l2)
+    assert (out[..., 3] > 0).all()

@@ -29,3 +29,18 @@ def test_two_ranks_on_one_device():
     # weak scaling: 2 ranks x (8 steps x 2 passes) over half of the pixels each = 16 full-frame passes of samples
     assert abs(d["value"]*d["ms_per_step"]*1e-3*8*1e6 - 16*512*384) < 1e-3*16*512*384
     assert d["roofline"]["kernel"] and d["cpu_baseline"] is None
+    # rank 0 also timed the SAME devices through the library's own multi-GPU path (tinsel_hip_group, one-device validation here)
+    g = d["group"]
+    assert g.get("n_gpus") == 2 and g["one_device_validation"] is True, g
+    assert g["kpass_msamples_s"] > 0 and g["api_1pass_plain_msamples_s"] > 0 and g["api_1pass_lookahead_msamples_s"] > 0, g
+
+
+def test_group_mode_prints_one_line():
+    """`bench.py --group --gpus 2`: tinsel_hip_group in one process (all members on device 0 on this pool's boxes)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--group", "--gpus", "2", "--steps", "4", "--warmup", "1", "--width", "256", "--height", "256"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    g = json.loads(lines[0])
+    assert g["n_gpus"] == 2 and g["kpass_passes_per_call"] == 8 and g["api_1pass_lookahead_pinned_output_msamples_s"] > 0

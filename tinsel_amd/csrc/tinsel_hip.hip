@@ -8,6 +8,7 @@
 
 #include "tn_launch.h"
 #include "tn_lbvh.h"
+#include "tn_ubench.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -649,6 +650,12 @@ extern "C" unsigned tinsel_fast_launch_args_size(void);
 
 void launch_path(tinsel_hip* r, int which, const LaunchArgs& a, hipStream_t st)
 {
+    if (!r->pathKernelsPrepared)
+    {
+        prepare_path_kernels(r->sharedMemLimit);
+        tinsel_fast_prepare_path_kernels(r->sharedMemLimit);
+        r->pathKernelsPrepared = true;
+    }
     if (r->arith == TINSEL_ARITH_FAST)
         tinsel_fast_launch_path_kernel(which, &a, st);
     else
@@ -911,6 +918,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     fp.accBegin = 0;
     fp.accEnd = fp.numPasses;
     fp.rrStart = r->rrStart;
+    fp.repack = 0;
     const int gridFlat = (int)std::max<size_t>(1, (slots + kBlock - 1)/kBlock);
     const int gridPersist = streaming_grid(r, slots, resolve_pipeline(r));
     // the trace kernels stride over the regions: by default one block per four regions like the others
@@ -935,6 +943,19 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         if (set_regions(r, a, slots, gridPersist))
             return -1;
         a.grid = gridPersist;
+        // k_bounce closes ranks between the closest-hit trace and the shading half (the waves' shading pools, tn_kernels.h:
+        // 27 KB of LDS per workgroup) where the pools do not cost a resident workgroup: two per CU in the parity arm (2 waves
+        // per SIMD), three in the tolerance arm
+        {
+            static const bool noRepack = getenv("TINSEL_HIP_NO_REPACK") != nullptr;
+            const size_t withPool = (size_t)a.ldsBytes + kPoolWords*sizeof(uint32_t);
+            const size_t perCU = 160u*1024u, blocksPerCU = r->arith == TINSEL_ARITH_FAST ? 3 : 2;
+            if (!noRepack && withPool*blocksPerCU <= perCU && withPool <= (size_t)r->sharedMemLimit)
+            {
+                a.fp.repack = 1;
+                a.ldsBytes = (uint32_t)withPool;
+            }
+        }
         static const bool noOrder = getenv("TINSEL_HIP_NO_REGION_ORDER") != nullptr;
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
@@ -2649,6 +2670,82 @@ int tinsel_hip_queue_counts(tinsel_hip* r, uint32_t* out, int max_bounces)
 
 // ---------------------------------------------------------------------------
 // scene packs
+
+// Yard-sticks on this GPU (tn_ubench.h): kind 0 = float4 stream copy of `bytes` bytes (units = bytes read + written),
+// kinds 1..3 = dependent 64-B record chases through a table of `bytes` bytes rounded down to a power of two, `steps` visits
+// per lane (units = records visited); the kind only names the kernel for the profiler (1 beyond the Infinity Cache, 2 the size
+// of a walked tree, 3 inside one L2).  One warm-up launch, then one timed with HIP events.
+int tinsel_hip_ubench(int device_index, int kind, unsigned long long bytes, int steps, double* out_ms, double* out_units)
+{
+    if (kind < 0 || kind > 3 || bytes < 4096 || !out_ms || !out_units)
+        return fail("ubench: bad arguments");
+    HIP_TRY(hipSetDevice(device_index));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_index));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float ms = 0.0f;
+    int rc = 0;
+    if (kind == 0)
+    {
+        const size_t n = (size_t)bytes/sizeof(float4);
+        float4 *in = nullptr, *out = nullptr;
+        if (hipMalloc((void**)&in, n*sizeof(float4)) != hipSuccess || hipMalloc((void**)&out, n*sizeof(float4)) != hipSuccess ||
+            hipMemset(in, 0x3c, n*sizeof(float4)) != hipSuccess)
+            rc = fail("ubench: allocation failed");
+        else
+        {
+            const unsigned grid = (unsigned)prop.multiProcessorCount*32u;
+            hipLaunchKernelGGL(k_ub_copy, dim3(grid), dim3(256), 0, nullptr, (const float4*)in, out, n);
+            (void)hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(k_ub_copy, dim3(grid), dim3(256), 0, nullptr, (const float4*)in, out, n);
+            (void)hipEventRecord(e1, nullptr);
+            if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess)
+                rc = fail("ubench: copy kernel failed");
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            *out_units = 2.0*(double)(n*sizeof(float4));
+        }
+        if (in) (void)hipFree(in);
+        if (out) (void)hipFree(out);
+    }
+    else
+    {
+        uint32_t nrec = 1;
+        while ((unsigned long long)nrec*2ull*64ull <= bytes && nrec < (1u << 30))
+            nrec *= 2u;
+        if (steps < 1)
+            steps = 64;
+        const unsigned grid = (unsigned)prop.multiProcessorCount*16u;       // 4 workgroups x 4 waves per SIMD-quad: 16 waves per CU
+        float4* recs = nullptr;
+        float* out = nullptr;
+        if (hipMalloc((void**)&recs, (size_t)nrec*64) != hipSuccess || hipMalloc((void**)&out, (size_t)grid*256*sizeof(float)) != hipSuccess)
+            rc = fail("ubench: allocation failed");
+        else
+        {
+            hipLaunchKernelGGL(k_ub_fill, dim3((unsigned)prop.multiProcessorCount*8u), dim3(256), 0, nullptr, recs, nrec);
+            auto launch = [&] {
+                if (kind == 1) hipLaunchKernelGGL((k_ub_gather<0>), dim3(grid), dim3(256), 0, nullptr, (const float4*)recs, nrec, steps, out);
+                else if (kind == 2) hipLaunchKernelGGL((k_ub_gather<1>), dim3(grid), dim3(256), 0, nullptr, (const float4*)recs, nrec, steps, out);
+                else hipLaunchKernelGGL((k_ub_gather<2>), dim3(grid), dim3(256), 0, nullptr, (const float4*)recs, nrec, steps, out);
+            };
+            launch();
+            (void)hipEventRecord(e0, nullptr);
+            launch();
+            (void)hipEventRecord(e1, nullptr);
+            if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess)
+                rc = fail("ubench: gather kernel failed");
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            *out_units = (double)grid*256.0*(double)steps;
+        }
+        if (recs) (void)hipFree(recs);
+        if (out) (void)hipFree(out);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *out_ms = (double)ms;
+    return rc;
+}
 
 int tinsel_pack_open(void* blob, size_t size, tinsel_scene_desc* out_scene, tinsel_camera* out_camera, tinsel_options* out_options)
 {

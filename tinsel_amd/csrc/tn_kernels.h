@@ -84,6 +84,7 @@ struct FrameParams
     uint32_t shardPerPass;              // path slots per pass of this shard (owned tiles x tile^2; W*H for one shard)
     uint32_t genCount;                  // camera paths the generation kernels enumerate per batch (gen_slot)
     int rrStart;                        // > 0: Russian roulette from this bounce on (opt-in, not the reference's behaviour)
+    int repack;                         // k_bounce: paths that hit a surface close ranks (per-wave LDS pool) before the shading half
     int filterType;
     float filterWidth, filterFalloff, filterOffset;
     float clampLen;
@@ -400,6 +401,58 @@ __global__ __launch_bounds__(kOrderBlock) void k_region_order(const uint32_t* __
 }
 
 // ---------------------------------------------------------------------------
+// k_bounce's shading pool.  A lane runs one iteration of the oracle's loop for its path, and a lane whose ray left the scene
+// used to idle through its wave-mates' shading half (shadow traces, light and BSDF terms, the BSDF step: two thirds of a
+// round's time; on cornell a fifth to a quarter of the rays of bounces 1..3 leave through the open front).  So between the
+// closest-hit trace and the shading half the wave closes ranks through LDS: every wave owns a pool of up to 63 paths that
+// have hit something.  After a round's traces either the lanes whose path is finished PULL a waiting path each (when pool +
+// this round's hits fill the wave: the shading half runs with 64 lanes), or the round's hits are PUSHED and the shading half
+// is skipped this round.  A region thus runs ceil(hits/64) shading rounds instead of one per trace round, no barrier, no
+// atomic; a path's arithmetic does not know which lane runs it, so no result changes.  Layout: pool[field][entry], one
+// dword per field, consecutive lanes on consecutive entries.
+constexpr int kPoolFields = 27;
+constexpr int kPoolWordsPerWave = kPoolFields*kWave;
+constexpr int kPoolWords = kPoolWordsPerWave*(kBlock/kWave);     // per workgroup: 27 KB
+
+TN_D void pool_store(uint32_t* pool, uint32_t e, const PathRegs& p, uint32_t slot, int prim, float t, V3 n)
+{
+    uint32_t* q = pool + e;
+    q[0*kWave] = __float_as_uint(p.o.x); q[1*kWave] = __float_as_uint(p.o.y); q[2*kWave] = __float_as_uint(p.o.z);
+    q[3*kWave] = __float_as_uint(p.d.x); q[4*kWave] = __float_as_uint(p.d.y); q[5*kWave] = __float_as_uint(p.d.z);
+    q[6*kWave] = __float_as_uint(p.time);
+    q[7*kWave] = __float_as_uint(p.thr.x); q[8*kWave] = __float_as_uint(p.thr.y); q[9*kWave] = __float_as_uint(p.thr.z);
+    q[10*kWave] = __float_as_uint(p.rad.x); q[11*kWave] = __float_as_uint(p.rad.y); q[12*kWave] = __float_as_uint(p.rad.z);
+    q[13*kWave] = p.rng.s1; q[14*kWave] = p.rng.s2;
+    q[15*kWave] = __float_as_uint(p.eta);
+    q[16*kWave] = __float_as_uint(p.absorption.x); q[17*kWave] = __float_as_uint(p.absorption.y); q[18*kWave] = __float_as_uint(p.absorption.z);
+    q[19*kWave] = __float_as_uint(p.bsdfPdf);
+    q[20*kWave] = (uint32_t)p.rayType;
+    q[21*kWave] = slot;
+    q[22*kWave] = (uint32_t)prim;
+    q[23*kWave] = __float_as_uint(t);
+    q[24*kWave] = __float_as_uint(n.x); q[25*kWave] = __float_as_uint(n.y); q[26*kWave] = __float_as_uint(n.z);
+}
+
+TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slot, int& prim, float& t, V3& n)
+{
+    const uint32_t* q = pool + e;
+    p.o = V3(__uint_as_float(q[0*kWave]), __uint_as_float(q[1*kWave]), __uint_as_float(q[2*kWave]));
+    p.d = V3(__uint_as_float(q[3*kWave]), __uint_as_float(q[4*kWave]), __uint_as_float(q[5*kWave]));
+    p.time = __uint_as_float(q[6*kWave]);
+    p.thr = V3(__uint_as_float(q[7*kWave]), __uint_as_float(q[8*kWave]), __uint_as_float(q[9*kWave]));
+    p.rad = V3(__uint_as_float(q[10*kWave]), __uint_as_float(q[11*kWave]), __uint_as_float(q[12*kWave]));
+    p.rng.s1 = q[13*kWave]; p.rng.s2 = q[14*kWave];
+    p.eta = __uint_as_float(q[15*kWave]);
+    p.absorption = V3(__uint_as_float(q[16*kWave]), __uint_as_float(q[17*kWave]), __uint_as_float(q[18*kWave]));
+    p.bsdfPdf = __uint_as_float(q[19*kWave]);
+    p.rayType = (int)q[20*kWave];
+    slot = q[21*kWave];
+    prim = (int)q[22*kWave];
+    t = __uint_as_float(q[23*kWave]);
+    n = V3(__uint_as_float(q[24*kWave]), __uint_as_float(q[25*kWave]), __uint_as_float(q[26*kWave]));
+}
+
+// ---------------------------------------------------------------------------
 // k_bounce: the streaming pipeline's per-bounce kernel (the product path).
 //
 // One launch per bounce.  Each lane takes ONE live path from queue[bounce] (bounce 0: straight
@@ -436,10 +489,14 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
 
+    // LDS: [stackEntries][kBlock] stack words, kScanWords, (fp.repack) the waves' shading pools, the staged arena
+    const bool repack = fp.repack != 0;
+    uint32_t* const pool = s_stack + stackEntries*kBlock + kScanWords + (threadIdx.x/kWave)*kPoolWordsPerWave;
     SceneT<LDS, false, DEFER ? 1 : 0> sc;
-    stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords);
+    stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords + (repack ? kPoolWords : 0));
 
     const uint32_t lane = __lane_id();
+    const unsigned long long below = (1ull << lane) - 1ull;
     const int cur = bounce & 1, nxt = cur ^ 1;
     const bool hasMedia = sc.hasMedia != 0;
     uint32_t rays = 0, shadowRays = 0, samples = 0;
@@ -484,12 +541,20 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         }
         RegionAppend out = { base, ss.regionLen, 0u, 0u };
 
-        for (uint32_t j0 = share ? threadIdx.x/kWave*kWave : 0u; j0 < n; j0 += share ? kBlock : kWave)
+        uint32_t poolCount = 0;         // wave-uniform: paths that hit a surface and wait for the shading half
+        for (uint32_t j0 = share ? threadIdx.x/kWave*kWave : 0u; ; j0 += share ? kBlock : kWave)
         {
+            // the region's rounds are done: what still waits in the pool is shaded, then the region ends
+            const bool flush = j0 >= n;
+            if (flush && poolCount == 0u)
+                break;
             const uint32_t j = j0 + lane;
             bool have = false, alive = false, front = true;
             PathRegs p;
             uint32_t slot = 0;
+            int prim = -1;
+            float t = 0.0f;
+            V3 n3;
 
             TN_TICK(4)
             if (j < n)
@@ -524,20 +589,49 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                 }
             }
 
+            // ---- the closest-hit trace; a ray that leaves the scene ends its path here ------------------------------------
             if (have)
             {
                 TN_TICK(0)
-                float t;
-                V3 n3;
-                const int prim = trace<SceneT<LDS, false, DEFER ? 1 : 0>, LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n3, ctr);
+                prim = trace<SceneT<LDS, false, DEFER ? 1 : 0>, LdsStack<kBlock>, COUNT>(sc, st, p.o, p.d, p.time, t, n3, ctr);
                 rays++;
                 TN_TICK(1)
-
                 if (prim < 0)
                 {
                     on_miss(sc, p, bounce);
+                    ss.radOut[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
+                    have = false;
+                }
+            }
+
+            // ---- close ranks (see the pool's comment above) -------------------------------------------------------------
+            if (repack)
+            {
+                const unsigned long long live = __ballot(have);
+                const uint32_t nLive = (uint32_t)__popcll(live);
+                if (flush || poolCount + nLive >= (uint32_t)kWave)
+                {
+                    const uint32_t take = (poolCount < (uint32_t)kWave - nLive) ? poolCount : (uint32_t)kWave - nLive;
+                    const uint32_t rank = (uint32_t)__popcll(~live & below);
+                    if (!have && rank < take)
+                    {
+                        pool_load(pool, poolCount - 1u - rank, p, slot, prim, t, n3);
+                        have = true;
+                    }
+                    poolCount -= take;
                 }
                 else
+                {
+                    if (have)
+                        pool_store(pool, poolCount + (uint32_t)__popcll(live & below), p, slot, prim, t, n3);
+                    poolCount += nLive;
+                    have = false;           // waits in the pool
+                }
+            }
+
+            // ---- the shading half: emission, light sampling with its shadow traces, the BSDF step ----------------------------
+            if (have)
+            {
                 {
                     const V3 n = n3;
                     const Mat mat = load_mat(sc.mats, prim);
@@ -600,6 +694,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
             const uint32_t np = out.push(alive, front);
             if (alive)
                 store_state(ss, nxt, np, p, slot, hasMedia);
+            if (flush)
+                break;
         }
         if (lane == 0)
         {

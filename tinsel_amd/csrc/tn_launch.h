@@ -129,11 +129,16 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
     }
 }
 
-// k_walk asks for more dynamic LDS than the default launch limit allows
+// k_walk (tree tops) and k_bounce (shading pools beside a staged arena) ask for more dynamic LDS than the default launch limit allows
 inline void prepare_path_kernels(int sharedMemLimit)
 {
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_walk<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+#define TN_PREP_BOUNCE(C, F, L, D) (void)hipFuncSetAttribute((const void*)k_bounce<C, F, L, D>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
+    TN_PREP_BOUNCE(true, true, true, false); TN_PREP_BOUNCE(true, true, false, false); TN_PREP_BOUNCE(true, false, true, false); TN_PREP_BOUNCE(true, false, false, false);
+    TN_PREP_BOUNCE(false, true, true, false); TN_PREP_BOUNCE(false, true, false, false); TN_PREP_BOUNCE(false, false, true, false); TN_PREP_BOUNCE(false, false, false, false);
+    TN_PREP_BOUNCE(false, true, true, true); TN_PREP_BOUNCE(false, true, false, true); TN_PREP_BOUNCE(false, false, true, true); TN_PREP_BOUNCE(false, false, false, true);
+#undef TN_PREP_BOUNCE
 }
 
 } // namespace tn

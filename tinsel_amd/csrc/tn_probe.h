@@ -78,16 +78,20 @@ TN_D int lower_bound(const float* array, int lower, int upper, float value)
 // ProbeSample (probe.h:205-236)
 TN_D void probe_sample(const DevProbe& p, V3& dir, V3& color, float& pdf, Rng& rng)
 {
-    float r1 = rng.randf();
+    const uint32_t u1 = rng.rand();
+    float r1 = (float)u1*(1.0f/4294967296.0f);      // Randf() of that draw
     float r2 = rng.randf();
 
     int row, col;
     if (p.alias)
     {
         // opt-in alias table (not sample-identical to the reference: same two draws, same distribution over the texels,
-        // ONE dependent 8-B load instead of ~21 for the two binary searches over 800 rows and 1600 columns)
+        // ONE dependent 8-B load instead of ~21 for the two binary searches over 800 rows and 1600 columns).  The bin comes
+        // from the draw's 32 INTEGER bits: the fp32 uniform has 24, which over n = 1.28 M bins (loft.hdr) would give a bin 13 or
+        // 14 of the representable values -- a selection probability up to 7 % off the pdf returned; with 32 bits a bin gets
+        // 3355 or 3356 of the 2^32 values (3e-4).
         const int n = p.width*p.height;
-        const int k = minI(int(r1*float(n)), n - 1);
+        const int k = (int)(((unsigned long long)u1*(unsigned long long)n) >> 32);
         const uint2 e = p.alias[k];
         const int idx = (r2 < __uint_as_float(e.x)) ? k : (int)e.y;
         row = idx/p.width;

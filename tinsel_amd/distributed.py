@@ -28,15 +28,32 @@ def owned_mask(width, height, rank, world, tile=32):
     return (t % world) == rank
 
 
-def reduce_accum(accum, dst=0, group=None):
+def reduce_accum(accum, dst=0, group=None, out=None):
     """The one collective of the path: the sum over ranks of the per-rank accumulators [H,W,4], returned on rank `dst`
     (None elsewhere).  `accum` itself is left untouched on every rank -- it keeps the rank's OWN partial sums since
     Init, so a later render + reduce_accum cannot count earlier samples twice (an in-place reduce would leave rank
     dst holding everyone's samples, and the gloo backend also overwrites the non-dst inputs).  The price is one
-    accumulator-sized scratch tensor per call."""
+    accumulator-sized scratch tensor: `out` (same shape, dtype and device) when the caller keeps one, else a new one
+    per call.  With the `nccl` backend (RCCL) the copy and the reduce are enqueued on the current stream, nothing
+    synchronises; a device tensor under a CPU backend (`gloo`: the one-device stand-in of bench.py) travels through
+    host memory."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return accum
-    total = accum.clone()
+    backend = dist.get_backend(group)
+    if accum.is_cuda and backend != "nccl":
+        host = accum.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank(group) != dst:
+            return None
+        if out is None:
+            return host.to(accum.device)
+        out.copy_(host)
+        return out
+    if out is None:
+        total = accum.clone()
+    else:
+        total = out
+        total.copy_(accum)
     dist.reduce(total, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return total if dist.get_rank(group) == dst else None

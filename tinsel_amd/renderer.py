@@ -105,6 +105,7 @@ def load_library():
     L.tinsel_hip_group_member.restype = vp
     L.tinsel_hip_group_member.argtypes = [vp, ci]
     L.tinsel_hip_group_set_lookahead.argtypes = [vp, ci]
+    L.tinsel_hip_ubench.argtypes = [ci, ci, C.c_ulonglong, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tinsel_hip_last_error.restype = C.c_char_p
     L.tinsel_pack_open.argtypes = [vp, C.c_size_t, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.Options)]
     _lib = L
@@ -121,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_russian_roulette", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
     "tinsel_hip_walked_prims", "tinsel_hip_queue_counts", "tinsel_hip_set_lookahead", "tinsel_hip_set_arithmetic", "tinsel_hip_get_arithmetic", "tinsel_hip_refit_mesh", "tinsel_hip_set_probe_sampling",
     "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
-    "tinsel_hip_group_size", "tinsel_hip_group_member", "tinsel_hip_group_set_lookahead",
+    "tinsel_hip_group_size", "tinsel_hip_group_member", "tinsel_hip_group_set_lookahead", "tinsel_hip_ubench",
 ]
 
 
@@ -418,6 +419,17 @@ class HipRendererGroup:
             self.close()
         except Exception:
             pass
+
+
+UBENCH_COPY, UBENCH_GATHER_BEYOND_CACHE, UBENCH_GATHER_TREE, UBENCH_GATHER_L2 = 0, 1, 2, 3
+
+
+def ubench(kind, nbytes, steps=64, device=0):
+    """tinsel_hip_ubench: (milliseconds, units) of one timed launch -- units = bytes moved (copy) or 64-B records visited."""
+    L = load_library()
+    ms, units = C.c_double(0.0), C.c_double(0.0)
+    _check(L.tinsel_hip_ubench(int(device), int(kind), int(nbytes), int(steps), C.byref(ms), C.byref(units)), "tinsel_hip_ubench")
+    return ms.value, units.value
 
 
 def create_gpu_renderer(scene: Scene, device: int = 0) -> HipRenderer:
