@@ -200,4 +200,4 @@ def test_whole_frame_equals_the_reference(label, pack, W, H, depth, spp):
     print("%s: per-pixel L2 vs %s = %.3e, %.4f %% of the pixels bit-identical; GPU %.2f s (with read-back), CPU %.1f s (%.1f s tracing, %d threads)" % (
         label, type(O).__name__, l2, 100.0*same, t_gpu, t_cpu, trace_s, os.cpu_count() or 1))
     assert np.array_equal(out, want), "%s: %d pixels differ, L2 %.3e" % (label, int((out != want).any(axis=-1).sum()), l2)
-    assert (out[..., 3] > 0).all()
+    assert np.isfinite(out).all() and (out[..., 3] > 0).mean() > 0.99      # (at 2 spp a pixel may sit between every footprint)

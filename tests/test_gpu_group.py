@@ -73,7 +73,7 @@ def test_group_normals_mode_is_the_image_not_n_times_it(n, tile, monkeypatch):
     assert np.array_equal(out2, g["normals"])
 
 
-@pytest.mark.parametrize("n,mode", [(2, abi.LOOKAHEAD_ON), (3, abi.LOOKAHEAD_PIN_OUTPUT)])
+@pytest.mark.parametrize("n,mode", [(2, abi.LOOKAHEAD_ON), (3, abi.LOOKAHEAD_ON), (2, abi.LOOKAHEAD_PIN_OUTPUT), (3, abi.LOOKAHEAD_PIN_OUTPUT)])
 def test_group_lookahead_changes_no_bit(n, mode, monkeypatch):
     """tinsel_hip_group_set_lookahead: the reference's call pattern (Render = 1 pass + full read-back) at N members -- every
     member traces batches of future calls of its shard, the next call's snapshots are reduced while this call's image is
@@ -89,7 +89,7 @@ def test_group_lookahead_changes_no_bit(n, mode, monkeypatch):
     for k, o in enumerate(script):
         want = plain.render(cam, o, passes=1)
         got = ahead.render(cam, o, output=out, passes=1)
-        assert np.array_equal(got, want), "call %d" % k
+        assert np.array_equal(got, want), "call %d: %d pixels differ, max abs difference %.3e" % (k, int((got != want).any(axis=-1).sum()), float(np.abs(got - want).max()))
         if k == 2:
             assert np.array_equal(ahead.present(o), plain.present(o))       # the committed sum only, speculation intact
         if k == 6:

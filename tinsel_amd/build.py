@@ -23,8 +23,13 @@ OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if not f.startswith("_")] + \
        [os.path.join(ROOT, "include", "tinsel_hip.h")]
 
+# -fno-slp-vectorize: the SLP vectoriser pairs neighbouring fp32 multiplies / adds into v_pk_mul_f32 / v_pk_add_f32.  On gfx950 a
+# packed fp32 op takes as long as the two plain ones (scratch/ubench/valu_bench.hip: 4.9 vs 2 x 2.65 cycles) but wants its
+# operands in aligned register PAIRS: k_bounce carried 1,000 extra v_mov and 100-192 B of scratch for it, k_extend / k_shadow
+# 128 VGPRs instead of 98 / 77, k_walk 83 instead of 65.  Same arithmetic (a packed op rounds each half like the plain one),
+# measured: cornell 2894 -> 3056 Msamples/s, glass 1191 -> 1303, many_spheres 1430 -> 1648, the 524k-triangle config 2028 -> 2114.
 COMMON_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
 ]
 HIPCC_FLAGS = COMMON_FLAGS + ["-ffp-contract=off", "-fno-fast-math"]

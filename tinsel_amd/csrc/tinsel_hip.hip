@@ -350,6 +350,7 @@ struct tinsel_hip
     std::vector<tinsel_bvh_node> sceneBvhHost;
     size_t arenaOffNodes = 0, arenaOffBoxes = 0;
     int sceneStackNeed = 1;
+    bool sceneEnclosed = false;         // two planes face each other: (practically) no ray leaves the scene (k_bounce's shading pools stay off)
     int bvhMode = TINSEL_BVH_REFERENCE;
     int rrStart = 0;                    // > 0: Russian roulette from this bounce on (opt-in)
     std::vector<void*> lbvhAllocs;
@@ -389,6 +390,8 @@ struct tinsel_hip
     BinPrims walkPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };   // the subset of binPrims whose closest hits k_walk computes (large trees)
     int walkPrimMesh[7] = { 0, 0, 0, 0, 0, 0, 0 };         // DevScene::meshes index of each walked primitive
     float4* walkRec = nullptr;                          // k_walk's closest-hit records (tn_walk.h); batch-sized
+    uint32_t* walkOverflow = nullptr;                   // k_walk's stack entries beyond the LDS ones (TINSEL_HIP_WALK_LDS_STACK)
+    size_t walkOverflowCap = 0;
     bool walkEnabled = true;                            // TINSEL_HIP_NO_WALK: walk meshes inline in k_extend / k_shadow (A/B)
     unsigned long long* walkProf = nullptr;             // developer-only (-DTN_WALK_PROF builds): section counters of k_walk
     uint2* probeAlias = nullptr;                        // alias table of the probe (tinsel_hip_set_probe_sampling), built on first use
@@ -750,14 +753,23 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     job.leafMin = std::min(64, std::max(1, leafMin));
 
     const size_t ctl = kWalkCtlWords*sizeof(uint32_t);
-    const size_t stackBig = (size_t)entries*1024*sizeof(uint32_t);
-    const bool big = forceBlock ? forceBlock == 1024 : stackBig + ctl + 16384 <= (size_t)r->sharedMemLimit;
+    // TINSEL_HIP_WALK_LDS_STACK=n (A/B): n stack entries per lane in LDS, the rest of the deepest tree's need in HBM, and TWO
+    // 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs) sharing the CU's LDS
+    static const int ldsStackEnv = getenv("TINSEL_HIP_WALK_LDS_STACK") ? atoi(getenv("TINSEL_HIP_WALK_LDS_STACK")) : 0;
+    const bool twoPerCU = ldsStackEnv > 0 && !forceBlock;
+    const int ldsEntries = twoPerCU ? std::min(entries, std::max(1, ldsStackEnv)) : entries;
+    job.stackEntries = ldsEntries;
+    job.overflow = nullptr;
+    job.overflowEntries = 0;
+    const size_t stackBig = (size_t)ldsEntries*1024*sizeof(uint32_t);
+    const size_t ldsBudget = twoPerCU ? (size_t)r->sharedMemLimit/2 : (size_t)r->sharedMemLimit;
+    const bool big = forceBlock ? forceBlock == 1024 : stackBig + ctl + 16384 <= ldsBudget;
     const int block = big ? 1024 : 256;
-    size_t lds = (size_t)entries*block*sizeof(uint32_t) + ctl;
+    size_t lds = (size_t)ldsEntries*block*sizeof(uint32_t) + ctl;
     if (big)
     {
         // what is left of the CU's LDS goes to the tree tops, in primitive order
-        size_t room = ((size_t)r->sharedMemLimit - lds)/sizeof(Node64);
+        size_t room = (ldsBudget - lds)/sizeof(Node64);
         room = std::min<size_t>(room, (size_t)std::max(0, topLimit));
         for (int k = 0; k < r->walkPrims.count && room > 0; ++k)
         {
@@ -768,10 +780,33 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
         }
     }
     const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1)*(size_t)r->walkPrims.count;
-    const int perCU = big ? gridMult : gridMult*4;
+    const int perCU = big ? gridMult*(twoPerCU ? 2 : 1) : gridMult*4;
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
-    a.walkBig = big ? 1 : 0;
+    a.walkBig = big ? (twoPerCU ? 2 : 1) : 0;
     a.ldsBytes = (uint32_t)lds;
+    if (ldsEntries < entries)
+    {
+        const size_t need = (size_t)a.grid*(size_t)block*(size_t)(entries - ldsEntries);
+        if (r->walkOverflowCap < need)
+        {
+            if (r->walkOverflow)
+            {
+                (void)hipStreamSynchronize(st);
+                (void)hipFree(r->walkOverflow);
+            }
+            r->walkOverflow = nullptr;
+            r->walkOverflowCap = 0;
+            if (hipMalloc((void**)&r->walkOverflow, need*sizeof(uint32_t)) == hipSuccess)
+                r->walkOverflowCap = need;
+        }
+        job.overflow = r->walkOverflow;
+        job.overflowEntries = entries - ldsEntries;
+        if (!job.overflow)
+        {
+            fail("k_walk: no memory for the stack overflow");
+            return;
+        }
+    }
     ScopedTimer t(r, KN_WALK, st);
     launch_path(r, PK_WALK, a, st);
 }
@@ -944,22 +979,38 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             return -1;
         a.grid = gridPersist;
         // k_bounce closes ranks between the closest-hit trace and the shading half (the waves' shading pools, tn_kernels.h:
-        // 27 KB of LDS per workgroup) where the pools do not cost a resident workgroup: two per CU in the parity arm (2 waves
-        // per SIMD), three in the tolerance arm
+        // 27 KB of LDS per workgroup) where rays can LEAVE the scene -- veach 1515 -> 1866 Msamples/s, features 755 -> 865, env_loft
+        // 3598 -> 3793, gloss 7584 -> 7934; between two facing planes every ray hits something and the pools only cost (cornell
+        // 2919 -> 2894: not one ray of its 5.68 per sample misses) -- and where the pools do not cost a resident workgroup: two
+        // per CU in the parity arm (2 waves per SIMD), three in the tolerance arm
         {
-            static const bool noRepack = getenv("TINSEL_HIP_NO_REPACK") != nullptr;
+            static const char* repackEnv = getenv("TINSEL_HIP_REPACK");          // 0 / 1: never / always (A/B); default: open scenes
+            const bool want = repackEnv ? atoi(repackEnv) != 0 : !r->sceneEnclosed;
             const size_t withPool = (size_t)a.ldsBytes + kPoolWords*sizeof(uint32_t);
             const size_t perCU = 160u*1024u, blocksPerCU = r->arith == TINSEL_ARITH_FAST ? 3 : 2;
-            if (!noRepack && withPool*blocksPerCU <= perCU && withPool <= (size_t)r->sharedMemLimit)
+            if (want && withPool*blocksPerCU <= perCU && withPool <= (size_t)r->sharedMemLimit)
             {
                 a.fp.repack = 1;
                 a.ldsBytes = (uint32_t)withPool;
             }
         }
         static const bool noOrder = getenv("TINSEL_HIP_NO_REGION_ORDER") != nullptr;
+        // ONE launch takes every region through all the bounces (k_bounce, tn_kernels.h); TINSEL_HIP_BOUNCE_LAUNCHES=per: one
+        // launch per bounce with the regions longest first, as before (A/B)
+        static const bool perBounce = getenv("TINSEL_HIP_BOUNCE_LAUNCHES") && !strcmp(getenv("TINSEL_HIP_BOUNCE_LAUNCHES"), "per");
+        if (!perBounce)
+        {
+            a.bounce = 0;
+            a.bounceEnd = fp.maxDepth;
+            a.order = nullptr;
+            ScopedTimer t(r, KN_BOUNCE, st);
+            launch_path(r, PK_BOUNCE, a, st);
+        }
+        else
         for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
         {
             a.bounce = bounce;
+            a.bounceEnd = bounce + 1;
             a.order = nullptr;
             if (bounce > 0 && !noOrder && gridPersist > r->numCUs*2)
             {
@@ -1813,6 +1864,17 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                     planes += boxes[(size_t)k].alwaysHit ? 1 : 0;
                 sc.sortQueues = (sc.flatScan && planes <= 2 && planes < P && !getenv("TINSEL_HIP_NO_SORT_QUEUES")) ? 1 : 0;
             }
+            // two infinite planes with opposite normals (a floor and a ceiling): every ray between them that is not parallel to
+            // them hits one -- a scene no ray leaves, whatever else is in it (cornell.tin, glass.tin)
+            for (int i = 0; i < P && !r->sceneEnclosed; ++i)
+                for (int j = i + 1; j < P && !r->sceneEnclosed; ++j)
+                    if (prims[(size_t)i].type == kPrimPlane && prims[(size_t)j].type == kPrimPlane)
+                    {
+                        const Prim64 &a = prims[(size_t)i], &b = prims[(size_t)j];
+                        const float d = a.g0*b.g0 + a.g1*b.g1 + a.g2*b.g2;
+                        const float la = sqrtf(a.g0*a.g0 + a.g1*a.g1 + a.g2*a.g2), lb = sqrtf(b.g0*b.g0 + b.g1*b.g1 + b.g2*b.g2);
+                        r->sceneEnclosed = la > 0.0f && lb > 0.0f && d < -0.99f*la*lb;
+                    }
             bool all = sc.arenaLdsBytes != 0;
             for (const DevMesh& dmesh : meshes)
                 all = all && dmesh.inArena;
@@ -1897,6 +1959,7 @@ void tinsel_hip_destroy(tinsel_hip* r)
     if (r->workStream) (void)hipStreamDestroy(r->workStream);
     if (r->copyStream) (void)hipStreamDestroy(r->copyStream);
     if (r->probeAlias) (void)hipFree(r->probeAlias);
+    if (r->walkOverflow) (void)hipFree(r->walkOverflow);
     if (r->walkProf)
     {
         unsigned long long wp[16] = { 0 };
@@ -3340,18 +3403,11 @@ int tinsel_hip_group_render(tinsel_hip_group* g, const tinsel_camera* camera, co
         g->aheadInFlight = true;
         group_post(g, GJ_AHEAD);
     };
-    if (g->pinnedPtr)
-    {
-        HIP_TRY(hipMemcpyAsync(out_rgba, g->total, bytes, hipMemcpyDeviceToHost, g->copyStream));
-        post_ahead();
-        HIP_TRY(hipStreamSynchronize(g->copyStream));
-    }
-    else
-    {
-        post_ahead();                   // a copy to pageable memory blocks this thread: the workers start first
-        HIP_TRY(hipSetDevice(g->members[0].device));
-        HIP_TRY(hipMemcpy(out_rgba, g->total, bytes, hipMemcpyDeviceToHost));
-    }
+    // the workers start first, then this thread copies (a blocking copy either way: the call cannot return before its image
+    // is on the host; into a page-locked array it is one DMA, into a pageable one it is staged by the runtime)
+    post_ahead();
+    HIP_TRY(hipSetDevice(g->members[0].device));
+    HIP_TRY(hipMemcpy(out_rgba, g->total, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -482,8 +482,13 @@ TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slo
 #define TN_CTR_NEE ctr
 #endif
 
-template <bool COUNT, bool FIRST, bool LDS, bool DEFER>
-__global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries, CameraParams cam,
+// The launch covers the bounces [bounceBegin, bounceEnd).  A path never leaves its region and a region belongs to one wave (one
+// workgroup where its waves share): nothing a bounce reads was written outside the workgroup, so ONE launch can take its regions
+// through ALL the bounces of a batch -- no launch boundary and no tail between bounces (what a 1 M-path batch spends most of its
+// time in), no k_region_order launches; the dispatcher balances the workgroups over whole paths instead of over bounces.  Between
+// two bounces a workgroup-scope fence (and a barrier where waves share regions) orders the state stores before their loads.
+template <bool COUNT, bool LDS, bool DEFER>
+__global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scIn, SplitState ss, QueueCtl q, int bounceBegin, int bounceEnd, int stackEntries, CameraParams cam,
                                                    FrameParams fp, const uint32_t* __restrict__ passSeeds, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
@@ -497,7 +502,6 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
 
     const uint32_t lane = __lane_id();
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int cur = bounce & 1, nxt = cur ^ 1;
     const bool hasMedia = sc.hasMedia != 0;
     uint32_t rays = 0, shadowRays = 0, samples = 0;
     TraceCounters ctr = { 0, 0, 0 };
@@ -510,6 +514,18 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         const uint32_t r0 = (order ? order[b] : b)*kRegionsPerBlock;
         const uint32_t r = r0 + threadIdx.x/kWave;            // the region this wave generates / appends to
         const uint32_t base = r*ss.regionLen;
+      for (int bounce = bounceBegin; bounce < bounceEnd; ++bounce)
+      {
+        const bool FIRST = bounce == 0;
+        const int cur = bounce & 1, nxt = cur ^ 1;
+        if (bounce > bounceBegin)
+        {
+            // this workgroup's stores of the previous bounce (path state, region counts) before this bounce's loads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (sc.totalLightSamples >= 3)
+                __syncthreads();        // its waves read each other's regions (`share` below); wave-uniform for the whole grid
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         uint32_t nFront = 0, n;
         // bounces > 0 of scenes with several shadow rays per bounce: the live entries of the workgroup's four regions form ONE
         // stream, dealt to its waves round by round.  A workgroup holds its LDS and its wave slots until its last wave ends;
@@ -702,6 +718,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
             ss.segFront[(size_t)(bounce + 1)*ss.numRegions + r] = out.nFront;
             ss.segBack[(size_t)(bounce + 1)*ss.numRegions + r] = out.nBack;
         }
+      }
     }
 
     wave_add_stat(q.stats, 0, rays);

@@ -34,9 +34,10 @@ struct LaunchArgs
     const uint32_t* order;          // region groups, longest first (k_region_order; null: in index order)
     BinPrims bins;                  // primitives whose leaf-box test sorts the queues
     WalkJob walk;                   // PK_WALK
-    int walkBig;                    // PK_WALK: 1024-thread workgroups with an LDS-resident tree top, else 256-thread ones
+    int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
     int bounce;
+    int bounceEnd;                  // PK_BOUNCE: the launch covers the bounces [bounce, bounceEnd)
     int stackEntries;
     int countDetail;                // detail counters on: the COUNT kernel variants
     int grid;
@@ -100,26 +101,24 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             hipLaunchKernelGGL((k_shade<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order);
         break;
     case PK_BOUNCE:
-#define TN_LAUNCH_BOUNCE(FIRST, DEFER)                                                                                 \
+#define TN_LAUNCH_BOUNCE(DEFER)                                                                                        \
         do {                                                                                                           \
-            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, FIRST, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); \
-                         else hipLaunchKernelGGL((k_bounce<true, FIRST, false, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); } \
-            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, FIRST, true, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); \
-                         else hipLaunchKernelGGL((k_bounce<false, FIRST, false, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); } \
+            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); \
+                         else hipLaunchKernelGGL((k_bounce<true, false, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); } \
+            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, true, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); \
+                         else hipLaunchKernelGGL((k_bounce<false, false, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); } \
         } while (0)
         // (the detail-counting variants walk the scene BVH: nothing to defer)
         if (a.scene.deferMeshes)
-        {
-            if (a.bounce == 0) TN_LAUNCH_BOUNCE(true, true); else TN_LAUNCH_BOUNCE(false, true);
-        }
+            TN_LAUNCH_BOUNCE(true);
         else
-        {
-            if (a.bounce == 0) TN_LAUNCH_BOUNCE(true, false); else TN_LAUNCH_BOUNCE(false, false);
-        }
+            TN_LAUNCH_BOUNCE(false);
 #undef TN_LAUNCH_BOUNCE
         break;
     case PK_WALK:
-        if (a.walkBig)
+        if (a.walkBig == 2)
+            hipLaunchKernelGGL((k_walk<1024, 8>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
+        else if (a.walkBig)
             hipLaunchKernelGGL((k_walk<1024, 4>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
         else
             hipLaunchKernelGGL((k_walk<256, 5>), grid, dim3(256), a.ldsBytes, st, a.scene, a.walk);
@@ -133,11 +132,11 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
 inline void prepare_path_kernels(int sharedMemLimit)
 {
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+    (void)hipFuncSetAttribute((const void*)k_walk<1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_walk<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
-#define TN_PREP_BOUNCE(C, F, L, D) (void)hipFuncSetAttribute((const void*)k_bounce<C, F, L, D>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
-    TN_PREP_BOUNCE(true, true, true, false); TN_PREP_BOUNCE(true, true, false, false); TN_PREP_BOUNCE(true, false, true, false); TN_PREP_BOUNCE(true, false, false, false);
-    TN_PREP_BOUNCE(false, true, true, false); TN_PREP_BOUNCE(false, true, false, false); TN_PREP_BOUNCE(false, false, true, false); TN_PREP_BOUNCE(false, false, false, false);
-    TN_PREP_BOUNCE(false, true, true, true); TN_PREP_BOUNCE(false, true, false, true); TN_PREP_BOUNCE(false, false, true, true); TN_PREP_BOUNCE(false, false, false, true);
+#define TN_PREP_BOUNCE(C, L, D) (void)hipFuncSetAttribute((const void*)k_bounce<C, L, D>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
+    TN_PREP_BOUNCE(true, true, false); TN_PREP_BOUNCE(true, false, false);
+    TN_PREP_BOUNCE(false, true, false); TN_PREP_BOUNCE(false, false, false); TN_PREP_BOUNCE(false, true, true); TN_PREP_BOUNCE(false, false, true);
 #undef TN_PREP_BOUNCE
 }
 

@@ -14,9 +14,23 @@
 
 namespace tn {
 
+// eight 16-B loads in flight per lane, then eight stores; consecutive lanes on consecutive float4s (the guide's streaming shape)
 __global__ __launch_bounds__(256) void k_ub_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n)
 {
-    for (size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x)
+    constexpr int kUnroll = 8;
+    const size_t stride = (size_t)gridDim.x*blockDim.x;
+    size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+    for (; i + (kUnroll - 1)*stride < n; i += kUnroll*stride)
+    {
+        float4 v[kUnroll];
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k)
+            v[k] = in[i + (size_t)k*stride];
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k)
+            out[i + (size_t)k*stride] = v[k];
+    }
+    for (; i < n; i += stride)
         out[i] = in[i];
 }
 

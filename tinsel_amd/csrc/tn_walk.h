@@ -54,7 +54,9 @@ struct WalkJob
     int numPrims;                   // walked primitives (1..7)
     int prim[kWalkMaxPrims];
     int topCount[kWalkMaxPrims];    // Node64 records of each walked primitive's tree staged into LDS (a prefix: breadth-first order)
-    int stackEntries;               // LDS stack entries per lane (deepest walked tree)
+    int stackEntries;               // LDS stack entries per lane (the deepest walked tree's need, or fewer: see overflow)
+    uint32_t* overflow;             // [lane of the grid][overflowEntries]: stack entries beyond the LDS ones (null: the LDS stack holds the deepest tree)
+    int overflowEntries;
     int refillMin;                  // idle lanes that trigger a refill from the workgroup's range
     int leafMin;                    // lanes waiting at a triangle that trigger the triangle phase
     unsigned long long* prof;       // developer-only (-DTN_WALK_PROF): per-section wave cycles and event counts
@@ -130,6 +132,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_walk[];
     uint32_t* const stack = s_walk + threadIdx.x;               // this lane's column: entry i at stack[i*BLOCK]
+    // a SHORT LDS stack leaves room for a second workgroup per CU (8 waves per SIMD at 64 VGPRs): the rare entries beyond it
+    // live in HBM, a column per lane of the grid
+    uint32_t* const spill = job.overflow ? job.overflow + ((size_t)blockIdx.x*BLOCK + threadIdx.x)*(size_t)job.overflowEntries : nullptr;
+    const int ldsEntries = job.stackEntries;
     uint32_t* const s_ctl = s_walk + job.stackEntries*BLOCK;    // [0] the workgroup's cursor
     WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_ctl + kWalkCtlWords);
 
@@ -370,7 +376,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
             {
                 // the reference pushes far then near and pops near: the near child continues in a register
                 const bool leftNear = tL < tR;
-                stack[sp*BLOCK] = leftNear ? nd.right : nd.left;
+                const uint32_t far = leftNear ? nd.right : nd.left;
+                if (sp < ldsEntries)
+                    stack[sp*BLOCK] = far;
+                else
+                    spill[sp - ldsEntries] = far;
                 ++sp;
                 ref = leftNear ? nd.left : nd.right;
             }
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
             if (sp > 0)
             {
                 --sp;
-                ref = stack[sp*BLOCK];
+                ref = sp < ldsEntries ? stack[sp*BLOCK] : spill[sp - ldsEntries];
             }
             else
             {
