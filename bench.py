@@ -219,7 +219,7 @@ def inner_pmc(args):
 
 def calibrate(pmc):
     """Bytes one count of FETCH_SIZE / WRITE_SIZE (KB units) stands for, from the yard-stick kernels of the same passes.
-    k_ub_copy launches twice (warm-up + timed) and reads / writes UB_COPY_BYTES each time; k_ub_gather<0> visits
+    every k_ub_copy launch (a few shapes, warm-up + timed each) reads and writes UB_COPY_BYTES; k_ub_gather<0> visits
     grid*256*UB_STEPS records of 64 B per launch, all of them misses down to HBM (1 GiB table)."""
     cal = {"stream_bytes_per_fetch_count": None, "gather_bytes_per_fetch_count": None, "bytes_per_write_count": None}
     f, w = pmc.get("fetch") or {}, pmc.get("write") or {}

@@ -45,8 +45,10 @@ namespace tn {
 #ifndef TN_WAVES_SCAN_EXTEND
 #define TN_WAVES_SCAN_EXTEND 4
 #endif
+// (without the SLP vectoriser -- tinsel_amd/build.py -- the trace kernels need 77-100 VGPRs: at 5 waves glass's k_extend 6.5 -> 5.7
+// ms, many_spheres' 10.4 -> 9.5; at 6 it spills, 11.6)
 #ifndef TN_WAVES_TRACE
-#define TN_WAVES_TRACE 4
+#define TN_WAVES_TRACE 5
 #endif
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
@@ -85,6 +87,7 @@ struct FrameParams
     uint32_t genCount;                  // camera paths the generation kernels enumerate per batch (gen_slot)
     int rrStart;                        // > 0: Russian roulette from this bounce on (opt-in, not the reference's behaviour)
     int repack;                         // k_bounce: paths that hit a surface close ranks (per-wave LDS pool) before the shading half
+    uint32_t groupStep;                 // k_bounce over all bounces: workgroup b takes region group (b*groupStep) mod groups (coprime; 1: in order)
     int filterType;
     float filterWidth, filterFalloff, filterOffset;
     float clampLen;
@@ -511,7 +514,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
     // (one workgroup per group of four regions; `order`: the groups with the most live entries first, k_region_order)
     for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
-        const uint32_t r0 = (order ? order[b] : b)*kRegionsPerBlock;
+        // (one launch over all bounces: the dispatcher hands out workgroups in index order and paths die in patches of the image
+        // -- a golden-section step between consecutive workgroups' region groups gives every stretch of the launch the same
+        // mix of long-lived and short-lived regions, as k_walk's work list does)
+        const uint32_t groups = ss.numRegions/kRegionsPerBlock;
+        const uint32_t r0 = (order ? order[b] : (b*fp.groupStep) % groups)*kRegionsPerBlock;      // (both below 2^16: checked by the host)
         const uint32_t r = r0 + threadIdx.x/kWave;            // the region this wave generates / appends to
         const uint32_t base = r*ss.regionLen;
       for (int bounce = bounceBegin; bounce < bounceEnd; ++bounce)

@@ -14,21 +14,29 @@
 
 namespace tn {
 
-// eight 16-B loads in flight per lane, then eight stores; consecutive lanes on consecutive float4s (the guide's streaming shape)
-__global__ __launch_bounds__(256) void k_ub_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n)
+// eight 16-B loads in flight per lane, then eight stores; consecutive lanes on consecutive float4s (the guide's streaming shape);
+// NT: non-temporal loads and stores (a stream that nobody re-reads need not displace what the caches hold)
+typedef float UbCopyF4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void k_ub_copy(const float4* __restrict__ inV, float4* __restrict__ outV, size_t n)
 {
+    const UbCopyF4* in = reinterpret_cast<const UbCopyF4*>(inV);
+    UbCopyF4* out = reinterpret_cast<UbCopyF4*>(outV);
     constexpr int kUnroll = 8;
     const size_t stride = (size_t)gridDim.x*blockDim.x;
     size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
     for (; i + (kUnroll - 1)*stride < n; i += kUnroll*stride)
     {
-        float4 v[kUnroll];
+        UbCopyF4 v[kUnroll];
 #pragma unroll
         for (int k = 0; k < kUnroll; ++k)
-            v[k] = in[i + (size_t)k*stride];
+            v[k] = NT ? __builtin_nontemporal_load(in + i + (size_t)k*stride) : in[i + (size_t)k*stride];
 #pragma unroll
         for (int k = 0; k < kUnroll; ++k)
-            out[i + (size_t)k*stride] = v[k];
+        {
+            if (NT) __builtin_nontemporal_store(v[k], out + i + (size_t)k*stride);
+            else out[i + (size_t)k*stride] = v[k];
+        }
     }
     for (; i < n; i += stride)
         out[i] = in[i];
