@@ -517,6 +517,10 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
         if (batch_alloc(r, &r->walkRec, cap*(size_t)(K > 1 ? K : 1)*(size_t)r->walkPrims.count*2) || batch_alloc(r, &r->walkList, cap) ||
             batch_alloc(r, &r->segPrefix, maxRegions + 1))
             return -1;
+    // k_swalk's list (scenes the flat scan cannot take): the same two arrays (such scenes have no walked primitives)
+    if (!r->walkList && !r->scene.flatScan)
+        if (batch_alloc(r, &r->walkList, cap) || batch_alloc(r, &r->segPrefix, maxRegions + 1))
+            return -1;
     return 0;
 }
 
@@ -729,7 +733,7 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     }
     {
         ScopedTimer t(r, KN_SEG, st);
-        hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, regionCounts, ss.numRegions, step, r->segPrefix);
+        hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, regionCounts, (const uint32_t*)nullptr, ss.numRegions, step, r->segPrefix);
         hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
     }
     WalkJob& job = a.walk;
@@ -815,6 +819,37 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     }
     ScopedTimer t(r, KN_WALK, st);
     launch_path(r, PK_WALK, a, st);
+}
+
+// k_swalk (tn_swalk.h): the scene-level walk with ray replacement, for scenes the flat scan cannot take.  The list: every live
+// entry of every region (front and back), regions in index order -- the workgroups' static ranges are image patches, coherent rays.
+void launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* front, const uint32_t* back, bool shadowRays)
+{
+    static const int refillMin = getenv("TINSEL_HIP_SWALK_REFILL") ? atoi(getenv("TINSEL_HIP_SWALK_REFILL")) : 16;
+    static const int leafMin = getenv("TINSEL_HIP_SWALK_LEAFMIN") ? atoi(getenv("TINSEL_HIP_SWALK_LEAFMIN")) : 16;
+    static const int gridMult = getenv("TINSEL_HIP_SWALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_SWALK_GRID_MULT")) : 8;
+    static const int stepEnv = getenv("TINSEL_HIP_SWALK_LIST_STEP") ? atoi(getenv("TINSEL_HIP_SWALK_LIST_STEP")) : 1;
+    const SplitState& ss = a.ss;
+    uint32_t step = (uint32_t)std::max(1, stepEnv);
+    if (step >= ss.numRegions || ss.numRegions > 65535u)
+        step = 1;
+    {
+        ScopedTimer t(r, KN_SEG, st);
+        hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, front, back, ss.numRegions, step, r->segPrefix);
+        hipLaunchKernelGGL(k_seg_expand_all, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, front, back, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
+    }
+    SwalkJob& job = a.swalk;
+    job.list = r->walkList;
+    job.count = r->segPrefix + ss.numRegions;
+    job.neePerPath = shadowRays ? r->neePerPath : 0;
+    job.stackEntries = r->stackNeed;
+    job.refillMin = std::min(64, std::max(1, refillMin));
+    job.leafMin = std::min(64, std::max(1, leafMin));
+    const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1);
+    a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + kBlock - 1)/kBlock, (size_t)r->numCUs*(size_t)std::max(1, gridMult)));
+    a.ldsBytes = (uint32_t)(((size_t)r->stackNeed*kBlock + kSwalkCtlWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes);
+    ScopedTimer t(r, shadowRays ? KN_SHADOW : KN_EXTEND, st);
+    launch_path(r, shadowRays ? PK_SWALK_SHADOW : PK_SWALK_EXTEND, a, st);
 }
 
 void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
@@ -1011,7 +1046,10 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             a.bounceEnd = fp.maxDepth;
             a.order = nullptr;
             {
-                static const int stepEnv = getenv("TINSEL_HIP_BOUNCE_GROUP_STEP") ? atoi(getenv("TINSEL_HIP_BOUNCE_GROUP_STEP")) : 0;
+                // workgroup b takes region group (b*step) mod groups.  Index order (step 1) is the default: a golden-section step,
+                // which k_walk's static ranges need, loses here -- the dispatcher already hands workgroups out dynamically
+                // (veach 1970 -> 1904 Msamples/s, features 898 -> 880, cornell 2999 -> 2979, env_loft 3812 -> 3820)
+                static const int stepEnv = getenv("TINSEL_HIP_BOUNCE_GROUP_STEP") ? atoi(getenv("TINSEL_HIP_BOUNCE_GROUP_STEP")) : 1;
                 const uint32_t groups = a.ss.numRegions/kRegionsPerBlock;
                 uint32_t step = stepEnv > 0 ? (uint32_t)stepEnv : (uint32_t)(groups*0.6180339887) | 1u;
                 auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
@@ -1074,6 +1112,10 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         static const bool noOrder = getenv("TINSEL_HIP_NO_REGION_ORDER") != nullptr;
         // (not where k_walk does the walking: what is left for the scan kernels is too short for the two extra launches per
         // bounce to pay -- glass 1087 -> 1077, config 3 1891 -> 1881; many_spheres, scene BVH walked inline, 1168 -> 1290)
+        // scenes the flat scan cannot take (more than 64 primitives): the scene-level walk with ray replacement (k_swalk, tn_swalk.h)
+        // in the place of k_extend / k_shadow; the detail counters count the inline walks
+        static const bool noSceneWalk = getenv("TINSEL_HIP_NO_SCENE_WALK") != nullptr;
+        const bool sceneWalk = !noSceneWalk && !r->scene.flatScan && !r->countDetail && r->walkList != nullptr && !walk;
         const bool ordered = !noOrder && !walk && gridPersist > r->numCUs*2;
         auto order_regions = [&](const uint32_t* front, const uint32_t* back, uint32_t* out) {
             ScopedTimer t(r, KN_SEG, st);
@@ -1096,6 +1138,12 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 a.grid = gridPersist;
                 launch_walk(r, st, a, r->ss.segFront + (size_t)bounce*W, false);
             }
+            if (sceneWalk)
+            {
+                a.grid = gridPersist;
+                launch_swalk(r, st, a, r->ss.segFront + (size_t)bounce*W, r->ss.segBack + (size_t)bounce*W, false);
+            }
+            else
             {
                 ScopedTimer t(r, KN_EXTEND, st);
                 a.grid = gridTrace;
@@ -1117,17 +1165,25 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                     a.grid = gridPersist;
                     launch_walk(r, st, a, r->ss.neeFront + (size_t)bounce*W, true);
                 }
-                if (ordered && bounce > 0)
+                if (sceneWalk)
                 {
-                    order_regions(r->ss.neeFront + (size_t)bounce*W, r->ss.neeBack + (size_t)bounce*W, r->regionOrderNee);
-                    a.order = r->regionOrderNee;
+                    a.grid = gridPersist;
+                    launch_swalk(r, st, a, r->ss.neeFront + (size_t)bounce*W, r->ss.neeBack + (size_t)bounce*W, true);
                 }
-                ScopedTimer t(r, KN_SHADOW, st);
-                a.grid = gridTrace;
-                a.ldsBytes = ldsTrace;
-                a.stackEntries = stackScan;
-                launch_path(r, PK_SHADOW, a, st);
-                a.order = pathOrder;
+                else
+                {
+                    if (ordered && bounce > 0)
+                    {
+                        order_regions(r->ss.neeFront + (size_t)bounce*W, r->ss.neeBack + (size_t)bounce*W, r->regionOrderNee);
+                        a.order = r->regionOrderNee;
+                    }
+                    ScopedTimer t(r, KN_SHADOW, st);
+                    a.grid = gridTrace;
+                    a.ldsBytes = ldsTrace;
+                    a.stackEntries = stackScan;
+                    launch_path(r, PK_SHADOW, a, st);
+                    a.order = pathOrder;
+                }
             }
             {
                 ScopedTimer t(r, KN_SHADE, st);
@@ -2778,14 +2834,23 @@ int tinsel_hip_ubench(int device_index, int kind, unsigned long long bytes, int 
             rc = fail("ubench: allocation failed");
         else
         {
-            // the best of a few shapes (workgroups per CU x plain / non-temporal): what this chip sustains, not what one shape gets
+            // the best of a few shapes (workgroups per CU x interleaved / workgroup-contiguous x plain / non-temporal): what this chip sustains, not what one shape gets
             float best = 0.0f;
-            for (int shape = 0; shape < 6 && !rc; ++shape)
+            for (int shape = 0; shape < 12 && !rc; ++shape)
             {
                 const unsigned grid = (unsigned)prop.multiProcessorCount*(shape % 3 == 0 ? 8u : shape % 3 == 1 ? 16u : 32u);
+                const bool contig = (shape/3) % 2 == 1 && n % ((size_t)grid*256*8) == 0;
                 auto launch = [&] {
-                    if (shape < 3) hipLaunchKernelGGL((k_ub_copy<false>), dim3(grid), dim3(256), 0, nullptr, (const float4*)in, out, n);
-                    else hipLaunchKernelGGL((k_ub_copy<true>), dim3(grid), dim3(256), 0, nullptr, (const float4*)in, out, n);
+                    if (shape < 6)
+                    {
+                        if (contig) hipLaunchKernelGGL((k_ub_copy<false, true>), dim3(grid), dim3(256), 0, nullptr, (const float4*)in, out, n);
+                        else hipLaunchKernelGGL((k_ub_copy<false, false>), dim3(grid), dim3(256), 0, nullptr, (const float4*)in, out, n);
+                    }
+                    else
+                    {
+                        if (contig) hipLaunchKernelGGL((k_ub_copy<true, true>), dim3(grid), dim3(256), 0, nullptr, (const float4*)in, out, n);
+                        else hipLaunchKernelGGL((k_ub_copy<true, false>), dim3(grid), dim3(256), 0, nullptr, (const float4*)in, out, n);
+                    }
                 };
                 launch();
                 (void)hipEventRecord(e0, nullptr);

@@ -1243,7 +1243,9 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
 // k_seg_expand: region r writes base_r + i at prefix[r] + i.
 constexpr int kSegBlock = 1024;
 
-__global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __restrict__ counts, uint32_t numRegions, uint32_t step, uint32_t* __restrict__ prefix)
+// (counts2: a second array added to the first -- front + back counts: every live entry, k_swalk's list; null: the front entries only)
+__global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ counts2, uint32_t numRegions, uint32_t step,
+                                                          uint32_t* __restrict__ prefix)
 {
     constexpr uint32_t kWaves = kSegBlock/kWave;
     __shared__ uint32_t s_wave[kWaves];
@@ -1256,9 +1258,10 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
     // the list visits the regions `step` apart (coprime to their number): entry i of the scan is region i*step mod numRegions
     // (numRegions <= 65535, checked by the host: the product fits 32 bits)
     auto region = [&](uint32_t i) -> uint32_t { return (i*step) % numRegions; };
+    auto count = [&](uint32_t r) -> uint32_t { return counts[r] + (counts2 ? counts2[r] : 0u); };
     uint32_t sum = 0;
     for (uint32_t i = begin + lane; i < end; i += kWave)
-        sum += counts[region(i)];
+        sum += count(region(i));
     for (int off = 32; off > 0; off >>= 1)
         sum += __shfl_xor(sum, off);
     if (lane == 0)
@@ -1274,7 +1277,7 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
     for (uint32_t i0 = begin; i0 < end; i0 += kWave)
     {
         const uint32_t i = i0 + lane;
-        const uint32_t v = i < end ? counts[region(i)] : 0u;
+        const uint32_t v = i < end ? count(region(i)) : 0u;
         uint32_t x = v;                                   // inclusive scan across the wave
         for (int off = 1; off < kWave; off <<= 1)
         {
@@ -1300,6 +1303,10 @@ __global__ __launch_bounds__(kBlock) void k_seg_expand(const uint32_t* __restric
             list[at + i] = r*regionLen + i;
     }
 }
+
+} // namespace tn
+#include "tn_swalk.h"
+namespace tn {
 
 // ---------------------------------------------------------------------------
 // k_mega: the A/B arm -- one lane walks one whole path (render.cpp:230-388), same pieces.

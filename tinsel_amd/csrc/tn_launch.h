@@ -17,7 +17,7 @@ namespace tn {
 
 enum PathKernel : int
 {
-    PK_GENERATE = 0, PK_EXTEND, PK_SHADE, PK_SHADOW, PK_BOUNCE, PK_MEGA, PK_WALK, PK_LIGHTS,
+    PK_GENERATE = 0, PK_EXTEND, PK_SHADE, PK_SHADOW, PK_BOUNCE, PK_MEGA, PK_WALK, PK_LIGHTS, PK_SWALK_EXTEND, PK_SWALK_SHADOW,
 };
 
 struct LaunchArgs
@@ -34,6 +34,7 @@ struct LaunchArgs
     const uint32_t* order;          // region groups, longest first (k_region_order; null: in index order)
     BinPrims bins;                  // primitives whose leaf-box test sorts the queues
     WalkJob walk;                   // PK_WALK
+    SwalkJob swalk;                 // PK_SWALK_*
     int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
     int bounce;
@@ -115,6 +116,12 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             TN_LAUNCH_BOUNCE(false);
 #undef TN_LAUNCH_BOUNCE
         break;
+    case PK_SWALK_EXTEND:
+        hipLaunchKernelGGL((k_swalk<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.swalk);
+        break;
+    case PK_SWALK_SHADOW:
+        hipLaunchKernelGGL((k_swalk<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.swalk);
+        break;
     case PK_WALK:
         if (a.walkBig == 2)
             hipLaunchKernelGGL((k_walk<1024, 8>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
@@ -133,6 +140,8 @@ inline void prepare_path_kernels(int sharedMemLimit)
 {
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+    (void)hipFuncSetAttribute((const void*)k_swalk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+    (void)hipFuncSetAttribute((const void*)k_swalk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_walk<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
 #define TN_PREP_BOUNCE(C, L, D) (void)hipFuncSetAttribute((const void*)k_bounce<C, L, D>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
     TN_PREP_BOUNCE(true, true, false); TN_PREP_BOUNCE(true, false, false);

@@ -17,15 +17,18 @@ namespace tn {
 // eight 16-B loads in flight per lane, then eight stores; consecutive lanes on consecutive float4s (the guide's streaming shape);
 // NT: non-temporal loads and stores (a stream that nobody re-reads need not displace what the caches hold)
 typedef float UbCopyF4 __attribute__((ext_vector_type(4)));
-template <bool NT>
+template <bool NT, bool CONTIG>
 __global__ __launch_bounds__(256) void k_ub_copy(const float4* __restrict__ inV, float4* __restrict__ outV, size_t n)
 {
     const UbCopyF4* in = reinterpret_cast<const UbCopyF4*>(inV);
     UbCopyF4* out = reinterpret_cast<UbCopyF4*>(outV);
     constexpr int kUnroll = 8;
-    const size_t stride = (size_t)gridDim.x*blockDim.x;
-    size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
-    for (; i + (kUnroll - 1)*stride < n; i += kUnroll*stride)
+    // CONTIG: a workgroup's eight loads are eight consecutive 4-KB rows (32 KB contiguous per workgroup and step); else the whole
+    // grid sweeps one row per load
+    const size_t stride = CONTIG ? (size_t)blockDim.x : (size_t)gridDim.x*blockDim.x;
+    const size_t jump = CONTIG ? (size_t)gridDim.x*blockDim.x*kUnroll : stride*kUnroll;
+    size_t i = CONTIG ? (size_t)blockIdx.x*blockDim.x*kUnroll + threadIdx.x : (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+    for (; i + (kUnroll - 1)*stride < n; i += jump)
     {
         UbCopyF4 v[kUnroll];
 #pragma unroll
@@ -38,8 +41,9 @@ __global__ __launch_bounds__(256) void k_ub_copy(const float4* __restrict__ inV,
             else out[i + (size_t)k*stride] = v[k];
         }
     }
-    for (; i < n; i += stride)
-        out[i] = in[i];
+    if (!CONTIG)
+        for (; i < n; i += stride)
+            out[i] = in[i];     // (the CONTIG shapes are launched on sizes that divide evenly)
 }
 
 // record i: 16 floats, the link to the next record of its chain in word 12.  next(i) = (a*i + c) mod nrec with nrec a power
