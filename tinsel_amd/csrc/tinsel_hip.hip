@@ -825,14 +825,22 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
 // entry of every region (front and back), regions in index order -- the workgroups' static ranges are image patches, coherent rays.
 void launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* front, const uint32_t* back, bool shadowRays)
 {
-    static const int refillMin = getenv("TINSEL_HIP_SWALK_REFILL") ? atoi(getenv("TINSEL_HIP_SWALK_REFILL")) : 16;
+    static const int refillMin = getenv("TINSEL_HIP_SWALK_REFILL") ? atoi(getenv("TINSEL_HIP_SWALK_REFILL")) : 32;
     static const int leafMin = getenv("TINSEL_HIP_SWALK_LEAFMIN") ? atoi(getenv("TINSEL_HIP_SWALK_LEAFMIN")) : 16;
-    static const int gridMult = getenv("TINSEL_HIP_SWALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_SWALK_GRID_MULT")) : 8;
-    static const int stepEnv = getenv("TINSEL_HIP_SWALK_LIST_STEP") ? atoi(getenv("TINSEL_HIP_SWALK_LIST_STEP")) : 1;
+    static const int gridMultEnv = getenv("TINSEL_HIP_SWALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_SWALK_GRID_MULT")) : 0;
+    static const int stepEnv = getenv("TINSEL_HIP_SWALK_LIST_STEP") ? atoi(getenv("TINSEL_HIP_SWALK_LIST_STEP")) : 0;
+    static const bool noLds = getenv("TINSEL_HIP_SWALK_NO_LDS") != nullptr;
     const SplitState& ss = a.ss;
-    uint32_t step = (uint32_t)std::max(1, stepEnv);
-    if (step >= ss.numRegions || ss.numRegions > 65535u)
-        step = 1;
+    // the list visits the regions a golden-section step apart: every workgroup's static range gets the same mix of rays
+    // (k_walk's lesson; in index order a 256-thread grid of 8 workgroups per CU took 14.4 ms where 32 per CU took 9.2)
+    uint32_t step = stepEnv > 0 ? (uint32_t)stepEnv : (uint32_t)(ss.numRegions*0.6180339887) | 1u;
+    {
+        auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
+        while (step > 1 && gcd(step, ss.numRegions) != 1)
+            step -= 1;
+        if (step >= ss.numRegions || ss.numRegions > 65535u)
+            step = 1;
+    }
     {
         ScopedTimer t(r, KN_SEG, st);
         hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, front, back, ss.numRegions, step, r->segPrefix);
@@ -845,9 +853,24 @@ void launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* f
     job.stackEntries = r->stackNeed;
     job.refillMin = std::min(64, std::max(1, refillMin));
     job.leafMin = std::min(64, std::max(1, leafMin));
+    // the whole arena beside the stacks of a 1024-thread workgroup?
+    const size_t bigLds = ((size_t)r->stackNeed*1024 + kSwalkCtlWords)*sizeof(uint32_t) + r->scene.arenaBytes;
+    const bool big = !noLds && bigLds <= (size_t)r->sharedMemLimit;
+    bool allInArena = true;
+    for (const DevMesh& dm : r->meshesNow)
+        allInArena = allInArena && dm.inArena;
+    a.swalkMode = big ? (allInArena ? 1 : 2) : 0;
+    const int block = big ? 1024 : kBlock;
+    const int gridMult = gridMultEnv > 0 ? gridMultEnv : (big ? 1 : 32);
     const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1);
-    a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + kBlock - 1)/kBlock, (size_t)r->numCUs*(size_t)std::max(1, gridMult)));
-    a.ldsBytes = (uint32_t)(((size_t)r->stackNeed*kBlock + kSwalkCtlWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes);
+    a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)gridMult));
+    if (big)
+    {
+        a.scene.arenaLdsBytes = a.scene.arenaBytes;
+        a.ldsBytes = (uint32_t)bigLds;
+    }
+    else
+        a.ldsBytes = (uint32_t)(((size_t)r->stackNeed*kBlock + kSwalkCtlWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes);
     ScopedTimer t(r, shadowRays ? KN_SHADOW : KN_EXTEND, st);
     launch_path(r, shadowRays ? PK_SWALK_SHADOW : PK_SWALK_EXTEND, a, st);
 }

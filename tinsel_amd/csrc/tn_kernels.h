@@ -126,7 +126,7 @@ TN_D void wave_add_stat(unsigned long long* stats, int word, uint32_t v)
 //                 load of an LDS aperture address.
 // MUST be reached by every thread of the block.
 template <bool LDS, bool WONLY, int DEFER, bool MIXED>
-TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER, MIXED>& sc, const DevScene& in, uint32_t* ldsWords)
+TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER, MIXED>& sc, const DevScene& in, uint32_t* ldsWords, uint32_t blockSize = kBlock)
 {
     static_cast<DevScene&>(sc) = in;
     unsigned char* lds = reinterpret_cast<unsigned char*>(ldsWords);
@@ -141,7 +141,7 @@ TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER, MIXED>& sc, const DevScene& 
     const float4* src = reinterpret_cast<const float4*>(in.arena);
     float4* dst = reinterpret_cast<float4*>(lds);
     const uint32_t n16 = (LDS ? in.arenaBytes : in.arenaLdsBytes)/16u;
-    for (uint32_t i = threadIdx.x; i < n16; i += kBlock)
+    for (uint32_t i = threadIdx.x; i < n16; i += blockSize)
         dst[i] = src[i];
     __syncthreads();
 
@@ -152,7 +152,7 @@ TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER, MIXED>& sc, const DevScene& 
     if (!LDS)
     {
         DevMesh* lm = reinterpret_cast<DevMesh*>(lds + (reinterpret_cast<const unsigned char*>(in.meshes) - g0));
-        for (int i = threadIdx.x; i < in.numMeshes; i += kBlock)
+        for (int i = threadIdx.x; i < in.numMeshes; i += (int)blockSize)
         {
             if (lm[i].inArena)
             {

@@ -35,6 +35,7 @@ struct LaunchArgs
     BinPrims bins;                  // primitives whose leaf-box test sorts the queues
     WalkJob walk;                   // PK_WALK
     SwalkJob swalk;                 // PK_SWALK_*
+    int swalkMode;                  // PK_SWALK_*: 0 = 256-thread workgroups, generic pointers; 1 / 2 = 1024-thread workgroups, arena in LDS (2: meshes in HBM too)
     int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
     int bounce;
@@ -117,10 +118,15 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
 #undef TN_LAUNCH_BOUNCE
         break;
     case PK_SWALK_EXTEND:
-        hipLaunchKernelGGL((k_swalk<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.swalk);
-        break;
     case PK_SWALK_SHADOW:
-        hipLaunchKernelGGL((k_swalk<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.swalk);
+#define TN_LAUNCH_SWALK(SH)                                                                                            \
+        do {                                                                                                           \
+            if (a.swalkMode == 1) hipLaunchKernelGGL((k_swalk<SH, 1024, 1>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.swalk); \
+            else if (a.swalkMode == 2) hipLaunchKernelGGL((k_swalk<SH, 1024, 2>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.swalk); \
+            else hipLaunchKernelGGL((k_swalk<SH, 256, 0>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.swalk); \
+        } while (0)
+        if (which == PK_SWALK_SHADOW) TN_LAUNCH_SWALK(true); else TN_LAUNCH_SWALK(false);
+#undef TN_LAUNCH_SWALK
         break;
     case PK_WALK:
         if (a.walkBig == 2)
@@ -140,8 +146,11 @@ inline void prepare_path_kernels(int sharedMemLimit)
 {
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
-    (void)hipFuncSetAttribute((const void*)k_swalk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
-    (void)hipFuncSetAttribute((const void*)k_swalk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+#define TN_PREP_SWALK(SH) (void)hipFuncSetAttribute((const void*)k_swalk<SH, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
+                          (void)hipFuncSetAttribute((const void*)k_swalk<SH, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
+                          (void)hipFuncSetAttribute((const void*)k_swalk<SH, 256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
+    TN_PREP_SWALK(false); TN_PREP_SWALK(true);
+#undef TN_PREP_SWALK
     (void)hipFuncSetAttribute((const void*)k_walk<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
 #define TN_PREP_BOUNCE(C, L, D) (void)hipFuncSetAttribute((const void*)k_bounce<C, L, D>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
     TN_PREP_BOUNCE(true, true, false); TN_PREP_BOUNCE(true, false, false);

@@ -43,15 +43,20 @@ __global__ __launch_bounds__(kBlock) void k_seg_expand_all(const uint32_t* __res
     }
 }
 
-template <bool SHADOW>
-__global__ __launch_bounds__(kBlock, TN_WAVES_SWALK) void k_swalk(DevScene scIn, SplitState ss, QueueCtl q, int bounce, SwalkJob job)
+// BLOCK / LDSMODE: 1024-thread workgroups (one per CU) whose LDS holds the stacks AND the whole scene arena -- the scene BVH, the
+// primitive and material records: a node visit is four ds_read_b128 instead of four global loads, and the walk of an
+// L1-resident tree is bound by the rate a CU's vector-memory front end retires records (tn_walk.h) -- with every scene access at a
+// compile-time LDS address (1: every mesh rides in the arena too; 2: some meshes live in HBM); 0: 256-thread workgroups and
+// generic pointers, for arenas that do not fit beside the stacks.
+template <bool SHADOW, int BLOCK, int LDSMODE>
+__global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : TN_WAVES_SWALK) void k_swalk(DevScene scIn, SplitState ss, QueueCtl q, int bounce, SwalkJob job)
 {
-    extern __shared__ uint32_t s_sw[];          // [stackEntries][kBlock] stack words, control words, the staged arena (if any)
-    LdsStack<kBlock> st = { s_sw + threadIdx.x };
-    uint32_t* const s_ctl = s_sw + job.stackEntries*kBlock;
-    typedef SceneT<false, false, 2, false> SC;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_sw[];     // [stackEntries][BLOCK] stack words, control words, the staged arena (if any)
+    LdsStack<BLOCK> st = { s_sw + threadIdx.x };
+    uint32_t* const s_ctl = s_sw + job.stackEntries*BLOCK;
+    typedef SceneT<LDSMODE != 0, false, 2, LDSMODE == 2> SC;
     SC sc;
-    stage_scene_lds(sc, scIn, s_ctl + kSwalkCtlWords);
+    stage_scene_lds(sc, scIn, s_ctl + kSwalkCtlWords, BLOCK);
 
     const int lane = (int)__lane_id();
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SWALK) void k_swalk(DevScene scIn,
                 float t;
                 V3 n;
                 const int index = (int)(ref & ~kLeafBit);
-                if (prim_intersect<SC, LdsStack<kBlock>, false, SHADOW>(sc, index, st, sp, o, d, time, t, n, ctr, tStop))
+                if (prim_intersect<SC, LdsStack<BLOCK>, false, SHADOW>(sc, index, st, sp, o, d, time, t, n, ctr, tStop))
                 {
                     if (t < minT && t > 0.0f)
                     {
