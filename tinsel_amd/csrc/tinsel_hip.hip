@@ -1210,8 +1210,11 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             }
             {
                 ScopedTimer t(r, KN_SHADE, st);
+                // TINSEL_HIP_SHADE_SORTED=1 (A/B): k_shade_sorted takes a region's paths class by class (tn_kernels.h)
+                static const bool shadeSorted = getenv("TINSEL_HIP_SHADE_SORTED") && atoi(getenv("TINSEL_HIP_SHADE_SORTED")) != 0;
                 a.grid = gridPersist;
-                a.ldsBytes = ldsShade;
+                a.shadeSorted = shadeSorted ? 1 : 0;
+                a.ldsBytes = ldsShade + (shadeSorted ? (uint32_t)(kShadeListWords*sizeof(uint32_t)) : 0u);
                 a.scene.arenaLdsBytes = arenaLdsShade;
                 launch_path(r, PK_SHADE, a, st);
                 a.scene.arenaLdsBytes = arenaLdsTrace;

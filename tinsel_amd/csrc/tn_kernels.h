@@ -1138,6 +1138,68 @@ struct ShadeFetch
     }
 };
 
+// the shading half of one path (shared by the two k_shade kernels): on_hit_begin / on_miss, the BSDF terms of the arriving light
+// samples, the BSDF step; true when the path goes on (its state in `p`, `front`: its next ray enters a mesh in HBM)
+template <class SC>
+TN_D bool shade_path(const SC& sc, const SplitState& ss, const ShadeFetch& f, int bounce, int maxDepth, int rrStart, const BinPrims& bp,
+                     PathRegs& p, uint32_t& slot, bool& front)
+{
+    const int K = ss.neePerPath;
+    bool alive = false;
+    f.unpack(p, slot);
+    const int prim = f.prim;
+    if (prim < 0)
+    {
+        on_miss(sc, p, bounce);
+    }
+    else
+    {
+        const float4 hh = f.hh;
+        const Mat mat = load_mat(sc.mats, prim);
+
+        HitCtx h;
+        on_hit_begin(p, mat, hh.x, V3(hh.y, hh.z, hh.w), bounce, h);
+
+        // SampleLights, after the traces (render.cpp:118-139, 171-224): k_shadow left, per shadow ray, the primitive
+        // whose emission arrives; the BSDF terms are evaluated for those rays only
+        if (K > 0)
+        {
+            const uint32_t qn = f.qn;
+            LightCursor lights;
+            const float2* res = ss.neeRes + qn;
+            const float4* wis = ss.neeRay + (size_t)ss.capacity + qn;       // {wi, nl} of ray k at wis[k*2*capacity]
+            V3 sum = nee_sum(sc, [&](int k) -> V3 {
+                const float2 rk = res[(size_t)k*ss.capacity];
+                const int hp = __float_as_int(rk.x);
+                if (sc.probe.valid && k == 0)
+                {
+                    if (hp < 0)
+                        return V3(0.0f);
+                    const float4 w = wis[0], sky = ss.neeSky[qn];
+                    return nee_contrib_probe(mat, h, V3(w.x, w.y, w.z), V3(sky.x, sky.y, sky.z), sky.w);
+                }
+                const int light = lights.next(sc);
+                if (hp < 0)
+                    return V3(0.0f);
+                const float4 w = wis[(size_t)(k*2)*ss.capacity];
+                return nee_contrib_light(sc, mat, h, V3(w.x, w.y, w.z), w.w, light, hp, rk.y);
+            });
+            p.rad = p.rad + p.thr*sum;
+        }
+
+        // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
+        if (bounce + 1 < maxDepth)
+            alive = bsdf_step(p, mat, h) == kContinue;
+        if (alive && rrStart > 0 && bounce + 1 >= rrStart)
+            alive = roulette_survives(p);
+        if (alive)
+            front = bp.count == 0 || ray_enters_big_mesh(sc.primBoxes, bp, p.o, p.d);
+    }
+    if (!alive)
+        ss.radOut[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
+    return alive;
+}
+
 template <bool LDS, bool MIXED = false>
 __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp, const uint32_t* __restrict__ order)
 {
@@ -1171,60 +1233,133 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
             PathRegs p;
             uint32_t slot = 0;
             if (j < n)
+                alive = shade_path(sc, ss, f, bounce, maxDepth, rrStart, bp, p, slot, front);
+            const uint32_t np = out.push(alive, front);
+            if (alive)
+                store_state(ss, nxt, np, p, slot, hasMedia);
+        }
+        if (lane == 0)
+        {
+            ss.segFront[(size_t)(bounce + 1)*ss.numRegions + r] = out.nFront;
+            ss.segBack[(size_t)(bounce + 1)*ss.numRegions + r] = out.nBack;
+        }
+    }
+}
+
+// k_shade_sorted: the same shading, the paths of a region taken CLASS BY CLASS instead of in position order -- rays that left
+// the scene / surfaces with a transmission or sub-surface lobe / plain opaque surfaces / lights (reference disney.h:172, 178,
+// 243, 246: the stochastic lobe choices; render.cpp:365-384 the miss branch, :322 the light-hit termination).  A wave of k_shade
+// mixes them and runs each branch with the lanes that take it (71 % of the lanes active on glass, round 2).  Here a wave reads
+// the 4-B hit primitive of its region's entries 64 at a time, drops each position into one of four LDS lists (2 KB per wave,
+// positions from a wave64 ballot), and whenever a list holds 64 it shades those 64 paths: every branch with a full wave.  What is
+// left at the end of the region (fewer than 64 per class) is shaded in mixed rounds, so a region costs at most one round more
+// than before.  The price: a class's 64 positions are scattered over the region (16-B gathers inside a 16-KB window per array
+// instead of one run), and the next round's records cannot be requested ahead.  Order never changes a result (the paths append
+// to the next bounce in another order, that is all).
+constexpr int kShadeClasses = 4;
+constexpr int kShadeListLen = 128;
+constexpr int kShadeListWordsPerWave = kShadeClasses*kShadeListLen;
+constexpr int kShadeListWords = kShadeListWordsPerWave*(kBlock/kWave);     // 8 KB per workgroup
+
+template <bool LDS, bool MIXED = false>
+__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade_sorted(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp, const uint32_t* __restrict__ order)
+{
+    extern __shared__ uint32_t s_arena[];       // the waves' class lists, then the staged arena
+    uint32_t* const list = s_arena + (threadIdx.x/kWave)*kShadeListWordsPerWave;
+    SceneT<LDS, false, 2, MIXED> sc;
+    stage_scene_lds(sc, scIn, s_arena + kShadeListWords);
+    const uint32_t lane = __lane_id();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int cur = bounce & 1, nxt = cur ^ 1;
+    const int K = ss.neePerPath;
+    const bool hasMedia = sc.hasMedia != 0;
+
+    for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
+    {
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
+        const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
+        const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
+        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        uint32_t cnt[kShadeClasses] = { 0u, 0u, 0u, 0u };       // wave-uniform
+
+        // One loop, ONE shading site (the shading code is 6,000 instructions: it must not be instantiated per class): every turn either
+        // shades 64 paths of a class whose list is full, or -- no list full -- reads the next 64 hit primitives of the region and files
+        // their positions, or -- region read -- shades what is left, class after class, in as few rounds as the leftovers' sum needs.
+        int nextPrim = -1;          // the hit primitives of the next round are requested a round ahead (4 B per path)
+        if (lane < n)
+            nextPrim = ss.hitPrim[region_pos(r*ss.regionLen, ss.regionLen, nFront, lane)];
+        uint32_t j0 = 0, e0 = 0;
+        for (;;)
+        {
+            uint32_t pos = 0;
+            bool valid = false;
+            const int full = cnt[0] >= (uint32_t)kWave ? 0 : cnt[1] >= (uint32_t)kWave ? 1 : cnt[2] >= (uint32_t)kWave ? 2 : cnt[3] >= (uint32_t)kWave ? 3 : -1;
+            if (full >= 0)
             {
-                f.unpack(p, slot);
-
-                const int prim = f.prim;
-                if (prim < 0)
-                {
-                    on_miss(sc, p, bounce);
-                }
-                else
-                {
-                    const float4 hh = f.hh;
-                    const Mat mat = load_mat(sc.mats, prim);
-
-                    HitCtx h;
-                    on_hit_begin(p, mat, hh.x, V3(hh.y, hh.z, hh.w), bounce, h);
-
-                    // SampleLights, after the traces (render.cpp:118-139, 171-224): k_shadow left, per shadow ray, the primitive
-                    // whose emission arrives; the BSDF terms are evaluated for those rays only
-                    if (K > 0)
+                uint32_t c0 = 0;
+#pragma unroll
+                for (int c = 0; c < kShadeClasses; ++c)
+                    if (c == full)
                     {
-                        const uint32_t qn = f.qn;
-                        LightCursor lights;
-                        const float2* res = ss.neeRes + qn;
-                        const float4* wis = ss.neeRay + (size_t)ss.capacity + qn;       // {wi, nl} of ray k at wis[k*2*capacity]
-                        V3 sum = nee_sum(sc, [&](int k) -> V3 {
-                            const float2 rk = res[(size_t)k*ss.capacity];
-                            const int hp = __float_as_int(rk.x);
-                            if (sc.probe.valid && k == 0)
-                            {
-                                if (hp < 0)
-                                    return V3(0.0f);
-                                const float4 w = wis[0], sky = ss.neeSky[qn];
-                                return nee_contrib_probe(mat, h, V3(w.x, w.y, w.z), V3(sky.x, sky.y, sky.z), sky.w);
-                            }
-                            const int light = lights.next(sc);
-                            if (hp < 0)
-                                return V3(0.0f);
-                            const float4 w = wis[(size_t)(k*2)*ss.capacity];
-                            return nee_contrib_light(sc, mat, h, V3(w.x, w.y, w.z), w.w, light, hp, rk.y);
-                        });
-                        p.rad = p.rad + p.thr*sum;
+                        cnt[c] -= (uint32_t)kWave;
+                        c0 = cnt[c];
                     }
-
-                    // the last iteration's BSDF sample is never used by the oracle's loop (render.cpp:250)
-                    if (bounce + 1 < maxDepth)
-                        alive = bsdf_step(p, mat, h) == kContinue;
-                    if (alive && rrStart > 0 && bounce + 1 >= rrStart)
-                        alive = roulette_survives(p);
-                    if (alive)
-                        front = bp.count == 0 || ray_enters_big_mesh(sc.primBoxes, bp, p.o, p.d);
-                }
-                if (!alive)
-                    ss.radOut[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
+                pos = list[full*kShadeListLen + c0 + lane];
+                valid = true;
             }
+            else if (j0 < n)
+            {
+                const uint32_t j = j0 + lane;
+                const uint32_t at = region_pos(r*ss.regionLen, ss.regionLen, nFront, j < n ? j : 0u);
+                const int prim = nextPrim;
+                if (j + kWave < n)
+                    nextPrim = ss.hitPrim[region_pos(r*ss.regionLen, ss.regionLen, nFront, j + kWave)];
+                int cls = -1;
+                if (j < n)
+                {
+                    if (prim < 0)
+                        cls = 0;
+                    else
+                    {
+                        const float4* mp = reinterpret_cast<const float4*>(sc.mats + prim);
+                        const float subsurface = mp[2].w, transmission = mp[4].w;
+                        const int lightSamples = __float_as_int(mp[5].w);
+                        cls = lightSamples ? 3 : (transmission > 0.0f || subsurface > 0.0f) ? 1 : 2;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < kShadeClasses; ++c)
+                {
+                    const unsigned long long m = __ballot(cls == c);
+                    if (cls == c)
+                        list[c*kShadeListLen + cnt[c] + (uint32_t)__popcll(m & below)] = at;
+                    cnt[c] += (uint32_t)__popcll(m);
+                }
+                j0 += kWave;
+                continue;
+            }
+            else
+            {
+                const uint32_t s1 = cnt[0], s2 = s1 + cnt[1], s3 = s2 + cnt[2], total = s3 + cnt[3];
+                if (e0 >= total)
+                    break;
+                const uint32_t e = e0 + lane;
+                if (e < total)
+                {
+                    const uint32_t c = e >= s3 ? 3u : e >= s2 ? 2u : e >= s1 ? 1u : 0u;
+                    pos = list[c*kShadeListLen + (e - (c == 3u ? s3 : c == 2u ? s2 : c == 1u ? s1 : 0u))];
+                    valid = true;
+                }
+                e0 += kWave;
+            }
+
+            ShadeFetch f;
+            f.issue(ss, cur, pos, valid, hasMedia, K > 0, bounce == 0);
+            bool alive = false, front = true;
+            PathRegs p;
+            uint32_t slot = 0;
+            if (valid)
+                alive = shade_path(sc, ss, f, bounce, maxDepth, rrStart, bp, p, slot, front);
             const uint32_t np = out.push(alive, front);
             if (alive)
                 store_state(ss, nxt, np, p, slot, hasMedia);

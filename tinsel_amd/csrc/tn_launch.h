@@ -37,6 +37,7 @@ struct LaunchArgs
     SwalkJob swalk;                 // PK_SWALK_*
     int swalkMode;                  // PK_SWALK_*: 0 = 256-thread workgroups, generic pointers; 1 / 2 = 1024-thread workgroups, arena in LDS (2: meshes in HBM too)
     int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
+    int shadeSorted;                // PK_SHADE: k_shade_sorted (paths taken class by class) instead of k_shade
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
     int bounce;
     int bounceEnd;                  // PK_BOUNCE: the launch covers the bounces [bounce, bounceEnd)
@@ -95,12 +96,14 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             hipLaunchKernelGGL((k_lights<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.bins, a.order);
         break;
     case PK_SHADE:
-        if (mixed)
-            hipLaunchKernelGGL((k_shade<true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order);
-        else if (lds)
-            hipLaunchKernelGGL((k_shade<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order);
-        else
-            hipLaunchKernelGGL((k_shade<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order);
+#define TN_LAUNCH_SHADE(KERNEL)                                                                                        \
+        do {                                                                                                           \
+            if (mixed) hipLaunchKernelGGL((KERNEL<true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order); \
+            else if (lds) hipLaunchKernelGGL((KERNEL<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order); \
+            else hipLaunchKernelGGL((KERNEL<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order); \
+        } while (0)
+        if (a.shadeSorted) TN_LAUNCH_SHADE(k_shade_sorted); else TN_LAUNCH_SHADE(k_shade);
+#undef TN_LAUNCH_SHADE
         break;
     case PK_BOUNCE:
 #define TN_LAUNCH_BOUNCE(DEFER)                                                                                        \
@@ -146,6 +149,9 @@ inline void prepare_path_kernels(int sharedMemLimit)
 {
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+    (void)hipFuncSetAttribute((const void*)k_shade_sorted<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+    (void)hipFuncSetAttribute((const void*)k_shade_sorted<true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+    (void)hipFuncSetAttribute((const void*)k_shade_sorted<false>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
 #define TN_PREP_SWALK(SH) (void)hipFuncSetAttribute((const void*)k_swalk<SH, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
                           (void)hipFuncSetAttribute((const void*)k_swalk<SH, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
                           (void)hipFuncSetAttribute((const void*)k_swalk<SH, 256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
