@@ -34,7 +34,7 @@ COMMON_FLAGS = [
 ]
 HIPCC_FLAGS = COMMON_FLAGS + ["-ffp-contract=off", "-fno-fast-math"]
 FAST_FLAGS = COMMON_FLAGS + ["-DTN_FAST=1", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math",
-                             "-fgpu-flush-denormals-to-zero", "-DTN_WAVES_BOUNCE=3", "-DTN_WAVES_SHADE=3"]
+                             "-fgpu-flush-denormals-to-zero"]
 
 
 def hipcc():

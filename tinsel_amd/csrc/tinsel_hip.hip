@@ -1047,12 +1047,12 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         // 27 KB of LDS per workgroup) where rays can LEAVE the scene -- veach 1515 -> 1866 Msamples/s, features 755 -> 865, env_loft
         // 3598 -> 3793, gloss 7584 -> 7934; between two facing planes every ray hits something and the pools only cost (cornell
         // 2919 -> 2894: not one ray of its 5.68 per sample misses) -- and where the pools do not cost a resident workgroup: two
-        // per CU in the parity arm (2 waves per SIMD), three in the tolerance arm
+        // per CU at three waves per SIMD (features' 32-KB arena + pools would leave two: there the third wave is worth more)
         {
             static const char* repackEnv = getenv("TINSEL_HIP_REPACK");          // 0 / 1: never / always (A/B); default: open scenes
             const bool want = repackEnv ? atoi(repackEnv) != 0 : !r->sceneEnclosed;
             const size_t withPool = (size_t)a.ldsBytes + kPoolWords*sizeof(uint32_t);
-            const size_t perCU = 160u*1024u, blocksPerCU = r->arith == TINSEL_ARITH_FAST ? 3 : 2;
+            const size_t perCU = 160u*1024u, blocksPerCU = 3;      // k_bounce runs three waves per SIMD = three workgroups per CU
             if (want && withPool*blocksPerCU <= perCU && withPool <= (size_t)r->sharedMemLimit)
             {
                 a.fp.repack = 1;

@@ -28,15 +28,16 @@ namespace tn {
 #ifndef TN_WAVES_FUSED
 #define TN_WAVES_FUSED 2
 #endif
-// k_bounce alone: the tolerance arm's k_bounce needs ~205 VGPRs and is faster squeezed to 168 (3 waves per SIMD, ~100 B of
-// scratch: cornell 3203 -> 3827 Msamples/s); its k_shade (split pipeline) needs ~180 and runs at 168 / 3 waves with 16-20 B of
-// scratch (glass 15.9 -> 15.0 ms); the exact arm's k_bounce (256 VGPRs + scratch already: 364-416 B at 168) and k_shade
-// (222 + the next round's records) stay at two waves.
+// k_bounce and k_shade: THREE waves per SIMD (168 VGPRs) in both arithmetic arms.  The parity arm's k_bounce needs ~250 registers and
+// k_shade ~230; with the SLP vectoriser on (round 2) squeezing them cost 364-416 B of scratch and ran 1.4-1.8x slower.  Without it
+// (tinsel_amd/build.py) the squeeze spills 48-80 registers and the third wave pays for them several times over -- the kernels
+// wait on dependent fp32 / fp64 chains, not on issue slots: cornell 2989 -> 3805 Msamples/s, veach 1961 -> 2575, gloss 8276 -> 9614
+// (k_bounce); glass 1320 -> 1372, the 524k-triangle config 2190 -> 2254 (k_shade; many_spheres 2081 -> 2016).
 #ifndef TN_WAVES_BOUNCE
-#define TN_WAVES_BOUNCE TN_WAVES_FUSED
+#define TN_WAVES_BOUNCE 3
 #endif
 #ifndef TN_WAVES_SHADE
-#define TN_WAVES_SHADE TN_WAVES_FUSED
+#define TN_WAVES_SHADE 3
 #endif
 #ifndef TN_WAVES_LIGHTS
 #define TN_WAVES_LIGHTS 4
