@@ -990,7 +990,10 @@ int streaming_grid(const tinsel_hip* r, size_t slots, int pipeline)
     const size_t regionTarget = regionEnv ? (size_t)regionEnv : (pipeline == TINSEL_PIPELINE_WAVEFRONT && r->neePerPath >= 3) ? 2048 : 1024;
     const size_t perBlock = regionTarget*(kBlock/kWave);
     const size_t blocks = (slots + perBlock - 1)/perBlock;
-    const size_t lo = std::min<size_t>((size_t)r->numCUs*2, (slots + kBlock - 1)/kBlock), hi = (size_t)r->numCUs*(size_t)grid_mult();
+    // (at least as many workgroups as the chip holds at once -- TINSEL_HIP_GRID_MIN per CU, default 3: k_bounce and k_shade run three
+    // waves per SIMD -- where the batch has that many 256-path pieces: a 1 M-path batch would otherwise leave the third wave slot empty)
+    static const int gridMin = getenv("TINSEL_HIP_GRID_MIN") ? std::max(1, atoi(getenv("TINSEL_HIP_GRID_MIN"))) : 3;
+    const size_t lo = std::min<size_t>((size_t)r->numCUs*(size_t)gridMin, (slots + kBlock - 1)/kBlock), hi = (size_t)r->numCUs*(size_t)grid_mult();
     return (int)std::max<size_t>(1, std::min(hi, std::max(lo, blocks)));
 }
 
@@ -1122,8 +1125,16 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         const uint32_t arenaLdsShade = (arenaLdsTrace == 0 && !noShadeArena && r->scene.arenaBytes <= 61440u && !getenv("TINSEL_HIP_NO_LDS_SCENE")) ? r->scene.arenaBytes : arenaLdsTrace;
         const uint32_t ldsShade = r->scene.allInArena ? r->scene.arenaBytes : arenaLdsShade;
         a.walkedOnly = walkedOnly ? 1 : 0;
+        static const bool noSceneWalkEarly = getenv("TINSEL_HIP_NO_SCENE_WALK") != nullptr;
         // the lean k_extend draws the light samples itself (tn_launch.h launches it when walkedOnly and not counting)
-        const bool lightsInExtend = walkedOnly && !r->countDetail;
+        // ... and so does the variant for a staged arena with meshes in HBM (glass): without the SLP vectoriser it fits 128 VGPRs and
+        // saves k_lights' pass over the path state (k_extend 5.7 + k_lights 7.1 -> 11.2 ms per 32 passes, glass 1366 -> 1425 Msamples/s;
+        // round 2, 170 VGPRs: 29.1 apart, 31.5 together).  TINSEL_HIP_LIGHTS_IN_EXTEND=0: k_lights as a kernel of its own (A/B)
+        static const bool lightsInExtendEnv = !(getenv("TINSEL_HIP_LIGHTS_IN_EXTEND") && atoi(getenv("TINSEL_HIP_LIGHTS_IN_EXTEND")) == 0);
+        const bool mixedArena = !r->scene.allInArena && r->scene.arenaLdsBytes != 0 && r->scene.arenaLdsBytes == r->scene.arenaBytes;
+        const bool lightsInMixed = lightsInExtendEnv && !walkedOnly && !r->countDetail && mixedArena && !(!noSceneWalkEarly && !r->scene.flatScan);
+        a.lightsInExtend = lightsInMixed ? 1 : 0;
+        const bool lightsInExtend = (walkedOnly && !r->countDetail) || lightsInMixed;
         if (set_regions(r, a, slots, gridPersist))
             return -1;
         const size_t W = a.ss.numRegions;

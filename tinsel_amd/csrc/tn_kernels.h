@@ -904,8 +904,12 @@ TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& b
 // kernel is the flat scan + record reads) also draws the light samples, the hit still in registers: there a kernel of its
 // own for them costs more than it saves (524k-triangle config: 2.1 + 2.9 ms apart, 3.9 together); behind the inline mesh
 // walk it is the other way round (the fused kernel needs 170 VGPRs: glass 21.2 + 7.9 apart, 31.5 together at 3 waves).
-template <bool COUNT, bool LDS, bool WONLY = false, bool MIXED = false>
-__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : TN_WAVES_TRACE) void k_extend(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
+// LIGHTS: the kernel draws the light samples too (always in the lean variant; in the others an A/B: TINSEL_HIP_LIGHTS_IN_EXTEND)
+#ifndef TN_WAVES_EXTEND_LIGHTS
+#define TN_WAVES_EXTEND_LIGHTS 4
+#endif
+template <bool COUNT, bool LDS, bool WONLY = false, bool MIXED = false, bool LIGHTS = WONLY>
+__global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_WAVES_EXTEND_LIGHTS : TN_WAVES_TRACE) void k_extend(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
                                                                   const float4* __restrict__ walkRec, uint32_t walkPrims, BinPrims bp, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : TN_WAVES_TRA
 
     const uint32_t lane = __lane_id();
     const int cur = bounce & 1;
-    const bool lights = WONLY && ss.neePerPath > 0;
+    const bool lights = LIGHTS && ss.neePerPath > 0;
     uint32_t rays = 0;
     TraceCounters ctr = { 0, 0, 0 };
     sc.walkRec = walkRec;           // k_walk's records of the front rays (null: meshes are walked inline)

@@ -38,6 +38,7 @@ struct LaunchArgs
     int swalkMode;                  // PK_SWALK_*: 0 = 256-thread workgroups, generic pointers; 1 / 2 = 1024-thread workgroups, arena in LDS (2: meshes in HBM too)
     int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
     int shadeSorted;                // PK_SHADE: k_shade_sorted (paths taken class by class) instead of k_shade
+    int lightsInExtend;             // PK_EXTEND, arena staged + meshes in HBM: the variant that draws the light samples too (A/B)
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
     int bounce;
     int bounceEnd;                  // PK_BOUNCE: the launch covers the bounces [bounce, bounceEnd)
@@ -68,6 +69,8 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             hipLaunchKernelGGL((k_extend<false, true, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         else if (a.walkedOnly && !count && !lds)
             hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
+        else if (mixed && a.lightsInExtend)
+            hipLaunchKernelGGL((k_extend<false, true, false, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         else if (mixed)
             hipLaunchKernelGGL((k_extend<false, true, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         else
