@@ -733,7 +733,7 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     }
     {
         ScopedTimer t(r, KN_SEG, st);
-        hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, regionCounts, (const uint32_t*)nullptr, ss.numRegions, step, r->segPrefix);
+        hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), ss.numRegions*sizeof(uint32_t), st, regionCounts, (const uint32_t*)nullptr, ss.numRegions, step, r->segPrefix);
         hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
     }
     WalkJob& job = a.walk;
@@ -843,7 +843,7 @@ void launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* f
     }
     {
         ScopedTimer t(r, KN_SEG, st);
-        hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), 0, st, front, back, ss.numRegions, step, r->segPrefix);
+        hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), ss.numRegions*sizeof(uint32_t), st, front, back, ss.numRegions, step, r->segPrefix);
         hipLaunchKernelGGL(k_seg_expand_all, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, front, back, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
     }
     SwalkJob& job = a.swalk;

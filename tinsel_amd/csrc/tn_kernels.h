@@ -1389,19 +1389,34 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
 {
     constexpr uint32_t kWaves = kSegBlock/kWave;
     __shared__ uint32_t s_wave[kWaves];
+    extern __shared__ uint32_t s_counts[];      // [numRegions]: the counts (and later the prefixes) by region
     const uint32_t lane = __lane_id(), wave = threadIdx.x/kWave;
-    // every wave scans one contiguous piece, 64 consecutive counts per step (coalesced)
+    // The scan visits the regions `step` apart: read through that permutation the counts would be 2 x numRegions scattered 4-B loads
+    // by ONE workgroup (53 us per launch, 616 launches per default bench run: 4 % of glass's frame).  So they are staged into LDS
+    // with coalesced loads first (numRegions <= 32768: 128 KB), scanned there, and the prefixes leave coalesced too.
+    for (uint32_t r = threadIdx.x; r < numRegions; r += kSegBlock)
+        s_counts[r] = counts[r] + (counts2 ? counts2[r] : 0u);
+    __syncthreads();
+
+    // every wave scans one contiguous piece of the PERMUTED sequence, 64 entries per step
     const uint32_t piece = ((numRegions + kWaves - 1u)/kWaves + kWave - 1u)/kWave*kWave;
     const uint32_t begin = wave*piece < numRegions ? wave*piece : numRegions;
     const uint32_t end = (begin + piece) < numRegions ? (begin + piece) : numRegions;
 
-    // the list visits the regions `step` apart (coprime to their number): entry i of the scan is region i*step mod numRegions
-    // (numRegions <= 65535, checked by the host: the product fits 32 bits)
-    auto region = [&](uint32_t i) -> uint32_t { return (i*step) % numRegions; };
-    auto count = [&](uint32_t r) -> uint32_t { return counts[r] + (counts2 ? counts2[r] : 0u); };
+    // entry i of the scan is region i*step mod numRegions (step coprime to numRegions <= 65535, checked by the host: the product
+    // fits 32 bits); the remainder is carried along instead of divided out: r(i + 64) = r(i) + 64*step mod numRegions
+    const uint32_t stride = (uint32_t)(((unsigned long long)kWave*step) % numRegions);
+    uint32_t reg = (uint32_t)(((unsigned long long)(begin + lane)*step) % numRegions);
     uint32_t sum = 0;
-    for (uint32_t i = begin + lane; i < end; i += kWave)
-        sum += count(region(i));
+    {
+        uint32_t rr = reg;
+        for (uint32_t i = begin + lane; i < end; i += kWave)
+        {
+            sum += s_counts[rr];
+            rr += stride;
+            if (rr >= numRegions) rr -= numRegions;
+        }
+    }
     for (int off = 32; off > 0; off >>= 1)
         sum += __shfl_xor(sum, off);
     if (lane == 0)
@@ -1417,7 +1432,7 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
     for (uint32_t i0 = begin; i0 < end; i0 += kWave)
     {
         const uint32_t i = i0 + lane;
-        const uint32_t v = i < end ? count(region(i)) : 0u;
+        const uint32_t v = i < end ? s_counts[reg] : 0u;
         uint32_t x = v;                                   // inclusive scan across the wave
         for (int off = 1; off < kWave; off <<= 1)
         {
@@ -1425,9 +1440,14 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
             if ((int)lane >= off) x += y;
         }
         if (i < end)
-            prefix[region(i)] = run + x - v;
+            s_counts[reg] = run + x - v;                  // (each region is visited once: the permutation is a bijection)
         run += __shfl(x, kWave - 1);
+        reg += stride;
+        if (reg >= numRegions) reg -= numRegions;
     }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < numRegions; r += kSegBlock)
+        prefix[r] = s_counts[r];
     if (threadIdx.x == 0)
         prefix[numRegions] = total;
 }

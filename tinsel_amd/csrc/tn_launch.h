@@ -150,6 +150,7 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
 // k_walk (tree tops) and k_bounce (shading pools beside a staged arena) ask for more dynamic LDS than the default launch limit allows
 inline void prepare_path_kernels(int sharedMemLimit)
 {
+    (void)hipFuncSetAttribute((const void*)k_seg_prefix, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit - 1024);      // (it has static LDS too)
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_walk<1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_shade_sorted<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
@@ -160,6 +161,7 @@ inline void prepare_path_kernels(int sharedMemLimit)
                           (void)hipFuncSetAttribute((const void*)k_swalk<SH, 256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
     TN_PREP_SWALK(false); TN_PREP_SWALK(true);
 #undef TN_PREP_SWALK
+    (void)hipGetLastError();        // a refused attribute must not surface as the next launch's error
     (void)hipFuncSetAttribute((const void*)k_walk<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
 #define TN_PREP_BOUNCE(C, L, D) (void)hipFuncSetAttribute((const void*)k_bounce<C, L, D>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
     TN_PREP_BOUNCE(true, true, false); TN_PREP_BOUNCE(true, false, false);
