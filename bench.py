@@ -149,8 +149,8 @@ def _kernel_key(name):
     m = re.search(r"(k_\w+)(<[^>]*>)?", name)
     if not m:
         return None
-    if m.group(2) and m.group(2).startswith("<true"):
-        return None                         # detail-counting variants (COUNT = true) are not the product kernels
+    if m.group(1) in ("k_extend", "k_shadow", "k_bounce", "k_mega") and m.group(2) and m.group(2).startswith("<true"):
+        return None                         # detail-counting variants (COUNT = true, their first template argument) are not the product kernels
     if m.group(1) == "k_ub_gather":
         return "k_ub_gather" + (m.group(2) or "")
     return "k_accumulate" if m.group(1).startswith("k_accumulate") else m.group(1)
@@ -552,8 +552,13 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         common["triangle_tests_G_s"] = rays*T_bar/(dom_ms*1e-3)/1e9
         if YARD[0]:
             common["record_chase_ceilings_G_s"] = {k: YARD[0].get(k) for k in ("gather_beyond_cache_Grecords_s", "gather_tree_sized_Grecords_s", "gather_l2_resident_Grecords_s")}
+            # records per second (a 48-B triangle = 0.75 of a 64-B record) against the two ceilings: above the first (the tree top in
+            # LDS and the L2 serve most visits), below the second (what a CU's vector-memory front end retires from L2)
+            recs = common["node_visits_G_s"] + 0.75*common["triangle_tests_G_s"]
             if YARD[0].get("gather_tree_sized_Grecords_s"):
-                common["frac_of_tree_sized_chase"] = (common["node_visits_G_s"] + 0.75*common["triangle_tests_G_s"])/YARD[0]["gather_tree_sized_Grecords_s"]
+                common["frac_of_tree_sized_chase"] = recs/YARD[0]["gather_tree_sized_Grecords_s"]
+            if YARD[0].get("gather_l2_resident_Grecords_s"):
+                common["frac_of_l2_resident_chase"] = recs/YARD[0]["gather_l2_resident_Grecords_s"]
     if scene_in_lds:
         # the scene never leaves the CU: the HBM model counts bytes that are LDS reads.  What binds is instruction issue.
         ach = (valu_per_launch/avg_launch_s/1e9) if (valu_per_launch and avg_launch_s > 0) else None
