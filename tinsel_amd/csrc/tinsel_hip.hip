@@ -965,7 +965,16 @@ int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, floa
             tiles = r->accTilesCount;
         }
         if (tiles > 0)
-            hipLaunchKernelGGL(k_accumulate_tiled, dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev, tileList);
+        {
+            const int span = 1 + (int)floorf(fp.filterWidth) + (int)ceilf(fp.filterWidth) + 1;     // reachLo + reachHi + 1
+            static const bool noSpan = getenv("TINSEL_HIP_ACC_NO_SPAN") != nullptr;
+            if (span == 3 && !noSpan)
+                hipLaunchKernelGGL((k_accumulate_tiled<3>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev, tileList);
+            else if (span == 4 && !noSpan)
+                hipLaunchKernelGGL((k_accumulate_tiled<4>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev, tileList);
+            else
+                hipLaunchKernelGGL((k_accumulate_tiled<0>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev, tileList);
+        }
     }
     else
     {

@@ -1656,6 +1656,10 @@ constexpr int kAccSide = kAccTile + kAccMaxHalo;
 constexpr int kAccEntries = kAccSide*kAccSide;
 constexpr int kAccMaxFoot = 5;      // widest footprint (pixels per axis) for filter widths <= 2
 
+// SPAN = the candidate window's edge (reachLo + reachHi + 1: 3 for the default filter width 0.75, 4 for cornell's 1.0) as a compile-time
+// constant: the gather loop is unrolled over the SPAN x SPAN window with no bounds -- candidates outside the frame are staged as
+// "covers nothing", so clipping the window changes nothing -- in the same raster order; 0 = the window's bounds at run time.
+template <int SPAN>
 __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, FrameParams fp, float4* __restrict__ accum,
                                                                 const uint32_t* __restrict__ passSeeds, const int* __restrict__ tileList)
 {
@@ -1762,28 +1766,38 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
         }
         __syncthreads();
 
+        auto add = [&](int le) {
+            const float4 c = s_c[le];
+            const uint32_t xm = __float_as_uint(c.w), ym = s_y[le];
+            const uint32_t kx = (uint32_t)(px - (int)(xm & 0xffffu)), ky = (uint32_t)(py - (int)(ym & 0xffffu));
+            if (kx >= (xm >> 16) || ky >= (ym >> 16))
+                return;
+            if (!gauss)
+            {
+                acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
+            }
+            else
+            {
+                const float w = s_wx[kx][le]*s_wy[ky][le];
+                acc.x += c.x*w; acc.y += c.y*w; acc.z += c.z*w; acc.w += w;
+            }
+        };
         if (inside)
         {
-            for (int j = j0; j <= j1; ++j)
+            if (SPAN > 0)
             {
-                for (int i = i0; i <= i1; ++i)
-                {
-                    const int le = j*kAccSide + i;
-                    const float4 c = s_c[le];
-                    const uint32_t xm = __float_as_uint(c.w), ym = s_y[le];
-                    const uint32_t kx = (uint32_t)(px - (int)(xm & 0xffffu)), ky = (uint32_t)(py - (int)(ym & 0xffffu));
-                    if (kx >= (xm >> 16) || ky >= (ym >> 16))
-                        continue;
-                    if (!gauss)
-                    {
-                        acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
-                    }
-                    else
-                    {
-                        const float w = s_wx[kx][le]*s_wy[ky][le];
-                        acc.x += c.x*w; acc.y += c.y*w; acc.z += c.z*w; acc.w += w;
-                    }
-                }
+                // the window of pixel (lx, ly) starts at LDS entry (lx, ly): px - reachLo - ox == lx
+#pragma unroll
+                for (int dj = 0; dj < SPAN; ++dj)
+#pragma unroll
+                    for (int di = 0; di < SPAN; ++di)
+                        add((ly + dj)*kAccSide + lx + di);
+            }
+            else
+            {
+                for (int j = j0; j <= j1; ++j)
+                    for (int i = i0; i <= i1; ++i)
+                        add(j*kAccSide + i);
             }
         }
         __syncthreads();
