@@ -32,6 +32,10 @@
 // 1/256 ranges, to even out the tail (3.3 of 4 waves per SIMD resident on average) -- per wave in chunks of 1024 items
 // (21.0 -> 24.8 ms) or per workgroup in chunks of 16384 shared through a 64-bit LDS {cursor, end} (25.4 ms): a CU that stays
 // in ONE contiguous part of the queue for the whole launch keeps that part's subtrees in its L1 / its XCD's L2.
+// Round 3: several node visits per turn of the loop, a lane that finds no child popping at once instead of at the turn's end (the
+// refill check, the leaf ballots and the bookkeeping are a quarter of the wave cycles): 16.7 -> 17.7 ms with the pop moved alone, 17.3 /
+// 17.1 / 17.3 with 2 / 3 / 4 visits per turn (profiles/r03_o_ab_walk_node_reps.txt) -- the pop's LDS read inside the node phase and the
+// registers it keeps alive cost more than the turns it saves.
 #pragma once
 
 #include "tn_isect.h"
