@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--maxdepth", type=int, default=0, help="0 = the scene's own / BASELINE value")
     ap.add_argument("--pipeline", choices=["auto", "wavefront", "mega", "split"], default="auto")
-    ap.add_argument("--bvh", choices=["reference", "lbvh"], default="reference",
+    ap.add_argument("--bvh", choices=["reference", "lbvh", "ploc"], default="reference",
                     help="mesh BVHs: the reference's host-built trees (parity path) or rebuilt on the device")
     ap.add_argument("--roulette", type=int, default=0, help="opt-in Russian roulette from this bounce on (0 = the reference's behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -202,8 +202,8 @@ def inner_pmc(args):
     if args.maxdepth > 0:
         opt.max_depth = args.maxdepth
     r = tinsel_amd.create_gpu_renderer(scene, 0)
-    if args.bvh == "lbvh":
-        r.set_mesh_bvh(abi.BVH_LBVH)
+    if args.bvh != "reference":
+        r.set_mesh_bvh(abi.BVH_LBVH if args.bvh == "lbvh" else abi.BVH_PLOC)
     if args.roulette > 0:
         r.set_russian_roulette(args.roulette)
     r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
@@ -282,7 +282,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     opt.mode = abi.MODE_PATHTRACE
 
     r = tinsel_amd.create_gpu_renderer(scene, local)
-    bvh_build_ms = r.set_mesh_bvh(abi.BVH_LBVH) if args.bvh == "lbvh" else None
+    bvh_build_ms = r.set_mesh_bvh(abi.BVH_LBVH if args.bvh == "lbvh" else abi.BVH_PLOC) if args.bvh != "reference" else None
     if args.roulette > 0:
         r.set_russian_roulette(args.roulette)
     r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])

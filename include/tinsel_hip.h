@@ -227,8 +227,10 @@ int tinsel_hip_read_accum(tinsel_hip* r, float* out_rgba);
  * TINSEL_BVH_LBVH: rebuild every mesh that does not live in LDS on the DEVICE (Morton-code linear BVH, one
  * triangle per leaf like the reference's trees; tn_lbvh.h) -- for meshes rebuilt per frame (main.cpp:318-327
  * re-inits per batch frame) or too large to wait for the host SAH sweep.  Same hits except exact ties; slower
- * to traverse than the SAH tree, far faster to build.  *build_ms (may be NULL) receives the device build time. */
-enum { TINSEL_BVH_REFERENCE = 0, TINSEL_BVH_LBVH = 1 };
+ * to traverse than the SAH tree, far faster to build.  TINSEL_BVH_PLOC: the same, the hierarchy by parallel locally-ordered
+ * clustering over the Morton order (agglomerative, surface-area driven: close to the SAH tree in render speed, a few ms to build).
+ * *build_ms (may be NULL) receives the device build time. */
+enum { TINSEL_BVH_REFERENCE = 0, TINSEL_BVH_LBVH = 1, TINSEL_BVH_PLOC = 2 };
 int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms);
 
 /* Refit for deforming meshes (per-frame vertex animation with unchanged topology; the reference rebuilds with its host SAH

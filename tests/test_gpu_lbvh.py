@@ -24,21 +24,25 @@ def _golden(name):
     return scene, cam, opt, g
 
 
-def test_lbvh_image_matches_reference_tree_and_restores():
+MODES = [(abi.BVH_LBVH, "LBVH"), (abi.BVH_PLOC, "PLOC")]
+
+
+@pytest.mark.parametrize("mode,label", MODES, ids=["lbvh", "ploc"])
+def test_lbvh_image_matches_reference_tree_and_restores(mode, label):
     import tinsel_amd
     scene, cam, opt, g = _golden("ajax_standin_96")
     passes = int(g["passes"])
     r = tinsel_amd.create_gpu_renderer(scene)
     ref_stack = r.stack_entries
-    ms = r.set_mesh_bvh(abi.BVH_LBVH)
+    ms = r.set_mesh_bvh(mode)
     assert ms > 0.0
     r.init(opt.width, opt.height)
     out = r.render(cam, opt, passes=passes)
     rad = r.batch_radiance(passes, opt.height, opt.width)
     same = np.all(rad == g["radiance"], axis=-1).mean()
     l2 = oa.image_l2(out, g["accum"])
-    print("LBVH (18,432 tris) built in %.3f ms, stack %d -> %d entries; paths bit-identical to the reference tree: %.4f %%, "
-          "per-pixel L2 %.3e" % (ms, ref_stack, r.stack_entries, 100*same, l2))
+    print("%s (18,432 tris) built in %.3f ms, stack %d -> %d entries; paths bit-identical to the reference tree: %.4f %%, "
+          "per-pixel L2 %.3e" % (label, ms, ref_stack, r.stack_entries, 100*same, l2))
     assert same >= 0.999 and l2 <= 1e-3
     # back to the reference trees: bit-identical again
     assert r.set_mesh_bvh(abi.BVH_REFERENCE) == 0.0
@@ -49,7 +53,8 @@ def test_lbvh_image_matches_reference_tree_and_restores():
     r.close()
 
 
-def test_lbvh_closest_hits_equal_reference_tree():
+@pytest.mark.parametrize("mode,label", MODES, ids=["lbvh", "ploc"])
+def test_lbvh_closest_hits_equal_reference_tree(mode, label):
     """PrimitiveIntersect on 400k random rays at the mesh primitive: same hit / miss and same t under both trees
     (a tie between two triangles at exactly the same t gives the same t either way)."""
     import ctypes as C
@@ -67,7 +72,7 @@ def test_lbvh_closest_hits_equal_reference_tree():
     rows = np.concatenate([o, d, np.zeros((n, 1), np.float32)], axis=1)
     r = tinsel_amd.create_gpu_renderer(scene)
     a = r.leaf(4, mesh_prim, n, 5, rows=rows)
-    r.set_mesh_bvh(abi.BVH_LBVH)
+    r.set_mesh_bvh(mode)
     b = r.leaf(4, mesh_prim, n, 5, rows=rows)
     r.close()
     hit_a, hit_b = a[:, 0] > 0.5, b[:, 0] > 0.5
@@ -79,7 +84,8 @@ def test_lbvh_closest_hits_equal_reference_tree():
 
 
 @pytest.mark.skipif(not os.path.exists(LARGE), reason="tests/golden/large/ajax_standin.pack not generated (make_large.py)")
-def test_lbvh_524k_triangles():
+@pytest.mark.parametrize("mode,label", MODES, ids=["lbvh", "ploc"])
+def test_lbvh_524k_triangles(mode, label):
     import tinsel_amd
     scene = tinsel_amd.Scene.load_pack(LARGE)
     cam, opt = scene.camera, scene.options.copy()
@@ -88,15 +94,15 @@ def test_lbvh_524k_triangles():
     r.init(1920, 1080)
     r.render(cam, opt, passes=1, readback=False)
     ref = r.batch_radiance(1, 1080, 1920)[0]
-    r.set_mesh_bvh(abi.BVH_LBVH)            # first build pays allocation; time the second
+    r.set_mesh_bvh(mode)                    # first build pays allocation; time the second
     r.set_mesh_bvh(abi.BVH_REFERENCE)
-    ms = r.set_mesh_bvh(abi.BVH_LBVH)
+    ms = r.set_mesh_bvh(mode)
     r.init(1920, 1080)
     r.set_pass_index(0)
     r.render(cam, opt, passes=1, readback=False)
     got = r.batch_radiance(1, 1080, 1920)[0]
     same = np.all(ref == got, axis=-1).mean()
-    print("LBVH over 524,288 triangles built on the device in %.3f ms (stack %d entries); paths identical to the "
-          "reference tree: %.4f %%" % (ms, r.stack_entries, 100*same))
+    print("%s over 524,288 triangles built on the device in %.3f ms (stack %d entries); paths identical to the "
+          "reference tree: %.4f %%" % (label, ms, r.stack_entries, 100*same))
     r.close()
     assert same >= 0.999

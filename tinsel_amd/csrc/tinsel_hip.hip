@@ -11,6 +11,7 @@
 #include "tn_ubench.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types only: the library is dlopen'ed by the first multi-GPU group (no link-time dependency)
@@ -1548,17 +1549,21 @@ struct ScratchPool
     }
 };
 
-// Builds a linear BVH over mesh `dm`'s triangles; on success fills nodes/root/stackNeed of `out`.
-int build_lbvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out)
+// Builds a BVH over mesh `dm`'s triangles on the device -- TINSEL_BVH_LBVH: Karras' hierarchy over the Morton order + box fitting level by
+// level; TINSEL_BVH_PLOC: agglomerative clustering over the same order (tn_lbvh.h) -- and emits it with its top numbered breadth-first
+// (k_walk stages a prefix of the node array into LDS).  On success fills nodes / root / stackNeed / topCount of `out`.
+int build_device_bvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out, int mode)
 {
     const int n = dm.numTris;
-    size_t sortBytes = 0;
-    if (rocprim::radix_sort_keys(nullptr, sortBytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)n, 0, 62, nullptr) != hipSuccess)
-        return fail("build_mesh_bvh: sort sizing failed");
+    size_t sortBytes = 0, scanBytes = 0;
+    if (rocprim::radix_sort_keys(nullptr, sortBytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)n, 0, 62, nullptr) != hipSuccess ||
+        rocprim::exclusive_scan(nullptr, scanBytes, (int*)nullptr, (int*)nullptr, 0, (size_t)n, rocprim::plus<int>(), nullptr) != hipSuccess)
+        return fail("build_mesh_bvh: sort / scan sizing failed");
     const size_t N = (size_t)n;
     ScratchPool tmp;
     if (!tmp.reserve(ScratchPool::padded(6*4) + 2*ScratchPool::padded(N*8) + ScratchPool::padded((N - 1)*8) + 2*ScratchPool::padded((2*N - 1)*4) +
-                     ScratchPool::padded((2*N - 1)*24) + ScratchPool::padded((N - 1)*4) + ScratchPool::padded(sortBytes)))
+                     ScratchPool::padded((2*N - 1)*24) + 7*ScratchPool::padded(N*4) + ScratchPool::padded(sortBytes) + ScratchPool::padded(scanBytes) +
+                     ScratchPool::padded(kWalkTopNodes*4) + 256))
         return fail("build_mesh_bvh: device allocation failed");
     uint32_t* bounds = tmp.get<uint32_t>(6);
     unsigned long long* keys = tmp.get<unsigned long long>(N);
@@ -1567,11 +1572,20 @@ int build_lbvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out)
     int* parent = tmp.get<int>(2*N - 1);
     float* boxes = tmp.get<float>((2*N - 1)*6);
     int* height = tmp.get<int>(2*N - 1);
-    int* visits = tmp.get<int>(N - 1);
+    int* visits = tmp.get<int>(N);          // LBVH: the fitting passes' generations; PLOC: nearest neighbours
+    int* clustersA = tmp.get<int>(N);
+    int* clustersB = tmp.get<int>(N);
+    int* keep = tmp.get<int>(N);
+    int* offsets = tmp.get<int>(N);
+    int* isTop = tmp.get<int>(N);
+    int* perm = tmp.get<int>(N);
     unsigned char* sortTmp = tmp.get<unsigned char>(sortBytes);
+    unsigned char* scanTmp = tmp.get<unsigned char>(scanBytes);
+    int* topIds = tmp.get<int>(kWalkTopNodes);
+    int* nextId = tmp.get<int>(2);          // [0] the next internal node id, [1] clusters left after a round
     Node64* nodes = nullptr;
-    if (!bounds || !keys || !sorted || !children || !parent || !boxes || !height || !visits || !sortTmp ||
-        hipMalloc((void**)&nodes, sizeof(Node64)*(N - 1)) != hipSuccess)
+    if (!bounds || !keys || !sorted || !children || !parent || !boxes || !height || !visits || !clustersA || !clustersB || !keep || !offsets || !isTop ||
+        !perm || !sortTmp || !scanTmp || !topIds || !nextId || hipMalloc((void**)&nodes, sizeof(Node64)*(N - 1)) != hipSuccess)
         return fail("build_mesh_bvh: device allocation failed");
 
     const uint32_t init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
@@ -1580,30 +1594,84 @@ int build_lbvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out)
     do
     {
         if (hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, nullptr) != hipSuccess ||
-            hipMemsetAsync(visits, 0, sizeof(int)*((size_t)n - 1), nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: init failed"); break; }
+            hipMemsetAsync(visits, 0, sizeof(int)*(size_t)n, nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: init failed"); break; }
         hipLaunchKernelGGL(k_lbvh_bounds, dim3(grid < 256u ? grid : 256u), dim3(256), 0, nullptr, dm.tris, n, bounds);
         hipLaunchKernelGGL(k_lbvh_keys, dim3(grid), dim3(256), 0, nullptr, dm.tris, n, bounds, keys);
         if (rocprim::radix_sort_keys(sortTmp, sortBytes, keys, sorted, (size_t)n, 0, 62, nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: sort failed"); break; }
-        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(grid), dim3(256), 0, nullptr, sorted, n, children, parent);
         hipLaunchKernelGGL(k_lbvh_leaves, dim3(grid), dim3(256), 0, nullptr, dm.tris, sorted, n, boxes, height);
-        // one pass per tree level (<= 63 for 62-bit keys); look at the root every 16 passes
-        int rootGen = 0;
-        for (int pass = 2; pass <= 66 && !rootGen; )
+        if (mode == TINSEL_BVH_PLOC)
         {
-            for (int k = 0; k < 16; ++k, ++pass)
-                hipLaunchKernelGGL(k_lbvh_fit_pass, dim3(grid), dim3(256), 0, nullptr, n, pass, children, boxes, height, visits);
-            if (hipMemcpy(&rootGen, visits, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            // agglomerative rounds over the Morton order; the host reads the number of clusters left after every round (8 B)
+            const int firstId = n - 2;
+            if (hipMemcpyAsync(nextId, &firstId, sizeof(int), hipMemcpyHostToDevice, nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: init failed"); break; }
+            hipLaunchKernelGGL(k_ploc_init, dim3(grid), dim3(256), 0, nullptr, n, clustersA);
+            int c = n;
+            int* cur = clustersA;
+            int* nxt = clustersB;
+            int rounds = 0;
+            while (c > 1 && !rc)
+            {
+                const unsigned g = (unsigned)((c + 255)/256);
+                hipLaunchKernelGGL(k_ploc_nearest, dim3(g), dim3(256), 0, nullptr, (const int*)cur, c, (const float*)boxes, visits);
+                hipLaunchKernelGGL(k_ploc_merge, dim3(g), dim3(256), 0, nullptr, cur, c, (const int*)visits, boxes, children, height, nextId, keep);
+                if (rocprim::exclusive_scan(scanTmp, scanBytes, keep, offsets, 0, (size_t)c, rocprim::plus<int>(), nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: scan failed"); break; }
+                hipLaunchKernelGGL(k_ploc_compact, dim3(g), dim3(256), 0, nullptr, (const int*)cur, c, (const int*)keep, (const int*)offsets, nxt, nextId + 1);
+                int left = 0;
+                if (hipMemcpy(&left, nextId + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("build_mesh_bvh: read-back failed"); break; }
+                if (left >= c || left < 1 || ++rounds > 4096) { rc = fail("build_mesh_bvh: clustering made no progress"); break; }
+                c = left;
+                std::swap(cur, nxt);
+            }
+            if (rc)
                 break;
         }
-        if (!rootGen) { rc = fail("build_mesh_bvh: box fitting did not reach the root"); break; }
-        hipLaunchKernelGGL(k_lbvh_emit, dim3(grid), dim3(256), 0, nullptr, sorted, n, children, boxes, nodes);
+        else
+        {
+            hipLaunchKernelGGL(k_lbvh_hierarchy, dim3(grid), dim3(256), 0, nullptr, sorted, n, children, parent);
+            // one pass per tree level (<= 63 for 62-bit keys); look at the root every 16 passes
+            int rootGen = 0;
+            for (int pass = 2; pass <= 66 && !rootGen; )
+            {
+                for (int k = 0; k < 16; ++k, ++pass)
+                    hipLaunchKernelGGL(k_lbvh_fit_pass, dim3(grid), dim3(256), 0, nullptr, n, pass, children, boxes, height, visits);
+                if (hipMemcpy(&rootGen, visits, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+                    break;
+            }
+            if (!rootGen) { rc = fail("build_mesh_bvh: box fitting did not reach the root"); break; }
+        }
+
+        // the tree's top, breadth-first: the host walks the first kWalkTopNodes internal nodes (children: 8 B per node)
+        std::vector<int2> hostChildren(N - 1);
+        if (hipMemcpy(hostChildren.data(), children, sizeof(int2)*(N - 1), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("build_mesh_bvh: read-back failed"); break; }
+        std::vector<int> topOrder;
+        topOrder.reserve(kWalkTopNodes);
+        {
+            std::vector<int> frontier(1, 0);
+            size_t head = 0;
+            while (head < frontier.size() && (int)topOrder.size() < kWalkTopNodes)
+            {
+                const int id = frontier[head++];
+                topOrder.push_back(id);
+                const int2 ch = hostChildren[(size_t)id];
+                if (ch.x < n - 1) frontier.push_back(ch.x);
+                if (ch.y < n - 1) frontier.push_back(ch.y);
+            }
+        }
+        const int top = (int)topOrder.size();
+        if (hipMemsetAsync(isTop, 0, sizeof(int)*(N - 1), nullptr) != hipSuccess ||
+            hipMemcpy(topIds, topOrder.data(), sizeof(int)*(size_t)top, hipMemcpyHostToDevice) != hipSuccess) { rc = fail("build_mesh_bvh: upload failed"); break; }
+        int* rank = keep;           // (free again)
+        hipLaunchKernelGGL(k_bfs_mark, dim3((unsigned)((top + 255)/256)), dim3(256), 0, nullptr, (const int*)topIds, top, isTop, rank);
+        if (rocprim::exclusive_scan(scanTmp, scanBytes, isTop, offsets, 0, N - 1, rocprim::plus<int>(), nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: scan failed"); break; }
+        hipLaunchKernelGGL(k_bfs_perm, dim3(grid), dim3(256), 0, nullptr, n - 1, top, (const int*)isTop, (const int*)rank, (const int*)offsets, perm);
+        hipLaunchKernelGGL(k_lbvh_emit_perm, dim3(grid), dim3(256), 0, nullptr, sorted, n, children, boxes, (const int*)perm, nodes);
         int rootHeight = 0;
         if (hipGetLastError() != hipSuccess || hipMemcpy(&rootHeight, height, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("build_mesh_bvh: kernels failed"); break; }
         out = dm;
         out.nodes = nodes;
-        out.root = 0;
+        out.root = 0;                   // perm[0] == 0: the root is the first node of the breadth-first walk
         out.stackNeed = rootHeight + 1;
-        out.topCount = 0;               // Karras numbering: no breadth-first prefix to stage
+        out.topCount = top;
     } while (false);
     if (rc)
         (void)hipFree(nodes);
@@ -2297,7 +2365,7 @@ int tinsel_image_quantize_rgb8(const float* rgba, int width, int height, unsigne
 int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
 {
     lookahead_cancel(r);
-    if (!r || (mode != TINSEL_BVH_REFERENCE && mode != TINSEL_BVH_LBVH))
+    if (!r || (mode != TINSEL_BVH_REFERENCE && mode != TINSEL_BVH_LBVH && mode != TINSEL_BVH_PLOC))
         return fail("set_mesh_bvh: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -2306,7 +2374,7 @@ int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
 
     std::vector<DevMesh> next = r->meshesRef;
     const size_t prevAllocs = r->lbvhAllocs.size();
-    if (mode == TINSEL_BVH_LBVH)
+    if (mode != TINSEL_BVH_REFERENCE)
     {
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
@@ -2315,7 +2383,7 @@ int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms)
         int rc = 0;
         for (size_t m = 0; m < next.size() && !rc; ++m)
             if (!next[m].inArena && next[m].numTris >= 2)       // LDS-resident meshes keep their (tiny) reference trees
-                rc = build_lbvh(r, r->meshesRef[m], next[m]);
+                rc = build_device_bvh(r, r->meshesRef[m], next[m], mode);
         (void)hipEventRecord(e1, nullptr);
         (void)hipEventSynchronize(e1);
         float ms = 0.0f;
