@@ -1004,7 +1004,36 @@ int streaming_grid(const tinsel_hip* r, size_t slots, int pipeline)
     // waves per SIMD -- where the batch has that many 256-path pieces: a 1 M-path batch would otherwise leave the third wave slot empty)
     static const int gridMin = getenv("TINSEL_HIP_GRID_MIN") ? std::max(1, atoi(getenv("TINSEL_HIP_GRID_MIN"))) : 3;
     const size_t lo = std::min<size_t>((size_t)r->numCUs*(size_t)gridMin, (slots + kBlock - 1)/kBlock), hi = (size_t)r->numCUs*(size_t)grid_mult();
-    return (int)std::max<size_t>(1, std::min(hi, std::max(lo, blocks)));
+    size_t grid = std::max<size_t>(1, std::min(hi, std::max(lo, blocks)));
+    // The workgroups that HAVE work (regions are a whole number of waves long, so fewer than the grid may) as close to a whole number
+    // of resident sets (gridMin per CU) as the region length allows within +-25 %: the last set of a launch is then full instead
+    // of, say, two thirds empty.  Glass at 20 passes per batch 1262 -> 1291 Msamples/s, the 524k-triangle config 2024 -> 2034, the
+    // fused configs +-0 (profiles/r03_s_ab_grid_round.txt); TINSEL_HIP_GRID_ROUND=0: off (A/B)
+    static const bool roundGrid = !(getenv("TINSEL_HIP_GRID_ROUND") && atoi(getenv("TINSEL_HIP_GRID_ROUND")) == 0);
+    const size_t resident = (size_t)r->numCUs*(size_t)gridMin;
+    if (roundGrid && grid > 2*resident)
+    {
+        auto busy = [&](size_t g) {         // workgroups with work for a grid of g (set_regions' region length)
+            const size_t regions = g*(kBlock/kWave);
+            const size_t len = ((slots + regions - 1)/regions + kWave - 1)/kWave*kWave;
+            return (slots + len*(kBlock/kWave) - 1)/(len*(kBlock/kWave));
+        };
+        size_t best = grid;
+        double bestWaste = 2.0;
+        for (size_t g = std::max(grid*3/4, 2*resident); g <= std::min(hi, grid*5/4); g += std::max<size_t>(1, resident/16))
+        {
+            const size_t b = busy(g);
+            const double sets = (double)b/(double)resident;
+            const double waste = std::ceil(sets) - sets;        // empty fraction of the last resident set
+            if (waste < bestWaste - 1e-9)
+            {
+                bestWaste = waste;
+                best = g;
+            }
+        }
+        grid = best;
+    }
+    return (int)grid;
 }
 
 int set_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int gridPersist)
