@@ -409,6 +409,15 @@ int tinsel_hip_group_size(tinsel_hip_group* g);
  * Whatever the group had speculated is dropped first (look-ahead starts over with the next read-back). */
 tinsel_hip* tinsel_hip_group_member(tinsel_hip_group* g, int rank);
 
+/* Exhaustive self-test of the parity arm's short reciprocal / square-root sequences (tn_math.h rcp_candidate / sqrt_candidate):
+ * compares the candidate with the compiler's correctly rounded `1.0f/x` (op 0) or `sqrtf(x)` (op 1) on ALL 2^32 fp32 bit patterns
+ * on the device.  variant < 0: the variant this library's kernels are built with (0 = the compiler's own expansion).
+ * out_counts[260]: [0..3] mismatches in total / with a denormal operand / with |x| >= 2^126 (op 0) or x < 0 (op 1) / any
+ * other; [4 + e] mismatches by the operand's exponent field e;
+ * out_first_bad: the smallest mismatching bit pattern (0xffffffff when none).  No reference counterpart (test infrastructure
+ * of this library: the reference divides with the host FPU / nvcc's IEEE division, render.cpp / maths.h throughout). */
+int tinsel_hip_selftest_arith(int device_index, int op, int variant, unsigned long long* out_counts, unsigned int* out_first_bad);
+
 /* Yard-sticks measured on the GPU itself, for bench.py's roofline (not part of the render path): kind 0 = a float4 stream
  * copy of `bytes` bytes (*out_units = bytes read + written); kinds 1..3 = dependent chases through a table of 64-B records
  * of `bytes` bytes (rounded down to a power of two), `steps` visits per lane, 16 waves per CU (*out_units = records

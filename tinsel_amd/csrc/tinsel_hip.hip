@@ -9,6 +9,7 @@
 #include "tn_launch.h"
 #include "tn_lbvh.h"
 #include "tn_ubench.h"
+#include "tn_selftest.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -2956,6 +2957,61 @@ int tinsel_hip_queue_counts(tinsel_hip* r, uint32_t* out, int max_bounces)
 // kinds 1..3 = dependent 64-B record chases through a table of `bytes` bytes rounded down to a power of two, `steps` visits
 // per lane (units = records visited); the kind only names the kernel for the profiler (1 beyond the Infinity Cache, 2 the size
 // of a walked tree, 3 inside one L2).  One warm-up launch, then one timed with HIP events.
+int tinsel_hip_selftest_arith(int device_index, int op, int variant, unsigned long long* out_counts, unsigned int* out_first_bad)
+{
+    if (!out_counts || !out_first_bad || op < 0 || op > 1)
+        return fail("selftest_arith: bad arguments");
+    if (variant < 0)
+        variant = op == 0 ? TN_RCP_VARIANT : TN_SQRT_VARIANT;      // what this library is built with
+    HIP_TRY(hipSetDevice(device_index));
+    unsigned long long* counts = nullptr;
+    uint32_t* first = nullptr;
+    HIP_TRY(hipMalloc((void**)&counts, 260*sizeof(unsigned long long)));
+    if (hipMalloc((void**)&first, sizeof(uint32_t)) != hipSuccess)
+    {
+        (void)hipFree(counts);
+        return fail("selftest_arith: allocation failed");
+    }
+    (void)hipMemset(counts, 0, 260*sizeof(unsigned long long));
+    (void)hipMemset(first, 0xff, sizeof(uint32_t));
+    bool known = true;
+    switch (op*100 + variant)
+    {
+    case 0: launch_selftest_arith<0, 0>(counts, first); break;
+    case 1: launch_selftest_arith<0, 1>(counts, first); break;
+    case 2: launch_selftest_arith<0, 2>(counts, first); break;
+    case 3: launch_selftest_arith<0, 3>(counts, first); break;
+    case 11: launch_selftest_arith<0, 11>(counts, first); break;
+    case 12: launch_selftest_arith<0, 12>(counts, first); break;
+    case 13: launch_selftest_arith<0, 13>(counts, first); break;
+    case 100: launch_selftest_arith<1, 0>(counts, first); break;
+    case 101: launch_selftest_arith<1, 1>(counts, first); break;
+    case 102: launch_selftest_arith<1, 2>(counts, first); break;
+    case 103: launch_selftest_arith<1, 3>(counts, first); break;
+    case 104: launch_selftest_arith<1, 4>(counts, first); break;
+    case 105: launch_selftest_arith<1, 5>(counts, first); break;
+    case 114: launch_selftest_arith<1, 14>(counts, first); break;
+    case 115: launch_selftest_arith<1, 15>(counts, first); break;
+    case 121: launch_selftest_arith<1, 21>(counts, first); break;
+    case 122: launch_selftest_arith<1, 22>(counts, first); break;
+    case 124: launch_selftest_arith<1, 24>(counts, first); break;
+    case 111: launch_selftest_arith<1, 11>(counts, first); break;
+    case 112: launch_selftest_arith<1, 12>(counts, first); break;
+    case 113: launch_selftest_arith<1, 13>(counts, first); break;
+    default: known = false; break;
+    }
+    int rc = 0;
+    if (!known)
+        rc = fail("selftest_arith: unknown variant");
+    else if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess ||
+             hipMemcpy(out_counts, counts, 260*sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+             hipMemcpy(out_first_bad, first, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail("selftest_arith: kernel failed");
+    (void)hipFree(counts);
+    (void)hipFree(first);
+    return rc;
+}
+
 int tinsel_hip_ubench(int device_index, int kind, unsigned long long bytes, int steps, double* out_ms, double* out_units)
 {
     if (kind < 0 || kind > 3 || bytes < 4096 || !out_ms || !out_units)

@@ -40,7 +40,7 @@ TN_D bool refract(V3 wi, V3 n, float eta, V3& wt)
     float sin2ThetaT = eta*eta*sin2ThetaI;
     if (sin2ThetaT >= 1)
         return false;
-    float cosThetaT = sqrtf(1.0f - sin2ThetaT);
+    float cosThetaT = sqrtf_cr(1.0f - sin2ThetaT);
     wt = eta*(-wi) + (eta*cosThetaI - cosThetaT)*n;
     return true;
 }
@@ -72,7 +72,7 @@ TN_D float smith_ggx(float NDotv, float alphaG)    // disney.h:71-76
 {
     float a = alphaG*alphaG;
     float b = NDotv*NDotv;
-    return 1/(NDotv + sqrtf(a + b - a*b));
+    return rcpf_cr(NDotv + sqrtf_cr(a + b - a*b));
 }
 
 TN_D float fresnel_dielectric(float VDotN, float etaI, float etaT)     // Fr, disney.h:79-96
@@ -80,7 +80,7 @@ TN_D float fresnel_dielectric(float VDotN, float etaI, float etaT)     // Fr, di
     float SinThetaT2 = sqr(etaI/etaT)*(1.0f - VDotN*VDotN);
     if (SinThetaT2 > 1.0f)
         return 1.0f;
-    float LDotN = sqrtf(1.0f - SinThetaT2);
+    float LDotN = sqrtf_cr(1.0f - SinThetaT2);
     float eta = etaT/etaI;
     float r1 = (VDotN - eta*LDotN)/(VDotN + eta*LDotN);
     float r2 = (LDotN - eta*VDotN)/(LDotN + eta*VDotN);
@@ -118,8 +118,8 @@ TN_D float bsdf_pdf(const Mat& mat, float etaI, float etaO, V3 n, V3 V, V3 L)
 TN_D V3 sample_ggx_reflection(const Mat& mat, V3 U, V3 Vt, V3 N, V3 view, float sinPhiHalf, float cosPhiHalf, float r2)
 {
     const float a = maxT(0.001f, mat.roughness);
-    const float cosThetaHalf = sqrtf((1.0f - r2)/(1.0f + (sqr(a) - 1.0f)*r2));
-    const float sinThetaHalf = sqrtf(maxT(0.0f, 1.0f - sqr(cosThetaHalf)));
+    const float cosThetaHalf = sqrtf_cr((1.0f - r2)/(1.0f + (sqr(a) - 1.0f)*r2));
+    const float sinThetaHalf = sqrtf_cr(maxT(0.0f, 1.0f - sqr(cosThetaHalf)));
 
     V3 half = U*(sinThetaHalf*cosPhiHalf) + Vt*(sinThetaHalf*sinPhiHalf) + N*cosThetaHalf;
     if (dot(half, view) <= 0.0f)
@@ -196,17 +196,17 @@ TN_D void bsdf_sample(const Mat& mat, float etaI, float etaO, V3 U, V3 Vt, V3 N,
     else if (lobe == kLobeCosine)
     {
         // CosineSampleHemisphere (maths.h:1304-1310, 1319-1325)
-        const float r = sqrtf(r1);
+        const float r = sqrtf_cr(r1);
         const float sx = r*cs;
         const float sy = r*sn;
-        const float z = sqrtf(maxT(0.0f, 1.0f - sx*sx - sy*sy));
+        const float z = sqrtf_cr(maxT(0.0f, 1.0f - sx*sx - sy*sy));
         light = U*sx + Vt*sy + N*z;
         type = kReflected;
     }
     else
     {
         // UniformSampleHemisphere (maths.h:1291-1302), z negated to sample inside the surface
-        const float w = sqrtf(1.0f - zIn*zIn);
+        const float w = sqrtf_cr(1.0f - zIn*zIn);
         const float x = cs*w;
         const float y = sn*w;
         light = U*x + Vt*y - N*zIn;

@@ -92,7 +92,7 @@ TN_D void on_hit_begin(PathRegs& p, const Mat& mat, float t, V3 n, int bounce, H
         float lightArea = mat.area;
         if (lightArea > 0.0f)
         {
-            float lightPdf = ((1.0f/lightArea)*t*t)/clampT(dot(-p.d, n), 1.e-3f, 1.0f);
+            float lightPdf = (rcpf_cr(lightArea)*t*t)/clampT(dot(-p.d, n), 1.e-3f, 1.0f);
 
             int N = int(float(mat.lightSamples) + kBsdfSamples);
             float cbsdf = kBsdfSamples/N;
@@ -115,7 +115,7 @@ struct NeeGeo
 {
     V3 o;               // shadow origin
     V3 wi;
-    float dist;         // sqrtf(dSq) for area lights; < 0 marks a probe sample
+    float dist;         // sqrtf_cr(dSq) for area lights; < 0 marks a probe sample
     float nl;           // |dot(lightNormal, wi)|
 };
 
@@ -178,11 +178,11 @@ TN_D void nee_sample_light(const SC& sc, V3 hitP, V3 hitN, float time, int light
 
     V3 wi = lightPos - hitP;
     float dSq = length_sq(wi);
-    wi = divs(wi, sqrtf(dSq));                  // wi /= sqrtf(dSq)  (maths.h:251)
+    wi = divs(wi, sqrtf_cr(dSq));                  // wi /= sqrtf_cr(dSq)  (maths.h:251)
 
     g.o = hitP + face_forward(hitN, wi)*kRayEpsilon;
     g.wi = wi;
-    g.dist = sqrtf(dSq);
+    g.dist = sqrtf_cr(dSq);
     g.nl = absf(dot(lightNormal, wi));
 }
 
@@ -202,7 +202,7 @@ TN_D V3 nee_contrib_light(const DevScene& sc, const Mat& surf, const HitCtx& h, 
     const float lightArea = lm->area;
     const int lightSamples = lm->lightSamples;
     float tSq = t*t;
-    float lightPdf = ((1.0f/lightArea)*tSq)/nl;
+    float lightPdf = (rcpf_cr(lightArea)*tSq)/nl;
 
     const float bsdfPdf = bsdf_pdf(surf, h.etaI, h.etaO, h.n, h.wo, wi);
     if (bsdfPdf > 0.0f)
@@ -281,7 +281,7 @@ TN_D V3 nee_sum(const DevScene& sc, Contrib contrib)
         V3 L(0.0f);
         for (int s = 0; s < numSamples; ++s)
             L = L + contrib(k++);
-        sum = sum + L*(1.0f/numSamples);                    // render.cpp:223
+        sum = sum + L*rcpf_cr(numSamples);                    // render.cpp:223
     }
     return sum;
 }
@@ -337,7 +337,7 @@ TN_D bool roulette_survives(PathRegs& p)
         const float u = p.rng.randf();
         if (u >= q)
             return false;
-        p.thr = p.thr*(1.0f/q);
+        p.thr = p.thr*rcpf_cr(q);
     }
     return true;
 }

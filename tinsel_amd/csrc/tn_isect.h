@@ -99,7 +99,7 @@ TN_D bool ray_sphere(V3 center, float radius, V3 o, V3 d, float& outT, V3& outN)
         return false;
 
     float sgn = (b < 0.0f) ? -1.0f : 1.0f;                 // Sign (maths.h:43)
-    float tt = -0.5f*(b + sgn*sqrtf(disc));
+    float tt = -0.5f*(b + sgn*sqrtf_cr(disc));
     float t0 = tt/a;
     float t1 = c/tt;
     if (t1 < t0) { float tmp = t0; t0 = t1; t1 = tmp; }    // Sort2 (intersection.h:9-13)
@@ -133,7 +133,7 @@ TN_D bool ray_tri(V3 p, V3 dir, V3 a, V3 b, V3 c, float& t, float& u, float& v, 
 
     V3 nd = -dir;
     float d = dot(nd, n);
-    float ood = 1.0f/d;
+    float ood = rcpf_cr(d);
     V3 ap = p - a;
 
     t = dot(ap, n)*ood;
@@ -168,7 +168,7 @@ struct MeshHit
 template <bool COUNT>
 TN_D bool ray_mesh_two_leaves(const Node64* mnodes, const Tri48* mtris, uint32_t mroot, V3 o, V3 d, MeshHit& hit, TraceCounters& ctr)
 {
-    const V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    const V3 rcp = rcp3_cr(d);
     const Node64 nd = load_node(mnodes, mroot);
     if (COUNT) ctr.internal++;
 
@@ -215,7 +215,7 @@ TN_D bool ray_mesh(const Node64* mnodes, const Tri48* mtris, uint32_t mroot, Sta
 {
     float closestT = kFltMax;
     float tmax = kFltMax;
-    V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    V3 rcp = rcp3_cr(d);
 
     const int base = sp;
     st.set(sp++, mroot);
@@ -491,7 +491,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
 template <class SC>
 TN_D bool ray_meets_bounded_prim(const SC& sc, V3 o, V3 d)
 {
-    const V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    const V3 rcp = rcp3_cr(d);
     bool any = false;
     for (int i = 0; i < sc.numPrims; ++i)
     {
@@ -528,7 +528,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
     int closest = -1;
     V3 cn;
 
-    V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    V3 rcp = rcp3_cr(d);
 
     // detail counting (COUNT) always walks the BVH: the counters define the reference algorithm's
     // per-ray constants I, T, P of the algorithmic-bytes model

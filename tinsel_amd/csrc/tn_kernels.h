@@ -763,7 +763,7 @@ struct BinPrims
 
 TN_D bool ray_enters_big_mesh(const PrimBox* __restrict__ primBoxes, const BinPrims& bp, V3 o, V3 d)
 {
-    const V3 rcp(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+    const V3 rcp = rcp3_cr(d);
     bool hit = !ray_sane(o);        // rays the flat scan refuses reach the mesh without a box test (trace, tn_isect.h)
     // fully unrolled with constant indices: bp lives in kernel-argument SGPRs, a dynamic index would spill it to scratch
 #pragma unroll

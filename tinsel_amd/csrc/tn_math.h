@@ -42,12 +42,151 @@ TN_HD V3 operator*(V3 a, float s) { return V3(a.x*s, a.y*s, a.z*s); }
 TN_HD V3 operator*(float s, V3 a) { return V3(a.x*s, a.y*s, a.z*s); }
 TN_HD V3 operator*(V3 a, V3 b) { return V3(a.x*b.x, a.y*b.y, a.z*b.z); }
 // operator/(Vec3, Real s) == a*(1.0/s)  (maths.h:242)
-TN_HD V3 divs(V3 a, float s) { float r = 1.0f/s; return V3(a.x*r, a.y*r, a.z*r); }
+TN_HD float rcpf_cr(float x);
+TN_HD float sqrtf_cr(float x);
+TN_HD V3 divs(V3 a, float s) { float r = rcpf_cr(s); return V3(a.x*r, a.y*r, a.z*r); }
+
+// ---------------------------------------------------------------------------
+// Correctly rounded 1/x and sqrt(x) without the compiler's general-purpose expansion.  hipcc expands an IEEE fp32 division into 12
+// VALU instructions (v_div_scale x2, v_rcp, five fma/mul, v_div_fmas, v_div_fixup) and sqrtf into 16 (2^32 scaling of small
+// operands, v_sqrt, two compare-and-step corrections, unscaling, class fix-up); k_bounce carries 228 divisions -- 110 of them
+// reciprocals -- and 76 square roots: ~30 % of its static VALU count.  For ONE operand the space is small enough to PROVE a shorter
+// sequence: the candidates below are compared with the compiler's `1.0f/x` and `sqrtf(x)` on ALL 2^32 bit patterns on the device
+// (tinsel_hip_selftest_arith, tests/test_gpu_arith.py); the library is built with a variant that showed zero mismatches -- NaNs,
+// infinities, zeros and denormals included.  Measured (profiles/r03_w_short_sqrt.md):
+//   sqrt 21  v_rsq + one coupled Newton step inside the compiler's own 2^32 scaling, branch-free, 12 VALU: exact on all 2^32;
+//            cornell +1.5 %, veach 4K +2.2 %, glass +1.2 %, ajax +0.6 %  -> the default
+//   sqrt 11  the same behind a branch (2^-96 <= x < inf, else sqrtf): exact; +0.7 % (the branch splits the scheduler's blocks)
+//   rcp 11   v_rcp + two Newton steps behind a branch (normal x, |x| < 2^126, else 1.0f/x): exact on all 2^32 but 4-5 % SLOWER --
+//            a straight-line form needs the quotient rounded once into the denormal range, which is what v_div_fmas is for: the
+//            compiler's expansion stays (variant 0); one guard per direction triple (TN_RCP3_GROUP) measured +-1 %: off
+#ifndef TN_RCP_VARIANT
+#define TN_RCP_VARIANT 0
+#endif
+#ifndef TN_RCP3_GROUP
+#define TN_RCP3_GROUP 0
+#endif
+#ifndef TN_SQRT_VARIANT
+#define TN_SQRT_VARIANT 21
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// variants 1..3: straight-line with v_div_fixup for the specials; 11..13: the same refinement behind a range guard (normal x,
+// |x| < 2^126 -- v_rcp_f32 flushes denormal operands and results), everything else through the compiler's division
+template <int V> __device__ __forceinline__ float rcp_refine(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    const float r1 = r;
+    e = __builtin_fmaf(-x, r, 1.0f);           // Markstein's correction of the quotient q = r
+    r = __builtin_fmaf(e, V == 3 ? r1 : r, r);
+    if (V >= 2)
+    {
+        e = __builtin_fmaf(-x, r, 1.0f);       // (the compiler's sequence runs this third step, with r1 as the multiplier: V == 3)
+        r = __builtin_fmaf(e, V == 3 ? r1 : r, r);
+    }
+    return r;
+}
+template <int V> __device__ __forceinline__ float rcp_candidate(float x)
+{
+    if (V == 0)
+        return 1.0f/x;
+    if (V < 10)
+        return __builtin_amdgcn_div_fixupf(rcp_refine<V>(x), x, 1.0f);     // zero, infinity, NaN
+    if (__builtin_expect(__builtin_isnormal(x) && __builtin_fabsf(x) < 0x1p126f, 1))
+        return rcp_refine<V - 10>(x);
+    return 1.0f/x;
+}
+
+// variants 1, 2: v_rsq_f32 + one / two Newton steps on s with a fixed h = y/2; 3: v_sqrt_f32 + the compiler's compare-and-step
+// without its denormal scaling; 4, 5: the coupled iteration (s and h refined together, then one / two Markstein steps);
+// 11..15: the same behind a guard (2^-96 <= x < inf: below, the residual x - s*s leaves the normal range), the rest through sqrtf;
+// 21..25: the same without a branch, small operands scaled by 2^32 as the compiler does
+template <int V> __device__ __forceinline__ float sqrt_refine(float x)
+{
+    if (V == 3)
+    {
+        float s = __builtin_amdgcn_sqrtf(x);
+        const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+        const float edn = __builtin_fmaf(-dn, s, x), eup = __builtin_fmaf(-up, s, x);
+        s = edn <= 0.0f ? dn : s;
+        s = eup > 0.0f ? up : s;
+        return s;
+    }
+    const float y = __builtin_amdgcn_rsqf(x);
+    float s = x*y;
+    float h = 0.5f*y;
+    if (V >= 4)
+    {
+        const float r = __builtin_fmaf(-h, s, 0.5f);
+        s = __builtin_fmaf(s, r, s);
+        h = __builtin_fmaf(h, r, h);
+    }
+    float e = __builtin_fmaf(-s, s, x);
+    s = __builtin_fmaf(e, h, s);
+    if (V == 2 || V == 5)
+    {
+        e = __builtin_fmaf(-s, s, x);
+        s = __builtin_fmaf(e, h, s);
+    }
+    return s;
+}
+template <int V> __device__ __forceinline__ float sqrt_candidate(float x)
+{
+    if (V == 0)
+        return sqrtf(x);
+    if (V < 10)     // +-0 and +inf pass through (rsq gives inf / 0 there and the products NaN); negative x and NaN are NaN either way
+        return (x == 0.0f || x == __builtin_inff()) ? x : sqrt_refine<V>(x);
+    if (V >= 20)
+    {
+        // branch-free: the compiler's own 2^32 scaling of small operands around the short iteration
+        const bool small = x < 0x1p-96f;
+        const float xs = small ? x*0x1p32f : x;
+        float s = sqrt_refine<V - 20>(xs);
+        s = small ? s*0x1p-16f : s;
+        return __builtin_amdgcn_classf(xs, 0x260) ? xs : s;       // -0, +0, +inf pass through
+    }
+    if (__builtin_expect(x >= 0x1p-96f && x < __builtin_inff(), 1))
+        return sqrt_refine<V - 10>(x);
+    return sqrtf(x);
+}
+#endif
+
+TN_HD float rcpf_cr(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(TN_FAST) && TN_FAST)
+    return rcp_candidate<TN_RCP_VARIANT>(x);
+#else
+    return 1.0f/x;
+#endif
+}
+TN_HD float sqrtf_cr(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(TN_FAST) && TN_FAST)
+    return sqrt_candidate<TN_SQRT_VARIANT>(x);
+#else
+    return sqrtf(x);
+#endif
+}
 
 TN_HD float dot(V3 a, V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }                                   // maths.h:257
 TN_HD V3 cross(V3 a, V3 b) { return V3(a.y*b.z - b.y*a.z, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x); }   // maths.h:256
+// the three reciprocals of a direction behind ONE guard (TN_RCP3_GROUP): a slab test's 1/d
+TN_HD V3 rcp3_cr(V3 d)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(TN_FAST) && TN_FAST) && TN_RCP3_GROUP
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    if (__builtin_expect(lo >= 0x1p-126f && hi < 0x1p126f && d.x == d.x && d.y == d.y && d.z == d.z, 1))
+        return V3(rcp_refine<1>(d.x), rcp_refine<1>(d.y), rcp_refine<1>(d.z));
+    return V3(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+#else
+    return V3(rcpf_cr(d.x), rcpf_cr(d.y), rcpf_cr(d.z));
+#endif
+}
 TN_HD float length_sq(V3 a) { return dot(a, a); }
-TN_HD float length(V3 a) { return sqrtf(dot(a, a)); }                                                // maths.h:259
+TN_HD float length(V3 a) { return sqrtf_cr(dot(a, a)); }                                                // maths.h:259
 TN_HD V3 normalize(V3 a) { return divs(a, length(a)); }                                              // maths.h:260
 
 // SafeNormalize (maths.h:261-273): a * (1.0/sqrt(m))
@@ -56,7 +195,7 @@ TN_HD V3 safe_normalize(V3 a, V3 fallback)
     float m = length_sq(a);
     if (m > 0.0f)
     {
-        float r = 1.0f/sqrtf(m);
+        float r = rcpf_cr(sqrtf_cr(m));
         return V3(a.x*r, a.y*r, a.z*r);
     }
     return fallback;
@@ -242,13 +381,13 @@ TN_D float m_acosf(float x)
         const float z = (one + x)*0.5f;
         const float p = z*(pS0 + z*(pS1 + z*(pS2 + z*(pS3 + z*(pS4 + z*pS5)))));
         const float q = one + z*(qS1 + z*(qS2 + z*(qS3 + z*qS4)));
-        const float sq = sqrtf(z);
+        const float sq = sqrtf_cr(z);
         const float r = p/q;
         const float w = r*sq - pio2_lo;
         return pi - 2.0f*(sq + w);
     }
     const float z = (one - x)*0.5f;
-    const float sq = sqrtf(z);
+    const float sq = sqrtf_cr(z);
     const float df = __uint_as_float(__float_as_uint(sq) & 0xfffff000u);
     const float c = (z - df*df)/(sq + df);
     const float p = z*(pS0 + z*(pS1 + z*(pS2 + z*(pS3 + z*(pS4 + z*pS5)))));
@@ -292,7 +431,7 @@ TN_D float m_atanf(float x)
         else
         {
             if (ix < 0x401c0000) { id = 2; hi = __uint_as_float(0x3f7b985eu); lo = __uint_as_float(0x33140fb4u); x = (x - 1.5f)/(one + 1.5f*x); }
-            else                 { id = 3; hi = __uint_as_float(0x3fc90fdau); lo = __uint_as_float(0x33a22168u); x = -1.0f/x; }
+            else                 { id = 3; hi = __uint_as_float(0x3fc90fdau); lo = __uint_as_float(0x33a22168u); x = -rcpf_cr(x); }
         }
     }
     const float z = x*x;
@@ -396,8 +535,8 @@ TN_HD V3 qrotate(Q4 q, V3 v)
 // Normalize(Quat)  (maths.h:547-553)
 TN_HD Q4 qnormalize(Q4 q)
 {
-    float len = sqrtf(q.x*q.x + q.y*q.y + q.z*q.z + q.w*q.w);
-    float r = 1.0f/len;
+    float len = sqrtf_cr(q.x*q.x + q.y*q.y + q.z*q.z + q.w*q.w);
+    float r = rcpf_cr(len);
     Q4 o = { q.x*r, q.y*r, q.z*r, q.w*r };
     return o;
 }
@@ -415,8 +554,8 @@ TN_HD Xform interpolate_xform(const Xform& a, const Xform& b, float t)
 
 TN_HD V3 xform_vector(const Xform& t, V3 v) { return qrotate(t.r, t.s*v); }                          // maths.h:601-604
 TN_HD V3 xform_point(const Xform& t, V3 v) { return t.p + qrotate(t.r, t.s*v); }                     // maths.h:606-609
-TN_HD V3 inv_xform_vector(const Xform& t, V3 v) { return (1.0f/t.s)*qrotate(qconj(t.r), v); }        // maths.h:611-614
-TN_HD V3 inv_xform_point(const Xform& t, V3 v) { return (1.0f/t.s)*qrotate(qconj(t.r), v - t.p); }   // maths.h:616-619
+TN_HD V3 inv_xform_vector(const Xform& t, V3 v) { return rcpf_cr(t.s)*qrotate(qconj(t.r), v); }        // maths.h:611-614
+TN_HD V3 inv_xform_point(const Xform& t, V3 v) { return rcpf_cr(t.s)*qrotate(qconj(t.r), v - t.p); }   // maths.h:616-619
 
 // ---------------------------------------------------------------------------
 // Random (maths.h:1036-1091): two-word xorshift/multiply generator
@@ -463,12 +602,12 @@ TN_HD void basis_from_vector(V3 w, V3& u, V3& v)
 {
     if (fabsf(w.x) > fabsf(w.y))
     {
-        float invLen = 1.0f/sqrtf(w.x*w.x + w.z*w.z);
+        float invLen = rcpf_cr(sqrtf_cr(w.x*w.x + w.z*w.z));
         u = V3(-w.z*invLen, 0.0f, w.x*invLen);
     }
     else
     {
-        float invLen = 1.0f/sqrtf(w.y*w.y + w.z*w.z);
+        float invLen = rcpf_cr(sqrtf_cr(w.y*w.y + w.z*w.z));
         u = V3(0.0f, w.z*invLen, -w.y*invLen);
     }
     v = cross(w, u);
@@ -478,7 +617,7 @@ TN_HD void basis_from_vector(V3 w, V3& u, V3& v)
 TN_D V3 uniform_sample_sphere(float u1, float u2)
 {
     float z = 1.f - 2.f*u1;
-    float r = sqrtf(maxT(0.f, 1.f - z*z));
+    float r = sqrtf_cr(maxT(0.f, 1.f - z*z));
     float phi = 2.f*kPi*u2;
     float sn, cs;
     m_sincosf(phi, sn, cs);
@@ -491,7 +630,7 @@ TN_D V3 uniform_sample_sphere(float u1, float u2)
 TN_D V3 uniform_sample_hemisphere(Rng& rng)
 {
     float z = rng.randf();
-    float w = sqrtf(1.0f - z*z);
+    float w = sqrtf_cr(1.0f - z*z);
     float phi = k2Pi*rng.randf();
     float sn, cs;
     m_sincosf(phi, sn, cs);
@@ -503,20 +642,20 @@ TN_D V3 uniform_sample_hemisphere(Rng& rng)
 // CosineSampleHemisphere (maths.h:1319-1325) via UniformSampleDisc (maths.h:1304-1310)
 TN_D V3 cosine_sample_hemisphere(float u1, float u2)
 {
-    float r = sqrtf(u1);
+    float r = sqrtf_cr(u1);
     float theta = k2Pi*u2;
     float sn, cs;
     m_sincosf(theta, sn, cs);
     float sx = r*cs;
     float sy = r*sn;
-    float z = sqrtf(maxT(0.0f, 1.0f - sx*sx - sy*sy));
+    float z = sqrtf_cr(maxT(0.0f, 1.0f - sx*sx - sy*sy));
     return V3(sx, sy, z);
 }
 
 // UniformSampleTriangle (maths.h:1312-1317)
 TN_D void uniform_sample_triangle(Rng& rng, float& u, float& v)
 {
-    float r = sqrtf(rng.randf());
+    float r = sqrtf_cr(rng.randf());
     u = 1.0f - r;
     v = rng.randf()*r;
 }

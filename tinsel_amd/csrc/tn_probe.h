@@ -127,7 +127,7 @@ TN_D V3 sky_eval(const DevScene& sc, V3 dir)
         return probe_eval(sc.probe, probe_dir_to_uv(dir));
     V3 h(sc.horizon[0], sc.horizon[1], sc.horizon[2]);
     V3 z(sc.zenith[0], sc.zenith[1], sc.zenith[2]);
-    return lerp3(h, z, sqrtf(absf(dir.y)));
+    return lerp3(h, z, sqrtf_cr(absf(dir.y)));
 }
 
 } // namespace tn

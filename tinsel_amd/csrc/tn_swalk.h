@@ -148,7 +148,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : TN_WAVES_SWALK) void k_s
                     }
                     o = V3(ro.x, ro.y, ro.z);
                     d = V3(rd.x, rd.y, rd.z);
-                    rcp = V3(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+                    rcp = rcp3_cr(d);
                     minT = kFltMax;
                     closest = -1;
                     cn = V3(0.0f);

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + index);
                         b0 = bp[0]; b1 = bp[1];
                     }
-                    const V3 wrcp(1.0f/wd.x, 1.0f/wd.y, 1.0f/wd.z);
+                    const V3 wrcp = rcp3_cr(wd);
                     float tbox;
                     bool enters = true;         // rays the scan does not box-test (ray_sane) are walked unconditionally
                     if (__float_as_uint(b1.z) == 0u && ray_sane(wo))
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         const Xform x = prim_pose(sc, p, time);
                         o = inv_xform_point(x, wo);
                         d = inv_xform_vector(x, wd);
-                        rcp = V3(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
+                        rcp = rcp3_cr(d);
                         if (single)
                         {
                             mnodes = mesh0nodes;

@@ -106,6 +106,7 @@ def load_library():
     L.tinsel_hip_group_member.argtypes = [vp, ci]
     L.tinsel_hip_group_set_lookahead.argtypes = [vp, ci]
     L.tinsel_hip_ubench.argtypes = [ci, ci, C.c_ulonglong, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.tinsel_hip_selftest_arith.argtypes = [ci, ci, ci, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
     L.tinsel_hip_last_error.restype = C.c_char_p
     L.tinsel_pack_open.argtypes = [vp, C.c_size_t, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.Options)]
     _lib = L
@@ -123,6 +124,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_walked_prims", "tinsel_hip_queue_counts", "tinsel_hip_set_lookahead", "tinsel_hip_set_arithmetic", "tinsel_hip_get_arithmetic", "tinsel_hip_refit_mesh", "tinsel_hip_set_probe_sampling",
     "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
     "tinsel_hip_group_size", "tinsel_hip_group_member", "tinsel_hip_group_set_lookahead", "tinsel_hip_ubench",
+    "tinsel_hip_selftest_arith",
 ]
 
 
@@ -430,6 +432,15 @@ def ubench(kind, nbytes, steps=64, device=0):
     ms, units = C.c_double(0.0), C.c_double(0.0)
     _check(L.tinsel_hip_ubench(int(device), int(kind), int(nbytes), int(steps), C.byref(ms), C.byref(units)), "tinsel_hip_ubench")
     return ms.value, units.value
+
+
+def selftest_arith(op, variant=-1, device=0):
+    """tinsel_hip_selftest_arith: (counts[4 + 256 by exponent field], first_bad) of the exhaustive 2^32-input comparison of a reciprocal (op 0) /
+    square-root (op 1) sequence with the compiler's IEEE expansion; variant -1 = the one the library is built with."""
+    L = load_library()
+    counts, first = (C.c_ulonglong*260)(), C.c_uint(0)
+    _check(L.tinsel_hip_selftest_arith(int(device), int(op), int(variant), counts, C.byref(first)), "tinsel_hip_selftest_arith")
+    return [int(c) for c in counts], int(first.value)
 
 
 def create_gpu_renderer(scene: Scene, device: int = 0) -> HipRenderer:
