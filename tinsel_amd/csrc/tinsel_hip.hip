@@ -398,8 +398,12 @@ struct tinsel_hip
     unsigned long long* walkProf = nullptr;             // developer-only (-DTN_WALK_PROF builds): section counters of k_walk
     uint2* probeAlias = nullptr;                        // alias table of the probe (tinsel_hip_set_probe_sampling), built on first use
     int sharedMemLimit = 65536;
-    uint32_t* passSeedsDev = nullptr;
-    size_t passSeedsCap = 0;
+    uint32_t* passSeedsDev = nullptr;   // the table: the seeds of passes [passSeedsBase, passSeedsBase + passSeedsCount)
+    size_t passSeedsCap = 0, passSeedsCount = 0;
+    uint32_t passSeedsBase = 0;
+    const uint32_t* passSeeds = nullptr;    // the current call's first seed, inside the table
+    hipEvent_t passSeedsReady = nullptr;    // recorded behind the launch that wrote the table, on passSeedsStream
+    hipStream_t passSeedsStream = nullptr;
     unsigned long long* statsDev = nullptr;
 
     size_t lastBatchSlots = 0;
@@ -694,7 +698,7 @@ LaunchArgs batch_args(tinsel_hip* r, const CameraParams& cam, const FrameParams&
     a.ctl = r->ctl;
     a.cam = cam;
     a.fp = fp;
-    a.passSeeds = r->passSeedsDev;
+    a.passSeeds = r->passSeeds;
     a.walkRec = walk_records(r);
     a.walkPrims = (uint32_t)r->walkPrims.count;
     a.bins = noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims;
@@ -970,18 +974,25 @@ int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, floa
         {
             const int span = 1 + (int)floorf(fp.filterWidth) + (int)ceilf(fp.filterWidth) + 1;     // reachLo + reachHi + 1
             static const bool noSpan = getenv("TINSEL_HIP_ACC_NO_SPAN") != nullptr;
-            if (span == 3 && !noSpan)
-                hipLaunchKernelGGL((k_accumulate_tiled<3>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev, tileList);
+            // few tiles (a wave per SIMD or less): 512-thread workgroups, the second half only stages (tn_kernels.h); TINSEL_HIP_ACC_WIDE=0/1: never / always (A/B)
+            static const char* wideEnv = getenv("TINSEL_HIP_ACC_WIDE");
+            const bool wide = wideEnv ? atoi(wideEnv) != 0 : tiles <= r->numCUs*4;
+            if (span == 3 && !noSpan && wide)
+                hipLaunchKernelGGL((k_accumulate_tiled<3, 2*kBlock>), dim3(tiles), dim3(2*kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
+            else if (span == 4 && !noSpan && wide)
+                hipLaunchKernelGGL((k_accumulate_tiled<4, 2*kBlock>), dim3(tiles), dim3(2*kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
+            else if (span == 3 && !noSpan)
+                hipLaunchKernelGGL((k_accumulate_tiled<3>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
             else if (span == 4 && !noSpan)
-                hipLaunchKernelGGL((k_accumulate_tiled<4>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev, tileList);
+                hipLaunchKernelGGL((k_accumulate_tiled<4>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
             else
-                hipLaunchKernelGGL((k_accumulate_tiled<0>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev, tileList);
+                hipLaunchKernelGGL((k_accumulate_tiled<0>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
         }
     }
     else
     {
         const int gridPix = (int)((npix + kBlock - 1)/kBlock);
-        hipLaunchKernelGGL(k_accumulate, dim3(gridPix), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeedsDev);
+        hipLaunchKernelGGL(k_accumulate, dim3(gridPix), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeeds);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1061,6 +1072,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     fp.accEnd = fp.numPasses;
     fp.rrStart = r->rrStart;
     fp.repack = 0;
+    fp.share = 0;
     fp.groupStep = 1;
     const int gridFlat = (int)std::max<size_t>(1, (slots + kBlock - 1)/kBlock);
     const int gridPersist = streaming_grid(r, slots, resolve_pipeline(r));
@@ -1101,6 +1113,13 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 a.fp.repack = 1;
                 a.ldsBytes = (uint32_t)withPool;
             }
+        }
+        // bounces > 0: a workgroup's four regions as ONE stream dealt to its waves -- where a round is long (three or more shadow rays)
+        // and where the regions are short (a small batch: the ragged last round of every region and bounce weighs more)
+        {
+            static const char* shareEnv = getenv("TINSEL_HIP_BOUNCE_SHARE");     // 0 / 1: never / always (A/B)
+            static const int shareLen = getenv("TINSEL_HIP_BOUNCE_SHARE_LEN") ? atoi(getenv("TINSEL_HIP_BOUNCE_SHARE_LEN")) : 512;     // cornell 256^2 x 16 passes (regions of 384): 2258 -> 2311 Msamples/s; 1024^2 x 20 (regions of 2048) +0.3 %
+            a.fp.share = shareEnv ? (atoi(shareEnv) != 0) : (r->neePerPath >= 3 || (int)a.ss.regionLen <= shareLen);
         }
         static const bool noOrder = getenv("TINSEL_HIP_NO_REGION_ORDER") != nullptr;
         // ONE launch takes every region through all the bounces (k_bounce, tn_kernels.h); TINSEL_HIP_BOUNCE_LAUNCHES=per: one
@@ -1332,29 +1351,47 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
     if (fp.maxDepth < 1)
         return 0;
 
-    // pass seeds for this call: passSeed[s] = (passIndex+s+1)-th output of Random(1).Rand().  The host only keeps the
-    // generator's state at passIndex; the seeds themselves are produced on the device, in stream order (k_pass_seeds).
-    if (r->seedRngIndex > r->passIndex)
+    // pass seeds: passSeed[s] = (passIndex+s+1)-th output of Random(1).Rand().  The device keeps a TABLE of them, produced there by
+    // one thread (k_pass_seeds) from the generator state the host keeps: this call's and the next thousand passes', so that a call
+    // launches its path kernels and nothing else (a 256^2 x 16-pass batch is 0.43 ms of kernels: a third launch per call was 1.5 % of it).
+    // The table is rewritten only when a call leaves it (every 1024 passes, or a rewind: tinsel_hip_set_pass_index) -- after a
+    // device-wide wait, because kernels of another stream (look-ahead) may still read it; a stream other than the one that wrote
+    // it waits for the writer's event.
+    constexpr size_t kSeedsAhead = 1024;
+    const bool covered = r->passSeedsCount > 0 && r->passIndex >= r->passSeedsBase &&
+                         (size_t)(r->passIndex - r->passSeedsBase) + (size_t)passes <= r->passSeedsCount;
+    if (!covered)
     {
-        r->seedRng = Rng::seeded(1u);
-        r->seedRngIndex = 0;
-    }
-    for (; r->seedRngIndex < r->passIndex; ++r->seedRngIndex)
-        (void)r->seedRng.rand();
-    if (r->passSeedsCap < (size_t)passes)
-    {
-        if (r->passSeedsDev)
+        if (r->seedRngIndex > r->passIndex)
         {
-            HIP_TRY(hipDeviceSynchronize());        // growth only: earlier launches may still read the old array
-            (void)hipFree(r->passSeedsDev);
-            r->passSeedsDev = nullptr;
-            r->passSeedsCap = 0;
+            r->seedRng = Rng::seeded(1u);
+            r->seedRngIndex = 0;
         }
-        const size_t cap = std::max<size_t>((size_t)passes, 64);
-        HIP_TRY(hipMalloc((void**)&r->passSeedsDev, sizeof(uint32_t)*cap));
-        r->passSeedsCap = cap;
+        for (; r->seedRngIndex < r->passIndex; ++r->seedRngIndex)
+            (void)r->seedRng.rand();
+        if (r->passSeedsDev)
+            HIP_TRY(hipDeviceSynchronize());
+        const size_t want = (size_t)passes + kSeedsAhead;
+        if (r->passSeedsCap < want)
+        {
+            if (r->passSeedsDev)
+                (void)hipFree(r->passSeedsDev);
+            r->passSeedsDev = nullptr;
+            r->passSeedsCap = r->passSeedsCount = 0;
+            HIP_TRY(hipMalloc((void**)&r->passSeedsDev, sizeof(uint32_t)*want));
+            r->passSeedsCap = want;
+        }
+        if (!r->passSeedsReady)
+            HIP_TRY(hipEventCreateWithFlags(&r->passSeedsReady, hipEventDisableTiming));
+        hipLaunchKernelGGL(k_pass_seeds, dim3(1), dim3(1), 0, st, r->seedRng.s1, r->seedRng.s2, (int)want, r->passSeedsDev);
+        HIP_TRY(hipEventRecord(r->passSeedsReady, st));
+        r->passSeedsBase = r->passIndex;
+        r->passSeedsCount = want;
+        r->passSeedsStream = st;
     }
-    hipLaunchKernelGGL(k_pass_seeds, dim3(1), dim3(1), 0, st, r->seedRng.s1, r->seedRng.s2, passes, r->passSeedsDev);
+    else if (st != r->passSeedsStream)
+        HIP_TRY(hipStreamWaitEvent(st, r->passSeedsReady, 0));
+    r->passSeeds = r->passSeedsDev + (r->passIndex - r->passSeedsBase);
 
     const size_t perPass = slots_per_pass(r, fp.width, fp.height);
     int perBatch = (int)std::max<size_t>(1, batch_slots(r)/perPass);
@@ -2198,6 +2235,7 @@ void tinsel_hip_destroy(tinsel_hip* r)
         (void)hipFree(p);
     if (r->accTilesDev) (void)hipFree(r->accTilesDev);
     if (r->passSeedsDev) (void)hipFree(r->passSeedsDev);
+    if (r->passSeedsReady) (void)hipEventDestroy(r->passSeedsReady);
     if (r->statsDev) (void)hipFree(r->statsDev);
     for (TimedSpan& s : r->spans)
     {

@@ -88,6 +88,7 @@ struct FrameParams
     uint32_t genCount;                  // camera paths the generation kernels enumerate per batch (gen_slot)
     int rrStart;                        // > 0: Russian roulette from this bounce on (opt-in, not the reference's behaviour)
     int repack;                         // k_bounce: paths that hit a surface close ranks (per-wave LDS pool) before the shading half
+    int share;                          // k_bounce, bounces > 0: the workgroup's four regions form one stream dealt to its waves (host: >= 3 light samples, or short regions)
     uint32_t groupStep;                 // k_bounce over all bounces: workgroup b takes region group (b*groupStep) mod groups (coprime; 1: in order)
     int filterType;
     float filterWidth, filterFalloff, filterOffset;
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         {
             // this workgroup's stores of the previous bounce (path state, region counts) before this bounce's loads
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (sc.totalLightSamples >= 3)
+            if (fp.share)
                 __syncthreads();        // its waves read each other's regions (`share` below); wave-uniform for the whole grid
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         // stream, dealt to its waves round by round.  A workgroup holds its LDS and its wave slots until its last wave ends;
         // where a round is long (veach: 4 shadow traces, features: 9) its waves drift apart unless they share (veach 1409 ->
         // 1457 Msamples/s, features 685 -> 712); where rounds are short the dealing costs more than it gives (env_loft, gloss -2 %)
-        const bool share = !FIRST && sc.totalLightSamples >= 3;
+        const bool share = !FIRST && fp.share != 0;
         uint32_t gF[kRegionsPerBlock], gStart[kRegionsPerBlock];
         if (FIRST)
         {
@@ -1659,10 +1660,13 @@ constexpr int kAccMaxFoot = 5;      // widest footprint (pixels per axis) for fi
 // SPAN = the candidate window's edge (reachLo + reachHi + 1: 3 for the default filter width 0.75, 4 for cornell's 1.0) as a compile-time
 // constant: the gather loop is unrolled over the SPAN x SPAN window with no bounds -- candidates outside the frame are staged as
 // "covers nothing", so clipping the window changes nothing -- in the same raster order; 0 = the window's bounds at run time.
-template <int SPAN>
-__global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, FrameParams fp, float4* __restrict__ accum,
+// THREADS = kBlock, or 2*kBlock for frames of few tiles (one wave per SIMD or less: a pass is then as long as one thread's chain, and
+// the second half of the workgroup -- no pixels of its own -- takes the second staging round off it).
+template <int SPAN, int THREADS = kBlock>
+__global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumulate_tiled(PathState ps, FrameParams fp, float4* __restrict__ accum,
                                                                 const uint32_t* __restrict__ passSeeds, const int* __restrict__ tileList)
 {
+    constexpr int kEnt = (kAccEntries + THREADS - 1)/THREADS;       // candidate entries a thread stages per pass
     // per candidate path of the tile: clamped sample, footprint [startX, startX+nX) x [startY, startY+nY)
     // and the separable Gaussian weights of its footprint columns / rows (each shared by up to 5 pixels)
     __shared__ float4 s_c[kAccEntries];                 // rgb, .w = bits(startX | nX << 16)
@@ -1680,9 +1684,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
     const int tilesX = (fp.width + kAccTile - 1)/kAccTile;
     const int tile = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;
     const int tx = tile % tilesX, ty = tile/tilesX;
-    const int lx = threadIdx.x % kAccTile, ly = threadIdx.x/kAccTile;
+    const int lx = threadIdx.x % kAccTile, ly = (threadIdx.x/kAccTile) % kAccTile;
     const int px = tx*kAccTile + lx, py = ty*kAccTile + ly;
-    const bool inside = px < fp.width && py < fp.height;
+    const bool inside = threadIdx.x < kBlock && px < fp.width && py < fp.height;
 
     const float fw = fp.filterWidth;
     const int reachLo = 1 + (int)floorf(fw);
@@ -1701,12 +1705,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
 
     // The (at most two) candidate entries this thread stages every pass: which path, where in LDS, whether the path
     // is this shard's.  The radiance of the NEXT pass is requested before the current pass is processed.
-    int entLe[2], entGx[2], entGy[2];
-    bool entLive[2];
-    float4 nextRa[2];
-    for (int k = 0; k < 2; ++k)
+    int entLe[kEnt], entGx[kEnt], entGy[kEnt];
+    bool entLive[kEnt];
+    float4 nextRa[kEnt];
+#pragma unroll
+    for (int k = 0; k < kEnt; ++k)
     {
-        const int e = threadIdx.x + k*kBlock;
+        const int e = threadIdx.x + k*THREADS;
         const int ex = e % side, ey = e/side;
         entGx[k] = ox + ex; entGy[k] = oy + ey;
         entLe[k] = ey*kAccSide + ex;
@@ -1719,15 +1724,20 @@ __global__ __launch_bounds__(kBlock, 4) void k_accumulate_tiled(PathState ps, Fr
 
     for (int s = fp.accBegin; s < fp.accEnd; ++s)
     {
-        float4 curRa[2] = { nextRa[0], nextRa[1] };
+        float4 curRa[kEnt];
+#pragma unroll
+        for (int k = 0; k < kEnt; ++k)
+            curRa[k] = nextRa[k];
         if (s + 1 < fp.accEnd)
-            for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int k = 0; k < kEnt; ++k)
                 if (entLive[k])
                     nextRa[k] = ps.rad[slot_of(fp, s + 1, entGx[k], entGy[k])];
 
-        for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int k = 0; k < kEnt; ++k)
         {
-            if (threadIdx.x + k*kBlock >= side*side)
+            if (threadIdx.x + k*THREADS >= side*side)
                 continue;
             const int gx = entGx[k], gy = entGy[k], le = entLe[k];
             float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // nX == 0: covers nothing
