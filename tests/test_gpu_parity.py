@@ -296,3 +296,23 @@ def test_every_shard_is_bit_identical_to_the_oracle_shard(pipeline, world, tile,
         total += n
     P.free(h)
     assert total == 2*opt.width*opt.height
+
+
+@pytest.mark.parametrize("share,wide", [("0", "0"), ("1", "1"), ("0", "1"), ("1", "0")])
+@pytest.mark.parametrize("name", ["cornell", "veach", "features", "gloss"])
+def test_small_frame_switches_change_no_bit(name, share, wide, monkeypatch):
+    """The two choices the library makes from the batch / frame size -- k_bounce's waves dealing their workgroup's regions as one
+    stream (TINSEL_HIP_BOUNCE_SHARE) and 512-thread accumulate workgroups (TINSEL_HIP_ACC_WIDE) -- forced both ways."""
+    monkeypatch.setenv("TINSEL_HIP_BOUNCE_SHARE", share)
+    monkeypatch.setenv("TINSEL_HIP_ACC_WIDE", wide)
+    scene, cam, opt, g = _load(name)
+    passes = int(g["passes"])
+    from tinsel_amd import create_gpu_renderer
+    r = create_gpu_renderer(scene)
+    r.set_pipeline(abi.PIPELINE_WAVEFRONT)
+    r.init(opt.width, opt.height)
+    out = r.render(cam, opt, passes=passes)
+    rad = r.batch_radiance(passes, opt.height, opt.width)
+    r.close()
+    assert np.array_equal(rad, g["radiance"])
+    assert np.array_equal(out, g["accum"])

@@ -975,7 +975,7 @@ int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, floa
             const int span = 1 + (int)floorf(fp.filterWidth) + (int)ceilf(fp.filterWidth) + 1;     // reachLo + reachHi + 1
             static const bool noSpan = getenv("TINSEL_HIP_ACC_NO_SPAN") != nullptr;
             // few tiles (a wave per SIMD or less): 512-thread workgroups, the second half only stages (tn_kernels.h); TINSEL_HIP_ACC_WIDE=0/1: never / always (A/B)
-            static const char* wideEnv = getenv("TINSEL_HIP_ACC_WIDE");
+            const char* wideEnv = getenv("TINSEL_HIP_ACC_WIDE");      // (read per call: tests switch it)
             const bool wide = wideEnv ? atoi(wideEnv) != 0 : tiles <= r->numCUs*4;
             if (span == 3 && !noSpan && wide)
                 hipLaunchKernelGGL((k_accumulate_tiled<3, 2*kBlock>), dim3(tiles), dim3(2*kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
@@ -1117,7 +1117,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         // bounces > 0: a workgroup's four regions as ONE stream dealt to its waves -- where a round is long (three or more shadow rays)
         // and where the regions are short (a small batch: the ragged last round of every region and bounce weighs more)
         {
-            static const char* shareEnv = getenv("TINSEL_HIP_BOUNCE_SHARE");     // 0 / 1: never / always (A/B)
+            const char* shareEnv = getenv("TINSEL_HIP_BOUNCE_SHARE");            // 0 / 1: never / always (A/B, tests: read per call)
             static const int shareLen = getenv("TINSEL_HIP_BOUNCE_SHARE_LEN") ? atoi(getenv("TINSEL_HIP_BOUNCE_SHARE_LEN")) : 512;     // cornell 256^2 x 16 passes (regions of 384): 2258 -> 2311 Msamples/s; 1024^2 x 20 (regions of 2048) +0.3 %
             a.fp.share = shareEnv ? (atoi(shareEnv) != 0) : (r->neePerPath >= 3 || (int)a.ss.regionLen <= shareLen);
         }

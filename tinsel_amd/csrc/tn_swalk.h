@@ -107,6 +107,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : TN_WAVES_SWALK) void k_s
         }
     };
 
+    const uint32_t KxM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xffffffffu/Kx));
     for (;;)
     {
         // ---- refill: idle lanes take the next rays of the workgroup's range ------------------------------------------------
@@ -129,8 +130,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : TN_WAVES_SWALK) void k_s
                 const uint32_t my = c0 + (uint32_t)__popcll(idleMask & below);
                 if (my < end)
                 {
-                    const uint32_t qi = my/Kx;
+                    uint32_t qi = __umulhi(my, KxM);                 // my/Kx with the uniform reciprocal in an SGPR (tn_walk.h)
                     kray = my - qi*Kx;
+                    if (kray >= Kx) { ++qi; kray -= Kx; }
                     pos = job.list[qi];
                     float4 ro, rd;
                     if (SHADOW)

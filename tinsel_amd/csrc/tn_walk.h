@@ -149,6 +149,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     const uint32_t Kb = (uint32_t)job.numPrims;
     const uint32_t per = Kx*Kb;                                 // work items per queued slot
     const uint32_t total = (*job.frontCount)*per;
+    // my/per and rem/Kb below: both divisors are wave-uniform, so the reciprocals live in SGPRs (the compiler's own expansion kept two
+    // VGPR reciprocals across the loop, spilled them, and reloaded them in every refill behind an s_waitcnt vmcnt(0) -- i.e. behind the
+    // finished rays' record stores).  q' = mulhi(n, floor((2^32-1)/d)) is q or q - 1 for n < 2^32: one correction.
+    const uint32_t perM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xffffffffu/per));
+    const uint32_t KbM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xffffffffu/Kb));
 
     // static ranges: workgroup b -> the b-th contiguous piece of the items; its waves share it through an LDS cursor
     const uint32_t chunk = (total + gridDim.x - 1u)/gridDim.x;
@@ -246,10 +251,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                 const uint32_t my = cur + (uint32_t)__popcll(idleMask & below);
                 if (my < end)
                 {
-                    const uint32_t qi = my/per;
-                    const uint32_t rem = my - qi*per;
-                    const uint32_t k = rem/Kb;
-                    const uint32_t kb = rem - k*Kb;
+                    uint32_t qi = __umulhi(my, perM), rem = my - qi*per;
+                    if (rem >= per) { ++qi; rem -= per; }
+                    uint32_t k = __umulhi(rem, KbM), kb = rem - k*Kb;
+                    if (kb >= Kb) { ++k; kb -= Kb; }
                     const uint32_t slot = job.queue[qi];
                     const uint32_t recAt = slot*per + rem;      // records are indexed by position, like everything the scan kernels read
 
