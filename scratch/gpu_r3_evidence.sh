@@ -21,7 +21,7 @@ print('| %s | %.1f | %.1f | %.2f | %s | %s | %s |' % (d['config']['workload'].sp
 PY
 }
 ( echo "| config | Msamples/s (exact) | Mrays/s | rays/sample | kernel ms of one timed block | Msamples/s (fast arm) | fast-vs-exact L2 @ 256 spp |"; echo "|---|---|---|---|---|---|---|"
-run --scene cornell --width 256 --height 256 --steps 16 --warmup 2
+run --scene cornell --width 256 --height 256 --steps 16 --warmup 4
 run --scene cornell --steps 20 --warmup 5
 run --scene cornell --steps 64 --warmup 8
 run --scene large/ajax_standin --width 1920 --height 1080 --steps 32 --warmup 2
