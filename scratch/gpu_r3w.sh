@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3w; mkdir -p $OUT
 python - 2>&1 <<'PY' | grep -v amdgpu.ids | tee $OUT/selftest.txt
 import tinsel_amd
-for v in (21, 22, 24, -1):
+for v in (21, -1):
     c, first = tinsel_amd.selftest_arith(1, v)
     print("sqrt variant %d: mismatches over 2^32 inputs: %d (first bad 0x%08x) %s" % (v, c[0], first, {e: n for e, n in enumerate(c[4:]) if n}))
 c, first = tinsel_amd.selftest_arith(0)

@@ -71,84 +71,59 @@ TN_HD V3 divs(V3 a, float s) { float r = rcpf_cr(s); return V3(a.x*r, a.y*r, a.z
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// variants 1..3: straight-line with v_div_fixup for the specials; 11..13: the same refinement behind a range guard (normal x,
-// |x| < 2^126 -- v_rcp_f32 flushes denormal operands and results), everything else through the compiler's division
-template <int V> __device__ __forceinline__ float rcp_refine(float x)
+// v_rcp_f32 + two Newton steps (the second one is Markstein's correction of the quotient q = r)
+__device__ __forceinline__ float rcp_refine(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);
     float e = __builtin_fmaf(-x, r, 1.0f);
     r = __builtin_fmaf(e, r, r);
-    const float r1 = r;
-    e = __builtin_fmaf(-x, r, 1.0f);           // Markstein's correction of the quotient q = r
-    r = __builtin_fmaf(e, V == 3 ? r1 : r, r);
-    if (V >= 2)
-    {
-        e = __builtin_fmaf(-x, r, 1.0f);       // (the compiler's sequence runs this third step, with r1 as the multiplier: V == 3)
-        r = __builtin_fmaf(e, V == 3 ? r1 : r, r);
-    }
-    return r;
+    e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
 }
+// variant 0: the compiler's division; 1: straight-line, v_div_fixup for zero / infinity / NaN (NOT exact: v_rcp_f32 flushes denormal
+// operands and results -- kept for the self-test to find); 11: the refinement behind a range guard (normal x, |x| < 2^126), everything
+// else through the compiler's division
 template <int V> __device__ __forceinline__ float rcp_candidate(float x)
 {
+    static_assert(V == 0 || V == 1 || V == 11, "unknown reciprocal variant");
     if (V == 0)
         return 1.0f/x;
-    if (V < 10)
-        return __builtin_amdgcn_div_fixupf(rcp_refine<V>(x), x, 1.0f);     // zero, infinity, NaN
+    if (V == 1)
+        return __builtin_amdgcn_div_fixupf(rcp_refine(x), x, 1.0f);
     if (__builtin_expect(__builtin_isnormal(x) && __builtin_fabsf(x) < 0x1p126f, 1))
-        return rcp_refine<V - 10>(x);
+        return rcp_refine(x);
     return 1.0f/x;
 }
 
-// variants 1, 2: v_rsq_f32 + one / two Newton steps on s with a fixed h = y/2; 3: v_sqrt_f32 + the compiler's compare-and-step
-// without its denormal scaling; 4, 5: the coupled iteration (s and h refined together, then one / two Markstein steps);
-// 11..15: the same behind a guard (2^-96 <= x < inf: below, the residual x - s*s leaves the normal range), the rest through sqrtf;
-// 21..25: the same without a branch, small operands scaled by 2^32 as the compiler does
-template <int V> __device__ __forceinline__ float sqrt_refine(float x)
+// v_rsq_f32, s = x*y, h = y/2, one Newton step on s with fused residual
+__device__ __forceinline__ float sqrt_refine(float x)
 {
-    if (V == 3)
-    {
-        float s = __builtin_amdgcn_sqrtf(x);
-        const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
-        const float edn = __builtin_fmaf(-dn, s, x), eup = __builtin_fmaf(-up, s, x);
-        s = edn <= 0.0f ? dn : s;
-        s = eup > 0.0f ? up : s;
-        return s;
-    }
     const float y = __builtin_amdgcn_rsqf(x);
-    float s = x*y;
-    float h = 0.5f*y;
-    if (V >= 4)
-    {
-        const float r = __builtin_fmaf(-h, s, 0.5f);
-        s = __builtin_fmaf(s, r, s);
-        h = __builtin_fmaf(h, r, h);
-    }
-    float e = __builtin_fmaf(-s, s, x);
-    s = __builtin_fmaf(e, h, s);
-    if (V == 2 || V == 5)
-    {
-        e = __builtin_fmaf(-s, s, x);
-        s = __builtin_fmaf(e, h, s);
-    }
-    return s;
+    const float s = x*y;
+    const float h = 0.5f*y;
+    const float e = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(e, h, s);
 }
+// variant 0: the compiler's sqrtf; 1: the bare step, +-0 and +inf passed through (NOT exact below 2^-96, where the residual x - s*s
+// leaves the normal range: kept for the self-test to find); 11: the step behind a guard (2^-96 <= x < inf), the rest through sqrtf;
+// 21: no branch -- operands below 2^-96 scaled by 2^32 as the compiler's own expansion does, the root scaled back by 2^-16
 template <int V> __device__ __forceinline__ float sqrt_candidate(float x)
 {
+    static_assert(V == 0 || V == 1 || V == 11 || V == 21, "unknown square-root variant");
     if (V == 0)
         return sqrtf(x);
-    if (V < 10)     // +-0 and +inf pass through (rsq gives inf / 0 there and the products NaN); negative x and NaN are NaN either way
-        return (x == 0.0f || x == __builtin_inff()) ? x : sqrt_refine<V>(x);
-    if (V >= 20)
+    if (V == 1)     // (rsq gives inf / 0 at 0 / inf and the products NaN; negative x and NaN are NaN either way)
+        return (x == 0.0f || x == __builtin_inff()) ? x : sqrt_refine(x);
+    if (V == 21)
     {
-        // branch-free: the compiler's own 2^32 scaling of small operands around the short iteration
         const bool small = x < 0x1p-96f;
         const float xs = small ? x*0x1p32f : x;
-        float s = sqrt_refine<V - 20>(xs);
+        float s = sqrt_refine(xs);
         s = small ? s*0x1p-16f : s;
         return __builtin_amdgcn_classf(xs, 0x260) ? xs : s;       // -0, +0, +inf pass through
     }
     if (__builtin_expect(x >= 0x1p-96f && x < __builtin_inff(), 1))
-        return sqrt_refine<V - 10>(x);
+        return sqrt_refine(x);
     return sqrtf(x);
 }
 #endif
@@ -179,7 +154,7 @@ TN_HD V3 rcp3_cr(V3 d)
     const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
     const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
     if (__builtin_expect(lo >= 0x1p-126f && hi < 0x1p126f && d.x == d.x && d.y == d.y && d.z == d.z, 1))
-        return V3(rcp_refine<1>(d.x), rcp_refine<1>(d.y), rcp_refine<1>(d.z));
+        return V3(rcp_refine(d.x), rcp_refine(d.y), rcp_refine(d.z));
     return V3(1.0f/d.x, 1.0f/d.y, 1.0f/d.z);
 #else
     return V3(rcpf_cr(d.x), rcpf_cr(d.y), rcpf_cr(d.z));
