@@ -410,9 +410,9 @@ int tinsel_hip_group_size(tinsel_hip_group* g);
 tinsel_hip* tinsel_hip_group_member(tinsel_hip_group* g, int rank);
 
 /* Exhaustive self-test of the parity arm's short reciprocal / square-root sequences (tn_math.h rcp_candidate / sqrt_candidate):
- * compares the candidate with the compiler's correctly rounded `1.0f/x` (op 0) or `sqrtf(x)` (op 1) on ALL 2^32 fp32 bit patterns
+ * compares the candidate with the compiler's correctly rounded `1.0f/x` (op 0), `sqrtf(x)` (op 1) or `1.0f/sqrtf(x)` (op 2) on ALL 2^32 fp32 bit patterns
  * on the device.  variant < 0: the variant this library's kernels are built with (0 = the compiler's own expansion).
- * out_counts[260]: [0..3] mismatches in total / with a denormal operand / with |x| >= 2^126 (op 0) or x < 0 (op 1) / any
+ * out_counts[260]: [0..3] mismatches in total / with a denormal operand / with |x| >= 2^126 (op 0) or x < 0 (ops 1, 2) / any
  * other; [4 + e] mismatches by the operand's exponent field e;
  * out_first_bad: the smallest mismatching bit pattern (0xffffffff when none).  No reference counterpart (test infrastructure
  * of this library: the reference divides with the host FPU / nvcc's IEEE division, render.cpp / maths.h throughout). */

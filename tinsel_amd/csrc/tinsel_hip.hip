@@ -2997,10 +2997,10 @@ int tinsel_hip_queue_counts(tinsel_hip* r, uint32_t* out, int max_bounces)
 // of a walked tree, 3 inside one L2).  One warm-up launch, then one timed with HIP events.
 int tinsel_hip_selftest_arith(int device_index, int op, int variant, unsigned long long* out_counts, unsigned int* out_first_bad)
 {
-    if (!out_counts || !out_first_bad || op < 0 || op > 1)
+    if (!out_counts || !out_first_bad || op < 0 || op > 2)
         return fail("selftest_arith: bad arguments");
     if (variant < 0)
-        variant = op == 0 ? TN_RCP_VARIANT : TN_SQRT_VARIANT;      // what this library is built with
+        variant = op == 0 ? TN_RCP_VARIANT : op == 1 ? TN_SQRT_VARIANT : TN_RSQRT_VARIANT;      // what this library is built with
     HIP_TRY(hipSetDevice(device_index));
     unsigned long long* counts = nullptr;
     uint32_t* first = nullptr;
@@ -3022,6 +3022,10 @@ int tinsel_hip_selftest_arith(int device_index, int op, int variant, unsigned lo
     case 101: launch_selftest_arith<1, 1>(counts, first); break;
     case 111: launch_selftest_arith<1, 11>(counts, first); break;
     case 121: launch_selftest_arith<1, 21>(counts, first); break;
+    case 200: launch_selftest_arith<2, 0>(counts, first); break;
+    case 201: launch_selftest_arith<2, 1>(counts, first); break;
+    case 202: launch_selftest_arith<2, 2>(counts, first); break;
+    case 203: launch_selftest_arith<2, 3>(counts, first); break;
     default: known = false; break;
     }
     int rc = 0;

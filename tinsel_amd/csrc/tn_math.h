@@ -147,6 +147,51 @@ TN_HD float sqrtf_cr(float x)
 
 TN_HD float dot(V3 a, V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }                                   // maths.h:257
 TN_HD V3 cross(V3 a, V3 b) { return V3(a.y*b.z - b.y*a.z, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x); }   // maths.h:256
+// 1/sqrt(x) AS THE REFERENCE ROUNDS IT -- RN(1 / RN(sqrt x)): every normalize (maths.h:260 `a/Length(a)`, :261-273, the basis helpers,
+// the quaternions) -- is again a function of ONE operand.  Variant 0: the two sequences above, one after the other (12 + 12 instructions).
+// Variants 1-3: the root as in sqrtf_cr; its reciprocal needs no scaling -- the root of any finite positive fp32 lies in [2^-75, 2^64] --
+// and v_rsq_f32's y ~ 1/sqrt(x) is within 2^-22 of it: two Newton steps against the ROUNDED root, v_div_fixup for the specials (+-0 ->
+// +-inf, inf -> 0, negative -> NaN), 18 instructions.  Started from y itself (variant 1) the step lands on a tie where the root's
+// mantissa is all ones and rounds to even: 255 wrong operands of 2^32, found by the self-test (and by one parity test, by luck).  From
+// v_rcp_f32(root) (2) or from y one ulp up (3) it is exact on all 2^32 (tinsel_hip_selftest_arith op 2); 3 is the default:
+// cornell +1.2 %, veach +0.9 % over variant 0 (profiles/r03_w_short_sqrt.md).
+#ifndef TN_RSQRT_VARIANT
+#define TN_RSQRT_VARIANT 3
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int V> __device__ __forceinline__ float rsqrt_candidate(float x)
+{
+    static_assert(V >= 0 && V <= 3, "unknown reciprocal-square-root variant");
+    if (V == 0)
+        return rcp_candidate<TN_RCP_VARIANT>(sqrt_candidate<TN_SQRT_VARIANT>(x));
+    const bool small = x < 0x1p-96f;
+    const float xs = small ? x*0x1p32f : x;
+    const float y = __builtin_amdgcn_rsqf(xs);
+    float s = xs*y;
+    const float h = 0.5f*y;
+    float e = __builtin_fmaf(-s, s, xs);
+    s = __builtin_fmaf(e, h, s);                                // RN(sqrt(xs)) (sqrt_candidate<21>)
+    s = __builtin_amdgcn_classf(xs, 0x260) ? xs : s;            // -0, +0, +inf
+    // the first guess of 1/s.  V == 1: y itself -- NOT exact: where s = 2^k (2 - 2^-23) the step from below lands on a tie and rounds to
+    // even, 255 operands of 2^32 (kept for the self-test to find); V == 2: v_rcp_f32(s); V == 3: y one ulp up (a step from above never ties)
+    const float r0 = V == 2 ? __builtin_amdgcn_rcpf(s) : V == 3 ? __uint_as_float(__float_as_uint(y) + 1u) : y;
+    e = __builtin_fmaf(-s, r0, 1.0f);
+    float r = __builtin_fmaf(e, r0, r0);
+    e = __builtin_fmaf(-s, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);                                // RN(1/s) where s is finite and positive
+    r = small ? r*0x1p16f : r;                                  // 1/sqrt(x) = 2^16 / sqrt(x 2^32): exact, the quotient is a normal number
+    return __builtin_amdgcn_div_fixupf(r, s, 1.0f);
+}
+#endif
+TN_HD float rsqrtf_cr(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(TN_FAST) && TN_FAST)
+    return rsqrt_candidate<TN_RSQRT_VARIANT>(x);
+#else
+    return 1.0f/sqrtf(x);
+#endif
+}
+
 // the three reciprocals of a direction behind ONE guard (TN_RCP3_GROUP): a slab test's 1/d
 TN_HD V3 rcp3_cr(V3 d)
 {
@@ -162,7 +207,7 @@ TN_HD V3 rcp3_cr(V3 d)
 }
 TN_HD float length_sq(V3 a) { return dot(a, a); }
 TN_HD float length(V3 a) { return sqrtf_cr(dot(a, a)); }                                                // maths.h:259
-TN_HD V3 normalize(V3 a) { return divs(a, length(a)); }                                              // maths.h:260
+TN_HD V3 normalize(V3 a) { const float r = rsqrtf_cr(dot(a, a)); return V3(a.x*r, a.y*r, a.z*r); }     // a*(1.0/Length(a))                                              // maths.h:260
 
 // SafeNormalize (maths.h:261-273): a * (1.0/sqrt(m))
 TN_HD V3 safe_normalize(V3 a, V3 fallback)
@@ -170,7 +215,7 @@ TN_HD V3 safe_normalize(V3 a, V3 fallback)
     float m = length_sq(a);
     if (m > 0.0f)
     {
-        float r = rcpf_cr(sqrtf_cr(m));
+        float r = rsqrtf_cr(m);
         return V3(a.x*r, a.y*r, a.z*r);
     }
     return fallback;
@@ -510,8 +555,7 @@ TN_HD V3 qrotate(Q4 q, V3 v)
 // Normalize(Quat)  (maths.h:547-553)
 TN_HD Q4 qnormalize(Q4 q)
 {
-    float len = sqrtf_cr(q.x*q.x + q.y*q.y + q.z*q.z + q.w*q.w);
-    float r = rcpf_cr(len);
+    float r = rsqrtf_cr(q.x*q.x + q.y*q.y + q.z*q.z + q.w*q.w);      // 1.0/Length(q)
     Q4 o = { q.x*r, q.y*r, q.z*r, q.w*r };
     return o;
 }
@@ -577,12 +621,12 @@ TN_HD void basis_from_vector(V3 w, V3& u, V3& v)
 {
     if (fabsf(w.x) > fabsf(w.y))
     {
-        float invLen = rcpf_cr(sqrtf_cr(w.x*w.x + w.z*w.z));
+        float invLen = rsqrtf_cr(w.x*w.x + w.z*w.z);
         u = V3(-w.z*invLen, 0.0f, w.x*invLen);
     }
     else
     {
-        float invLen = rcpf_cr(sqrtf_cr(w.y*w.y + w.z*w.z));
+        float invLen = rsqrtf_cr(w.y*w.y + w.z*w.z);
         u = V3(0.0f, w.z*invLen, -w.y*invLen);
     }
     v = cross(w, u);

@@ -21,8 +21,9 @@ __global__ __launch_bounds__(256) void k_selftest_arith(unsigned long long* __re
         const uint32_t bits = k*(1u << 24) + base;     // grid = 2^24 threads
         const float x = __uint_as_float(bits);
         float want, got;
-        if constexpr (OP == 0) { want = 1.0f/x; got = rcp_candidate<V>(x); }
-        else                   { want = sqrtf(x); got = sqrt_candidate<V>(x); }
+        if constexpr (OP == 0)      { want = 1.0f/x; got = rcp_candidate<V>(x); }
+        else if constexpr (OP == 1) { want = sqrtf(x); got = sqrt_candidate<V>(x); }
+        else                        { want = 1.0f/sqrtf(x); got = rsqrt_candidate<V>(x); }
         const uint32_t wb = __float_as_uint(want), gb = __float_as_uint(got);
         const bool same = wb == gb || (want != want && got != got);     // any NaN equals any NaN (payloads are not consumed anywhere)
         if (!same)
