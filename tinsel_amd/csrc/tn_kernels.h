@@ -1102,6 +1102,9 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
 }
 
 // what k_shade reads of a path before it can do anything: its state, its hit, where its shadow rays are
+#ifndef TN_SHADE_PREFETCH
+#define TN_SHADE_PREFETCH 0
+#endif
 struct ShadeFetch
 {
     float4 ro, rd, th, ra, ab, rr, hh;
@@ -1223,18 +1226,29 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
-        // The kernel runs two waves per SIMD, too few to hide a round's loads behind another wave's arithmetic: the records
-        // of round i + 1 are requested before round i is shaded (they are reads of buffer `cur`, which nothing here writes).
+        // A round's records are requested at its start.  (Round 2 requested round i + 1's before shading round i: at two waves per SIMD
+        // that hid a latency.  At three, the 30 registers of a second ShadeFetch are spilled ones, and the wait for the shadow-ray
+        // records in the middle of the round -- vmcnt counts in order -- waited for the early request as well: without it k_shade spills
+        // 124 B instead of 196 and runs 3-9 % faster on the 524k-triangle config and many_spheres, +-1 % on glass,
+        // profiles/r03_z3_ab_shade_fetch.md; -DTN_SHADE_PREFETCH=1 is the old arm.  Requesting the shadow-ray records a round ahead too, in
+        // registers or through LDS with global_load_lds, spills 352-400 B and doubles the kernel's time.)
+#if TN_SHADE_PREFETCH
         ShadeFetch next;
         next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, lane < n ? lane : 0u), lane < n, hasMedia, K > 0, bounce == 0);
+#endif
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
+#if TN_SHADE_PREFETCH
             const ShadeFetch f = next;
             {
                 const uint32_t jn = j + kWave;
                 next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, jn < n ? jn : 0u), jn < n, hasMedia, K > 0, bounce == 0);
             }
+#else
+            ShadeFetch f;
+            f.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, j < n ? j : 0u), j < n, hasMedia, K > 0, bounce == 0);
+#endif
             bool alive = false, front = true;
             PathRegs p;
             uint32_t slot = 0;
