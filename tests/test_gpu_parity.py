@@ -161,6 +161,28 @@ def test_against_reference_live(name, W, H, passes, depth):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libtinsel_ref.so")),
                     reason="oracle/_ref not built")
+@pytest.mark.parametrize("depth", [1, 2, 7])
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (65, 3), (33, 1), (1, 40)], ids=lambda s: "%dx%d" % s)
+@pytest.mark.parametrize("name", ["cornell", "glass", "features_probe", "many_spheres"])
+def test_ragged_frames_against_reference_live(name, size, depth):
+    """Frames of one pixel, of one row or column, of less than a wave and with a ragged last wave; path depths of one and two bounces:
+    every pipeline against the reference's PathTrace run here, whole framebuffer bit for bit."""
+    from tests.oracle_api import RefOracle
+    R = RefOracle()
+    scene, cam, opt, g = _load(name)
+    opt.width, opt.height, opt.max_depth = size[0], size[1], depth
+    passes = 6
+    h = R.load_pack(os.path.join(GOLDEN, name + ".pack"))
+    ref, _, _ = R.render_seeded(h, cam, opt, 0, passes)
+    R.free(h)
+    for pipeline in (abi.PIPELINE_WAVEFRONT, abi.PIPELINE_WAVEFRONT_SPLIT, abi.PIPELINE_MEGAKERNEL):
+        out, st = _render(scene, cam, opt, passes, pipeline)
+        assert st["samples"] == passes*size[0]*size[1]
+        assert np.array_equal(out, ref), "pipeline %d differs from the reference on a %dx%d frame, depth %d" % (pipeline, size[0], size[1], depth)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libtinsel_ref.so")),
+                    reason="oracle/_ref not built")
 @pytest.mark.parametrize("ftype,width,falloff", [(0, 1.0, 2.0), (0, 2.0, 2.0), (1, 0.5, 2.0), (1, 1.0, 2.0), (1, 1.5, 1.0),
                                                  (1, 2.0, 0.5), (1, 2.5, 0.5), (1, 3.0, 1.0)],
                          ids=["box1", "box2", "gauss0.5", "gauss1", "gauss1.5", "gauss2", "gauss2.5", "gauss3"])
