@@ -1053,10 +1053,37 @@ int set_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int gridPersist)
     a.ss = r->ss;
     a.ss.numRegions = (uint32_t)gridPersist*(kBlock/kWave);
     a.ss.regionLen = (uint32_t)(((slots + a.ss.numRegions - 1)/a.ss.numRegions + kWave - 1)/kWave*kWave);
+    a.ss.bigRegions = a.ss.numRegions;
+    a.ss.shortLen = a.ss.regionLen;
     if (a.ss.numRegions > r->splitMaxRegions || (size_t)a.ss.numRegions*a.ss.regionLen > r->splitCap)
         return fail("render: path buffers too small for this batch");
     r->lastRegions = a.ss.numRegions;
     return 0;
+}
+
+// k_bounce over all bounces: the last `tailShare` of the batch's positions in regions a quarter as long (SplitState::bigRegions /
+// shortLen, tn_kernels.h).  Leaves `a` as set_regions made it when the batch is too small for that to mean anything or the
+// region arrays are too short.
+void split_tail_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, double tailShare, int divide)
+{
+    const uint32_t per = kBlock/kWave;                        // regions per group
+    const uint32_t L = a.ss.regionLen;
+    if (L < (uint32_t)(kWave*divide*2) || a.ss.numRegions < 64u*per)
+        return;
+    const uint32_t S = L/(uint32_t)divide/kWave*kWave;        // short regions: a multiple of 64 positions
+    uint32_t big = (uint32_t)((double)a.ss.numRegions*(1.0 - tailShare))/per*per;
+    const size_t covered = (size_t)big*L;
+    if (covered >= slots)
+        return;
+    const size_t rest = slots - covered;
+    const uint32_t small = (uint32_t)((rest + (size_t)S*per - 1)/((size_t)S*per))*per;
+    if (big + small > r->splitMaxRegions || (size_t)big*L + (size_t)small*S > r->splitCap)
+        return;
+    a.ss.bigRegions = big;
+    a.ss.shortLen = S;
+    a.ss.numRegions = big + small;
+    a.grid = (int)(a.ss.numRegions/per);
+    r->lastRegions = a.ss.numRegions;
 }
 
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp, bool accumulate = true)
@@ -1130,6 +1157,19 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             a.bounce = 0;
             a.bounceEnd = fp.maxDepth;
             a.order = nullptr;
+            {
+                // The last eighth of the positions in regions a quarter as long: a workgroup's region group is 0.75 ms of a 5 ms launch
+                // (cornell, 20 passes) and the launch ends when its last workgroup does.  cornell 1024^2 x 20 passes 3878 -> 4012 Msamples/s,
+                // x 8 3539 -> 3685, 512^2 x 16 2812 -> 3021, features 1183 -> 1292, veach 1080p 2414 -> 2610; gloss and env_loft at 64
+                // passes +0.3 % (profiles/r03_z5_ab_tail_split.md).  TINSEL_HIP_TAIL_SPLIT="share,divide" (A/B; "0": off)
+                const char* tailEnv = getenv("TINSEL_HIP_TAIL_SPLIT");
+                double share = 0.125;
+                int divide = 4;
+                if (tailEnv)
+                    sscanf(tailEnv, "%lf,%d", &share, &divide);
+                if (share > 0.0 && share < 0.9 && divide >= 2 && a.grid == gridPersist && (size_t)gridPersist*(kBlock/kWave) == a.ss.numRegions)
+                    split_tail_regions(r, a, slots, share, divide);
+            }
             {
                 // workgroup b takes region group (b*step) mod groups.  Index order (step 1) is the default: a golden-section step,
                 // which k_walk's static ranges need, loses here -- the dispatcher already hands workgroups out dynamically

@@ -309,6 +309,10 @@ struct SplitState
     uint32_t* neeFront; // [bounce][region] the same for the paths that have shadow rays, by NEE position
     uint32_t* neeBack;
     uint32_t numRegions, regionLen;     // regionLen is a multiple of 64
+    // k_bounce over all bounces only: the regions [bigRegions, numRegions) are SHORT ones (shortLen positions each, a multiple of 64; they
+    // follow the long ones in the position space).  Workgroups are dispatched in index order, so the short regions are what the chip works
+    // on when the launch runs out: its tail is a short region's time, not a long one's.  bigRegions == numRegions: all alike.
+    uint32_t bigRegions, shortLen;
     uint32_t capacity;  // positions per array
     int32_t neePerPath; // K
 };
@@ -522,7 +526,9 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         const uint32_t groups = ss.numRegions/kRegionsPerBlock;
         const uint32_t r0 = (order ? order[b] : (b*fp.groupStep) % groups)*kRegionsPerBlock;      // (both below 2^16: checked by the host)
         const uint32_t r = r0 + threadIdx.x/kWave;            // the region this wave generates / appends to
-        const uint32_t base = r*ss.regionLen;
+        const bool longOne = r < ss.bigRegions;            // (wave-uniform, and the same for the four regions of a group)
+        const uint32_t rLen = longOne ? ss.regionLen : ss.shortLen;
+        const uint32_t base = longOne ? r*ss.regionLen : ss.bigRegions*ss.regionLen + (r - ss.bigRegions)*ss.shortLen;
       for (int bounce = bounceBegin; bounce < bounceEnd; ++bounce)
       {
         const bool FIRST = bounce == 0;
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         uint32_t gF[kRegionsPerBlock], gStart[kRegionsPerBlock];
         if (FIRST)
         {
-            const uint32_t end = (base + ss.regionLen) < fp.genCount ? (base + ss.regionLen) : fp.genCount;
+            const uint32_t end = (base + rLen) < fp.genCount ? (base + rLen) : fp.genCount;
             n = base < end ? end - base : 0u;
         }
         else if (share)
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
             nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
             n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         }
-        RegionAppend out = { base, ss.regionLen, 0u, 0u };
+        RegionAppend out = { base, rLen, 0u, 0u };
 
         uint32_t poolCount = 0;         // wave-uniform: paths that hit a surface and wait for the shading half
         for (uint32_t j0 = share ? threadIdx.x/kWave*kWave : 0u; ; j0 += share ? kBlock : kWave)
@@ -605,10 +611,10 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
 #pragma unroll
                         for (uint32_t q2 = 1; q2 < kRegionsPerBlock; ++q2)
                             if (j >= gStart[q2]) { k = q2; f = gF[q2]; s0 = gStart[q2]; }
-                        pos = region_pos((r0 + k)*ss.regionLen, ss.regionLen, f, j - s0);
+                        pos = region_pos(base + (k - threadIdx.x/kWave)*rLen, rLen, f, j - s0);     // region r0 + k of this group
                     }
                     else
-                        pos = region_pos(base, ss.regionLen, nFront, j);
+                        pos = region_pos(base, rLen, nFront, j);
                     load_state(ss, cur, pos, p, slot, hasMedia);
                     have = true;
                 }
