@@ -491,7 +491,8 @@ int resolve_pipeline(const tinsel_hip* r)
 int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
 {
     const size_t K = split ? (size_t)r->neePerPath : 0;
-    const size_t maxRegions = (size_t)r->numCUs*(size_t)grid_mult()*(kBlock/kWave);
+    // (half as many again as the widest grid: the short regions at the end of a batch, split_tail_regions)
+    const size_t maxRegions = (size_t)r->numCUs*(size_t)grid_mult()*(kBlock/kWave)*3/2;
     const size_t cap = slots + maxRegions*kWave;        // a region is a whole number of waves long
     SplitState& ss = r->ss;
     memset(&ss, 0, sizeof(ss));
@@ -740,7 +741,7 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     {
         ScopedTimer t(r, KN_SEG, st);
         hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), ss.numRegions*sizeof(uint32_t), st, regionCounts, (const uint32_t*)nullptr, ss.numRegions, step, r->segPrefix);
-        hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
+        hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss, r->walkList);
     }
     WalkJob& job = a.walk;
     job.queue = r->walkList;
@@ -850,7 +851,7 @@ void launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* f
     {
         ScopedTimer t(r, KN_SEG, st);
         hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), ss.numRegions*sizeof(uint32_t), st, front, back, ss.numRegions, step, r->segPrefix);
-        hipLaunchKernelGGL(k_seg_expand_all, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, front, back, (const uint32_t*)r->segPrefix, ss.numRegions, ss.regionLen, r->walkList);
+        hipLaunchKernelGGL(k_seg_expand_all, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, front, back, (const uint32_t*)r->segPrefix, ss, r->walkList);
     }
     SwalkJob& job = a.swalk;
     job.list = r->walkList;
@@ -1061,29 +1062,53 @@ int set_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int gridPersist)
     return 0;
 }
 
-// k_bounce over all bounces: the last `tailShare` of the batch's positions in regions a quarter as long (SplitState::bigRegions /
-// shortLen, tn_kernels.h).  Leaves `a` as set_regions made it when the batch is too small for that to mean anything or the
-// region arrays are too short.
-void split_tail_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, double tailShare, int divide)
+// The last `tailShare` of the batch's positions in regions 1/divide as long (SplitState::bigRegions / shortLen, tn_kernels.h): what the chip
+// works on when a launch runs out.  `maxRegions` bounds their number (the region arrays; k_seg_prefix's LDS): where the uniform cut is
+// already at the bound the long regions get longer.  Leaves `a` as set_regions made it when the batch is too small for any of that.
+void split_tail_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, double tailShare, int divide, size_t maxRegions)
 {
     const uint32_t per = kBlock/kWave;                        // regions per group
-    const uint32_t L = a.ss.regionLen;
-    if (L < (uint32_t)(kWave*divide*2) || a.ss.numRegions < 64u*per)
+    maxRegions = std::min<size_t>(maxRegions, r->splitMaxRegions);
+    if (a.ss.regionLen < (uint32_t)(kWave*divide*2) || a.ss.numRegions < 64u*per || maxRegions < 128u*per)
         return;
+    const double factor = (1.0 - tailShare) + tailShare*(double)divide;
+    uint32_t L = a.ss.regionLen;
+    if ((double)slots*factor/(double)L + 2.0*per > (double)maxRegions)
+        L = (uint32_t)(((size_t)((double)slots*factor/(double)(maxRegions - 2*per)) + kWave)/kWave*kWave);
     const uint32_t S = L/(uint32_t)divide/kWave*kWave;        // short regions: a multiple of 64 positions
-    uint32_t big = (uint32_t)((double)a.ss.numRegions*(1.0 - tailShare))/per*per;
+    const uint32_t big = (uint32_t)((double)slots*(1.0 - tailShare)/(double)L)/per*per;
     const size_t covered = (size_t)big*L;
-    if (covered >= slots)
+    if (S < (uint32_t)kWave || big < per || covered >= slots)
         return;
     const size_t rest = slots - covered;
     const uint32_t small = (uint32_t)((rest + (size_t)S*per - 1)/((size_t)S*per))*per;
-    if (big + small > r->splitMaxRegions || (size_t)big*L + (size_t)small*S > r->splitCap)
+    if (big + small > maxRegions || (size_t)big*L + (size_t)small*S > r->splitCap)
         return;
+    a.ss.regionLen = L;
     a.ss.bigRegions = big;
     a.ss.shortLen = S;
     a.ss.numRegions = big + small;
-    a.grid = (int)(a.ss.numRegions/per);
     r->lastRegions = a.ss.numRegions;
+}
+
+// set_regions + the short regions at the end.  The last eighth of the positions in regions a quarter as long: a workgroup's region group
+// is 0.75 ms of a 5 ms launch (cornell, 20 passes) and a launch ends when its last workgroup does.  k_bounce alone (round 3, call Z5):
+// cornell 1024^2 x 20 passes 3878 -> 4012 Msamples/s, x 8 3539 -> 3685, 512^2 x 16 2812 -> 3021, features 1183 -> 1292, veach 1080p
+// 2414 -> 2610 (profiles/r03_z5_ab_tail_split.md).  TINSEL_HIP_TAIL_SPLIT="share,divide" (A/B; "0": off).  On return *grid is the number
+// of region groups = the workgroups of a launch that gives every group its own.
+int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t maxRegions)
+{
+    if (set_regions(r, a, slots, *grid))
+        return -1;
+    const char* tailEnv = getenv("TINSEL_HIP_TAIL_SPLIT");
+    double share = 0.125;
+    int divide = 4;
+    if (tailEnv)
+        sscanf(tailEnv, "%lf,%d", &share, &divide);
+    if (share > 0.0 && share < 0.9 && divide >= 2)
+        split_tail_regions(r, a, slots, share, divide, maxRegions);
+    *grid = (int)(a.ss.numRegions/(kBlock/kWave));
+    return 0;
 }
 
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp, bool accumulate = true)
@@ -1102,10 +1127,10 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     fp.share = 0;
     fp.groupStep = 1;
     const int gridFlat = (int)std::max<size_t>(1, (slots + kBlock - 1)/kBlock);
-    const int gridPersist = streaming_grid(r, slots, resolve_pipeline(r));
+    int gridPersist = streaming_grid(r, slots, resolve_pipeline(r));
     // the trace kernels stride over the regions: by default one block per four regions like the others
     static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : 0;
-    const int gridTrace = gridMultTrace > 0 ? std::max(1, std::min(gridPersist, r->numCUs*gridMultTrace)) : gridPersist;
+    int gridTrace = gridMultTrace > 0 ? std::max(1, std::min(gridPersist, r->numCUs*gridMultTrace)) : gridPersist;
     r->lastBatchSlots = slots;
 
     const int pipeline = resolve_pipeline(r);
@@ -1122,7 +1147,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     }
     else if (pipeline == TINSEL_PIPELINE_WAVEFRONT)
     {
-        if (set_regions(r, a, slots, gridPersist))
+        if (cut_regions(r, a, slots, &gridPersist, r->splitMaxRegions))
             return -1;
         a.grid = gridPersist;
         // k_bounce closes ranks between the closest-hit trace and the shading half (the waves' shading pools, tn_kernels.h:
@@ -1157,19 +1182,6 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             a.bounce = 0;
             a.bounceEnd = fp.maxDepth;
             a.order = nullptr;
-            {
-                // The last eighth of the positions in regions a quarter as long: a workgroup's region group is 0.75 ms of a 5 ms launch
-                // (cornell, 20 passes) and the launch ends when its last workgroup does.  cornell 1024^2 x 20 passes 3878 -> 4012 Msamples/s,
-                // x 8 3539 -> 3685, 512^2 x 16 2812 -> 3021, features 1183 -> 1292, veach 1080p 2414 -> 2610; gloss and env_loft at 64
-                // passes +0.3 % (profiles/r03_z5_ab_tail_split.md).  TINSEL_HIP_TAIL_SPLIT="share,divide" (A/B; "0": off)
-                const char* tailEnv = getenv("TINSEL_HIP_TAIL_SPLIT");
-                double share = 0.125;
-                int divide = 4;
-                if (tailEnv)
-                    sscanf(tailEnv, "%lf,%d", &share, &divide);
-                if (share > 0.0 && share < 0.9 && divide >= 2 && a.grid == gridPersist && (size_t)gridPersist*(kBlock/kWave) == a.ss.numRegions)
-                    split_tail_regions(r, a, slots, share, divide);
-            }
             {
                 // workgroup b takes region group (b*step) mod groups.  Index order (step 1) is the default: a golden-section step,
                 // which k_walk's static ranges need, loses here -- the dispatcher already hands workgroups out dynamically
@@ -1234,8 +1246,14 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         const bool lightsInMixed = lightsInExtendEnv && !walkedOnly && !r->countDetail && mixedArena && !(!noSceneWalkEarly && !r->scene.flatScan);
         a.lightsInExtend = lightsInMixed ? 1 : 0;
         const bool lightsInExtend = (walkedOnly && !r->countDetail) || lightsInMixed;
-        if (set_regions(r, a, slots, gridPersist))
+        // No short regions at the end by default here (TINSEL_HIP_TAIL_SPLIT_SPLIT=1: A/B): the launches are many and short, k_walk cuts its
+        // own list into static ranges, and more regions cost k_seg_prefix / k_walk more than the other kernels' tails gain -- the 524k-triangle
+        // config 2319 -> 2254 Msamples/s, many_spheres 2108 -> 2082, glass +-0 (profiles/r03_z5_ab_tail_split.md).  (k_seg_prefix stages
+        // the regions' counts in LDS: 39936 of them at most where a walk list is built.)
+        static const bool tailInSplit = getenv("TINSEL_HIP_TAIL_SPLIT_SPLIT") && atoi(getenv("TINSEL_HIP_TAIL_SPLIT_SPLIT")) != 0;
+        if (cut_regions(r, a, slots, &gridPersist, !tailInSplit ? (size_t)0 : r->walkList != nullptr ? (size_t)39936 : (size_t)r->splitMaxRegions))
             return -1;
+        gridTrace = gridMultTrace > 0 ? std::max(1, std::min(gridPersist, r->numCUs*gridMultTrace)) : gridPersist;
         const size_t W = a.ss.numRegions;
         {
             ScopedTimer t(r, KN_GENERATE, st);

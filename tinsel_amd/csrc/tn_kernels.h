@@ -325,6 +325,14 @@ TN_D uint32_t region_pos(uint32_t base, uint32_t len, uint32_t nFront, uint32_t 
     return i < nFront ? base + i : base + len - 1u - (i - nFront);
 }
 
+// a region's first position and its length: the regions [bigRegions, numRegions) are the short ones at the end of the position space
+// (SplitState::bigRegions); wave-uniform
+TN_D uint32_t region_len(const SplitState& ss, uint32_t r) { return r < ss.bigRegions ? ss.regionLen : ss.shortLen; }
+TN_D uint32_t region_base(const SplitState& ss, uint32_t r)
+{
+    return r < ss.bigRegions ? r*ss.regionLen : ss.bigRegions*ss.regionLen + (r - ss.bigRegions)*ss.shortLen;
+}
+
 // Appends to the two ends of a region, one wave at a time.  push() must be reached by every lane that is still in the
 // caller's loop (lanes with nothing to append pass keep = false).
 struct RegionAppend
@@ -526,9 +534,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         const uint32_t groups = ss.numRegions/kRegionsPerBlock;
         const uint32_t r0 = (order ? order[b] : (b*fp.groupStep) % groups)*kRegionsPerBlock;      // (both below 2^16: checked by the host)
         const uint32_t r = r0 + threadIdx.x/kWave;            // the region this wave generates / appends to
-        const bool longOne = r < ss.bigRegions;            // (wave-uniform, and the same for the four regions of a group)
-        const uint32_t rLen = longOne ? ss.regionLen : ss.shortLen;
-        const uint32_t base = longOne ? r*ss.regionLen : ss.bigRegions*ss.regionLen + (r - ss.bigRegions)*ss.shortLen;
+        const uint32_t rLen = region_len(ss, r);           // (the same for the four regions of a group)
+        const uint32_t base = region_base(ss, r);
       for (int bounce = bounceBegin; bounce < bounceEnd; ++bounce)
       {
         const bool FIRST = bounce == 0;
@@ -797,9 +804,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(SplitState ss, QueueCtl 
     uint32_t samples = 0;
     for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
     {
-        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
-        const uint32_t begin = r*ss.regionLen;
-        const uint32_t end = (begin + ss.regionLen) < fp.genCount ? (begin + ss.regionLen) : fp.genCount;
+        const uint32_t begin = region_base(ss, r), rLen = region_len(ss, r);
+        RegionAppend out = { begin, rLen, 0u, 0u };
+        const uint32_t end = (begin + rLen) < fp.genCount ? (begin + rLen) : fp.genCount;
         for (uint32_t i0 = begin; i0 < end; i0 += kWave)
         {
             const uint32_t idx = i0 + lane;
@@ -936,11 +943,12 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_
         const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
-        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
+        RegionAppend out = { rBase, rLen, 0u, 0u };
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
-            const uint32_t pos = region_pos(r*ss.regionLen, ss.regionLen, nFront, j < n ? j : 0u);
+            const uint32_t pos = region_pos(rBase, rLen, nFront, j < n ? j : 0u);
             bool has = false;
             V3 hitP, hitN;
             float time = 0.0f;
@@ -994,11 +1002,12 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
         const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
-        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
+        RegionAppend out = { rBase, rLen, 0u, 0u };
         // the next round's records are requested before this round's samples are drawn (see k_shade)
         float4 nro, nrd, nhh;
         int nprim = -1;
-        uint32_t npos = region_pos(r*ss.regionLen, ss.regionLen, nFront, lane < n ? lane : 0u);
+        uint32_t npos = region_pos(rBase, rLen, nFront, lane < n ? lane : 0u);
         if (lane < n)
         {
             nro = ss.rayO[cur][npos]; nrd = ss.rayD[cur][npos]; nhh = ss.hit[npos]; nprim = ss.hitPrim[npos];
@@ -1011,7 +1020,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
             const bool has = j < n && nprim >= 0;
             {
                 const uint32_t jn = j + kWave;
-                npos = region_pos(r*ss.regionLen, ss.regionLen, nFront, jn < n ? jn : 0u);
+                npos = region_pos(rBase, rLen, nFront, jn < n ? jn : 0u);
                 if (jn < n)
                 {
                     nro = ss.rayO[cur][npos]; nrd = ss.rayD[cur][npos]; nhh = ss.hit[npos]; nprim = ss.hitPrim[npos];
@@ -1065,12 +1074,13 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
         const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t nFront = wave_uniform(ss.neeFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.neeBack[(size_t)bounce*ss.numRegions + r]);
+        const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
             if (j >= n)
                 continue;
-            const uint32_t qn = region_pos(r*ss.regionLen, ss.regionLen, nFront, j);
+            const uint32_t qn = region_pos(rBase, rLen, nFront, j);
             const float time = ss.neeTime[qn];
 
             for (int k = 0; k < K; ++k)
@@ -1231,7 +1241,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
         const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
-        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
+        RegionAppend out = { rBase, rLen, 0u, 0u };
         // A round's records are requested at its start.  (Round 2 requested round i + 1's before shading round i: at two waves per SIMD
         // that hid a latency.  At three, the 30 registers of a second ShadeFetch are spilled ones, and the wait for the shadow-ray
         // records in the middle of the round -- vmcnt counts in order -- waited for the early request as well: without it k_shade spills
@@ -1240,7 +1251,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
         // registers or through LDS with global_load_lds, spills 352-400 B and doubles the kernel's time.)
 #if TN_SHADE_PREFETCH
         ShadeFetch next;
-        next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, lane < n ? lane : 0u), lane < n, hasMedia, K > 0, bounce == 0);
+        next.issue(ss, cur, region_pos(rBase, rLen, nFront, lane < n ? lane : 0u), lane < n, hasMedia, K > 0, bounce == 0);
 #endif
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
@@ -1249,11 +1260,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
             const ShadeFetch f = next;
             {
                 const uint32_t jn = j + kWave;
-                next.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, jn < n ? jn : 0u), jn < n, hasMedia, K > 0, bounce == 0);
+                next.issue(ss, cur, region_pos(rBase, rLen, nFront, jn < n ? jn : 0u), jn < n, hasMedia, K > 0, bounce == 0);
             }
 #else
             ShadeFetch f;
-            f.issue(ss, cur, region_pos(r*ss.regionLen, ss.regionLen, nFront, j < n ? j : 0u), j < n, hasMedia, K > 0, bounce == 0);
+            f.issue(ss, cur, region_pos(rBase, rLen, nFront, j < n ? j : 0u), j < n, hasMedia, K > 0, bounce == 0);
 #endif
             bool alive = false, front = true;
             PathRegs p;
@@ -1305,7 +1316,8 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade_sorted(DevScen
         const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
-        RegionAppend out = { r*ss.regionLen, ss.regionLen, 0u, 0u };
+        const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
+        RegionAppend out = { rBase, rLen, 0u, 0u };
         uint32_t cnt[kShadeClasses] = { 0u, 0u, 0u, 0u };       // wave-uniform
 
         // One loop, ONE shading site (the shading code is 6,000 instructions: it must not be instantiated per class): every turn either
@@ -1313,7 +1325,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade_sorted(DevScen
         // their positions, or -- region read -- shades what is left, class after class, in as few rounds as the leftovers' sum needs.
         int nextPrim = -1;          // the hit primitives of the next round are requested a round ahead (4 B per path)
         if (lane < n)
-            nextPrim = ss.hitPrim[region_pos(r*ss.regionLen, ss.regionLen, nFront, lane)];
+            nextPrim = ss.hitPrim[region_pos(rBase, rLen, nFront, lane)];
         uint32_t j0 = 0, e0 = 0;
         for (;;)
         {
@@ -1336,10 +1348,10 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade_sorted(DevScen
             else if (j0 < n)
             {
                 const uint32_t j = j0 + lane;
-                const uint32_t at = region_pos(r*ss.regionLen, ss.regionLen, nFront, j < n ? j : 0u);
+                const uint32_t at = region_pos(rBase, rLen, nFront, j < n ? j : 0u);
                 const int prim = nextPrim;
                 if (j + kWave < n)
-                    nextPrim = ss.hitPrim[region_pos(r*ss.regionLen, ss.regionLen, nFront, j + kWave)];
+                    nextPrim = ss.hitPrim[region_pos(rBase, rLen, nFront, j + kWave)];
                 int cls = -1;
                 if (j < n)
                 {
@@ -1473,15 +1485,14 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
         prefix[numRegions] = total;
 }
 
-__global__ __launch_bounds__(kBlock) void k_seg_expand(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix, uint32_t numRegions,
-                                                       uint32_t regionLen, uint32_t* __restrict__ list)
+__global__ __launch_bounds__(kBlock) void k_seg_expand(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix, SplitState ss, uint32_t* __restrict__ list)
 {
     const uint32_t lane = __lane_id();
-    for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < numRegions; r += gridDim.x*(kBlock/kWave))
+    for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
     {
-        const uint32_t n = wave_uniform(counts[r]), at = wave_uniform(prefix[r]);
+        const uint32_t n = wave_uniform(counts[r]), at = wave_uniform(prefix[r]), base = region_base(ss, r);
         for (uint32_t i = lane; i < n; i += kWave)
-            list[at + i] = r*regionLen + i;
+            list[at + i] = base + i;
     }
 }
 

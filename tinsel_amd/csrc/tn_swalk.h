@@ -32,14 +32,15 @@ constexpr int kSwalkCtlWords = 16;
 
 // the listed positions of a region packed at both ends: entry i of the region's n = nFront + nBack live entries
 __global__ __launch_bounds__(kBlock) void k_seg_expand_all(const uint32_t* __restrict__ front, const uint32_t* __restrict__ back, const uint32_t* __restrict__ prefix,
-                                                           uint32_t numRegions, uint32_t regionLen, uint32_t* __restrict__ list)
+                                                           SplitState ss, uint32_t* __restrict__ list)
 {
     const uint32_t lane = __lane_id();
-    for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < numRegions; r += gridDim.x*(kBlock/kWave))
+    for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
     {
         const uint32_t nF = wave_uniform(front[r]), n = nF + wave_uniform(back[r]), at = wave_uniform(prefix[r]);
+        const uint32_t base = region_base(ss, r), len = region_len(ss, r);
         for (uint32_t i = lane; i < n; i += kWave)
-            list[at + i] = region_pos(r*regionLen, regionLen, nF, i);
+            list[at + i] = region_pos(base, len, nF, i);
     }
 }
 
