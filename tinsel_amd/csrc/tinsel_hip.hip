@@ -1091,7 +1091,7 @@ void split_tail_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, double tailS
     r->lastRegions = a.ss.numRegions;
 }
 
-// set_regions + the short regions at the end.  The last eighth of the positions in regions a quarter as long: a workgroup's region group
+// set_regions + the short regions at the end.  The last eighth or so of the positions in regions a quarter as long: a workgroup's region group
 // is 0.75 ms of a 5 ms launch (cornell, 20 passes) and a launch ends when its last workgroup does.  k_bounce alone (round 3, call Z5):
 // cornell 1024^2 x 20 passes 3878 -> 4012 Msamples/s, x 8 3539 -> 3685, 512^2 x 16 2812 -> 3021, features 1183 -> 1292, veach 1080p
 // 2414 -> 2610 (profiles/r03_z5_ab_tail_split.md).  TINSEL_HIP_TAIL_SPLIT="share,divide" (A/B; "0": off).  On return *grid is the number
@@ -1101,10 +1101,18 @@ int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t ma
     if (set_regions(r, a, slots, *grid))
         return -1;
     const char* tailEnv = getenv("TINSEL_HIP_TAIL_SPLIT");
-    double share = 0.125;
+    double share = -0.5;
     int divide = 4;
     if (tailEnv)
         sscanf(tailEnv, "%lf,%d", &share, &divide);
+    if (share < 0.0)
+    {
+        // a negative share: that multiple of ONE resident set's part of the batch (three workgroups per CU: k_bounce).  The default, half a
+        // set's part, against a fixed eighth: cornell x 20 passes 4036 -> 4059, x 64 4203 -> 4221, features 1289 -> 1298, veach 1080p
+        // 2610 -> 2621, gloss 10570 -> 10530 (call Z8)
+        const double sets = (double)*grid/(double)(3*r->numCUs);
+        share = std::min(0.25, std::max(0.03, -share/std::max(1.0, sets)));
+    }
     if (share > 0.0 && share < 0.9 && divide >= 2)
         split_tail_regions(r, a, slots, share, divide, maxRegions);
     *grid = (int)(a.ss.numRegions/(kBlock/kWave));
