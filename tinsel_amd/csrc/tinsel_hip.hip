@@ -1091,6 +1091,33 @@ void split_tail_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, double tailS
     r->lastRegions = a.ss.numRegions;
 }
 
+// A batch that ONE resident set of workgroups takes whole (cfg1: 256^2 x 16 passes = 683 region groups for 768 slots): two thirds of the CUs
+// get three groups, a third gets two, and the launch lasts as long as three.  Cut so that every CU gets TWO long groups -- three quarters of
+// the batch -- and the rest in groups a third as long, which the dispatcher deals out as slots come free: every CU ends up with the same
+// work.  cornell 256^2 x 16 passes 2402 -> 2670 Msamples/s, 512^2 x 4 2600 -> 2919, veach 256^2 x 16 1176 -> 1324 (call Z10).
+bool split_one_set(tinsel_hip* r, LaunchArgs& a, size_t slots)
+{
+    const uint32_t per = kBlock/kWave;
+    const size_t cus = (size_t)r->numCUs;
+    const uint32_t L = (uint32_t)((slots*3/4)/(2*cus*per)/kWave*kWave);
+    if (L < 3u*kWave)
+        return false;
+    const uint32_t S = L/3/kWave*kWave;
+    const uint32_t big = (uint32_t)(2*cus)*per;
+    const size_t covered = (size_t)big*L;
+    if (covered >= slots)
+        return false;
+    const uint32_t small = (uint32_t)((slots - covered + (size_t)S*per - 1)/((size_t)S*per))*per;
+    if (big + small > r->splitMaxRegions || (size_t)big*L + (size_t)small*S > r->splitCap)
+        return false;
+    a.ss.regionLen = L;
+    a.ss.bigRegions = big;
+    a.ss.shortLen = S;
+    a.ss.numRegions = big + small;
+    r->lastRegions = a.ss.numRegions;
+    return true;
+}
+
 // set_regions + the short regions at the end.  The last eighth or so of the positions in regions a quarter as long: a workgroup's region group
 // is 0.75 ms of a 5 ms launch (cornell, 20 passes) and a launch ends when its last workgroup does.  k_bounce alone (round 3, call Z5):
 // cornell 1024^2 x 20 passes 3878 -> 4012 Msamples/s, x 8 3539 -> 3685, 512^2 x 16 2812 -> 3021, features 1183 -> 1292, veach 1080p
@@ -1105,6 +1132,12 @@ int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t ma
     int divide = 4;
     if (tailEnv)
         sscanf(tailEnv, "%lf,%d", &share, &divide);
+    // (three workgroups per CU are resident: k_bounce)
+    if (share < 0.0 && maxRegions > 0 && (size_t)*grid <= (size_t)r->numCUs*3 && (size_t)*grid > (size_t)r->numCUs*2 && split_one_set(r, a, slots))
+    {
+        *grid = (int)(a.ss.numRegions/(kBlock/kWave));
+        return 0;
+    }
     if (share < 0.0)
     {
         // a negative share: that multiple of ONE resident set's part of the batch (three workgroups per CU: k_bounce).  The default, half a
