@@ -409,6 +409,12 @@ int tinsel_hip_group_size(tinsel_hip_group* g);
  * Whatever the group had speculated is dropped first (look-ahead starts over with the next read-back). */
 tinsel_hip* tinsel_hip_group_member(tinsel_hip_group* g, int rank);
 
+/* How a batch of `slots` path slots is cut into regions on a device of `num_cus` CUs (the dense path state of the wavefront pipelines:
+ * DESIGN.md section 4; `fused` != 0: the fused pipeline, which ends a batch with shorter regions).  Pure host arithmetic -- no device is
+ * touched: out[6] = number of regions, positions per region, regions of that length (the rest are short), positions per short region,
+ * workgroups of a launch, capacity of the region arrays.  Introspection for the tests; no reference counterpart. */
+int tinsel_hip_plan_regions(unsigned long long slots, int num_cus, int nee_per_path, int fused, unsigned int* out);
+
 /* Exhaustive self-test of the parity arm's short reciprocal / square-root sequences (tn_math.h rcp_candidate / sqrt_candidate):
  * compares the candidate with the compiler's correctly rounded `1.0f/x` (op 0), `sqrtf(x)` (op 1) or `1.0f/sqrtf(x)` (op 2) on ALL 2^32 fp32 bit patterns
  * on the device.  variant < 0: the variant this library's kernels are built with (0 = the compiler's own expansion).

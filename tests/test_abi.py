@@ -139,3 +139,33 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_api" not in text and "libtinsel_oracle" not in text and "libtinsel_ref" not in text, f
                 assert not re.search(r'#include\s+"[^"]*oracle', text), f
+
+
+def test_region_cut_invariants_over_the_whole_range_of_batch_sizes():
+    """tinsel_hip_plan_regions (host arithmetic of streaming_grid + cut_regions, no device): however a batch is cut -- uniform regions,
+    short regions at the end of a large batch, the equal-share cut of a batch that one resident set takes whole -- the regions cover
+    every slot, are whole waves long, come in whole workgroups of four, fit the arrays sized for them, and the short ones are the last."""
+    import random
+    import tinsel_amd
+    rng = random.Random(7)
+    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 65536, 256*256*16, 512*512*4, 1024*1024, 1920*1080, 1920*1080*20,
+             1024*1024*20, 1024*1024*64, 3840*2160*8, (64 << 20) - 1, 64 << 20, (64 << 20) + 1, 200_000_000, 4_000_000_000]
+    sizes += [rng.randrange(1, 1 << rng.randrange(1, 32)) for _ in range(1500)]
+    for cus in (256, 304, 64, 8):
+        for fused in (True, False):
+            for nee in (1, 4):
+                for slots in sizes:
+                    p = tinsel_amd.plan_regions(slots, cus, nee, fused)
+                    n, L, big, S, grid, cap = (p[k] for k in ("num_regions", "region_len", "big_regions", "short_len", "grid", "max_regions"))
+                    what = "%d slots, %d CUs, fused %s: %s" % (slots, cus, fused, p)
+                    assert n >= 4 and n % 4 == 0 and big % 4 == 0 and 0 < big <= n, what
+                    assert L >= 64 and L % 64 == 0 and S >= 64 and S % 64 == 0 and S <= L, what
+                    assert grid*4 == n and n <= cap, what
+                    covered = big*L + (n - big)*S
+                    assert covered >= slots, what
+                    assert covered <= slots + cap*64, what          # the arrays' padding: a wave per region
+                    assert covered < (1 << 32), what                # positions are 32-bit
+                    if not fused:
+                        assert big == n, what                       # the split pipeline keeps all regions alike
+                    if n > big:                                     # short regions exist: the long ones alone do not cover the batch
+                        assert big*L < slots, what

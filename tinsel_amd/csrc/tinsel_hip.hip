@@ -3094,6 +3094,28 @@ int tinsel_hip_queue_counts(tinsel_hip* r, uint32_t* out, int max_bounces)
 // kinds 1..3 = dependent 64-B record chases through a table of `bytes` bytes rounded down to a power of two, `steps` visits
 // per lane (units = records visited); the kind only names the kernel for the profiler (1 beyond the Infinity Cache, 2 the size
 // of a walked tree, 3 inside one L2).  One warm-up launch, then one timed with HIP events.
+// How a batch of `slots` path slots would be cut into regions on a device of `num_cus` CUs (streaming_grid + cut_regions): pure host
+// arithmetic, no device needed -- tests/test_abi.py checks its invariants over the whole range of batch sizes on the CPU box
+int tinsel_hip_plan_regions(unsigned long long slots, int num_cus, int nee_per_path, int fused, unsigned int* out)
+{
+    if (!out || slots == 0 || slots >= 0xffffffffull || num_cus < 1 || num_cus > 4096)
+        return fail("plan_regions: bad arguments");
+    tinsel_hip* r = new tinsel_hip();
+    r->numCUs = num_cus;
+    r->neePerPath = nee_per_path;
+    // (alloc_dense's capacities)
+    const size_t maxRegions = (size_t)num_cus*(size_t)grid_mult()*(kBlock/kWave)*3/2;
+    r->splitMaxRegions = (uint32_t)maxRegions;
+    r->splitCap = (size_t)slots + maxRegions*kWave;
+    LaunchArgs a = {};
+    int grid = streaming_grid(r, (size_t)slots, fused ? TINSEL_PIPELINE_WAVEFRONT : TINSEL_PIPELINE_WAVEFRONT_SPLIT);
+    const int rc = cut_regions(r, a, (size_t)slots, &grid, fused ? (size_t)r->splitMaxRegions : (size_t)0);
+    out[0] = a.ss.numRegions; out[1] = a.ss.regionLen; out[2] = a.ss.bigRegions; out[3] = a.ss.shortLen;
+    out[4] = (unsigned int)grid; out[5] = r->splitMaxRegions;
+    delete r;
+    return rc;
+}
+
 int tinsel_hip_selftest_arith(int device_index, int op, int variant, unsigned long long* out_counts, unsigned int* out_first_bad)
 {
     if (!out_counts || !out_first_bad || op < 0 || op > 2)

@@ -107,6 +107,7 @@ def load_library():
     L.tinsel_hip_group_set_lookahead.argtypes = [vp, ci]
     L.tinsel_hip_ubench.argtypes = [ci, ci, C.c_ulonglong, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tinsel_hip_selftest_arith.argtypes = [ci, ci, ci, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
+    L.tinsel_hip_plan_regions.argtypes = [C.c_ulonglong, ci, ci, ci, C.POINTER(C.c_uint)]
     L.tinsel_hip_last_error.restype = C.c_char_p
     L.tinsel_pack_open.argtypes = [vp, C.c_size_t, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.Options)]
     _lib = L
@@ -124,7 +125,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_walked_prims", "tinsel_hip_queue_counts", "tinsel_hip_set_lookahead", "tinsel_hip_set_arithmetic", "tinsel_hip_get_arithmetic", "tinsel_hip_refit_mesh", "tinsel_hip_set_probe_sampling",
     "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
     "tinsel_hip_group_size", "tinsel_hip_group_member", "tinsel_hip_group_set_lookahead", "tinsel_hip_ubench",
-    "tinsel_hip_selftest_arith",
+    "tinsel_hip_selftest_arith", "tinsel_hip_plan_regions",
 ]
 
 
@@ -432,6 +433,14 @@ def ubench(kind, nbytes, steps=64, device=0):
     ms, units = C.c_double(0.0), C.c_double(0.0)
     _check(L.tinsel_hip_ubench(int(device), int(kind), int(nbytes), int(steps), C.byref(ms), C.byref(units)), "tinsel_hip_ubench")
     return ms.value, units.value
+
+
+def plan_regions(slots, num_cus=256, nee_per_path=1, fused=True):
+    """tinsel_hip_plan_regions: dict of how a batch of `slots` path slots would be cut (host arithmetic only, no GPU needed)."""
+    L = load_library()
+    out = (C.c_uint*6)()
+    _check(L.tinsel_hip_plan_regions(int(slots), int(num_cus), int(nee_per_path), 1 if fused else 0, out), "tinsel_hip_plan_regions")
+    return dict(zip(("num_regions", "region_len", "big_regions", "short_len", "grid", "max_regions"), (int(v) for v in out)))
 
 
 def selftest_arith(op, variant=-1, device=0):
