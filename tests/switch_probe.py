@@ -1,4 +1,4 @@
-"""Child process of tests/test_gpu_switches.py: renders a few fixtures through every pipeline with the environment it was started in (the
+"""Child process of tests/test_gpu_switches.py: renders a few fixtures through both wavefront pipelines with the environment it was started in (the
 library reads most of its A/B switches once per process) and compares per-path radiance and the framebuffer with the golden files, bit for bit.
 Prints one line per (fixture, pipeline): `ok` or the number of paths that differ; exit status 1 on any difference."""
 import os
@@ -12,7 +12,7 @@ from tinsel_amd import Scene, abi, create_gpu_renderer  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 FIXTURES = sys.argv[1].split(",") if len(sys.argv) > 1 else ["cornell", "veach", "glass", "features", "ajax_standin_96", "many_spheres"]
-PIPELINES = [("wavefront", abi.PIPELINE_WAVEFRONT), ("split", abi.PIPELINE_WAVEFRONT_SPLIT), ("auto", abi.PIPELINE_AUTO)]
+PIPELINES = [("wavefront", abi.PIPELINE_WAVEFRONT), ("split", abi.PIPELINE_WAVEFRONT_SPLIT)]      # (the default pipeline is one of the two)
 
 
 def main():
