@@ -2,26 +2,34 @@
 //
 // A thin extern "C" driver around the *unmodified* reference CPU path.  It is
 // compiled together with the reference's own sources where they lie under
-// /root/reference/src (render.cpp scene.cpp mesh.cpp loader.cpp pfm.cpp
-// platform.cpp) by oracle/Makefile into oracle/_ref/libtinsel_ref.so.  Nothing
-// here re-implements the integrator: radiance comes from the reference's exported
+// /root/reference/src (scene.cpp mesh.cpp loader.cpp pfm.cpp platform.cpp nlm.cpp
+// png.cpp; render.cpp is #included below, unmodified, so that this translation unit
+// sees the definition of `struct CpuRenderer`) by oracle/Makefile into
+// oracle/_ref/libtinsel_ref.so.  Nothing here re-implements the integrator or the
+// framebuffer splat: radiance comes from the reference's
 //     Vec3 PathTrace(const Scene&, const Vec3&, const Vec3&, float, int, Random&)
-// (reference src/render.cpp:230) and from CreateCpuRenderer (render.cpp:528).
+// (reference src/render.cpp:230), the framebuffer from the reference's own compiled
+//     CpuRenderer::AddSample (render.cpp:401-445)
+// and the faithful loop from CreateCpuRenderer (render.cpp:528).
 //
 // What this file adds (all of it cited):
 //   * the per-path seed contract  Random(i + j*W + passSeed[s])   (render.cu:940,1050-1052,1099)
 //   * the camera-sample draw order of the CPU oracle              (render.cpp:476-484)
-//   * a restatement of CpuRenderer::AddSample (a private member)  (render.cpp:401-445)
 //   * scene-pack (de)serialisation so scenes travel without the reference loader
 //   * leaf-function tables (reference inline functions evaluated on caller arrays)
+//   * a restatement of AddSample kept ONLY to be compared with the compiled one (ref_add_sample_agrees, tests/test_oracle.py)
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load this.
+
+// The reference's render.cpp, compiled HERE, unmodified, from where it lies: PathTrace (:230; declared in none of its headers),
+// struct CpuRenderer with its AddSample (:390-524), CreateCpuRenderer (:528).  (oracle/Makefile leaves render.cpp out of the list of
+// separately compiled sources for that reason.  It comes first: disney.h, which it includes, has no include guard.)
+#include "render.cpp"
 
 #include "render.h"
 #include "intersection.h"
 #include "util.h"
 #include "sampler.h"
-#include "disney.h"
 #include "loader.h"
 #include "mesh.h"
 #include "scene.h"
@@ -38,8 +46,6 @@
 #include <thread>
 #include <vector>
 
-// exported by the reference's render.cpp but declared in none of its headers
-Vec3 PathTrace(const Scene& scene, const Vec3& startOrigin, const Vec3& startDir, float time, int maxDepth, Random& rand);
 
 static_assert(sizeof(Primitive) == sizeof(tinsel_primitive), "Primitive mirror");
 static_assert(sizeof(BVHNode) == sizeof(tinsel_bvh_node), "BVHNode mirror");
@@ -82,8 +88,9 @@ inline uint32_t PassSeed(uint32_t passIndex)
     return v;
 }
 
-// CpuRenderer::AddSample (render.cpp:401-445); private to render.cpp, so restated here.
-void AddSample(Color* output, int width, int height, float rasterX, float rasterY, float clamp, const Filter& filter, const Vec3& sample)
+// A restatement of CpuRenderer::AddSample (render.cpp:401-445).  NOT what the oracle's framebuffer is made with (that is the
+// reference's own compiled member, ref_render_seeded below): kept to be compared with it (ref_add_sample_agrees).
+void AddSampleRestated(Color* output, int width, int height, float rasterX, float rasterY, float clamp, const Filter& filter, const Vec3& sample)
 {
     int startX = Max(0, int(rasterX - filter.width));
     int startY = Max(0, int(rasterY - filter.width));
@@ -521,12 +528,14 @@ double ref_render_seeded(void* h, const tinsel_camera* cam_, const tinsel_option
 
         if (accum)
         {
+            // the reference's own compiled CpuRenderer::AddSample (render.cpp:401-445), in raster order like render.cpp:462-490
+            CpuRenderer splat(&rs->scene);
             Color* out = (Color*)accum;
             for (int j = y0; j < y1; ++j)
                 for (int i = x0; i < x1; ++i)
                 {
                     size_t k = (size_t)(j - y0)*winW + (i - x0);
-                    AddSample(out, W, H, rasters[k].x, rasters[k].y, options.clamp, options.filter, samples[k]);
+                    splat.AddSample(out, W, H, rasters[k].x, rasters[k].y, options.clamp, options.filter, samples[k]);
                 }
         }
     }
@@ -735,5 +744,27 @@ void ref_primitive_bounds(void* h, int prim, float* out6)
 }
 
 int ref_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
+
+// The restated AddSample against the reference's compiled CpuRenderer::AddSample (render.cpp:401-445): `n` seeded random samples
+// (raster positions over and around a W x H frame, radiance up to 8 so that `clamp` bites) splatted with both into two buffers; returns
+// the number of floats that differ (0 expected).  filterType: eFilterBox / eFilterGaussian.
+int ref_add_sample_agrees(int W, int H, int filterType, float filterWidth, float filterFalloff, float clamp, uint32_t seed, int n)
+{
+    std::vector<Color> a((size_t)W*H), b((size_t)W*H);
+    Filter filter((FilterType)filterType, filterWidth, filterFalloff);
+    CpuRenderer compiled(nullptr);
+    Random rand = SeededRandom(seed);
+    for (int k = 0; k < n; ++k)
+    {
+        const float x = rand.Randf(-2.0f, (float)W + 2.0f), y = rand.Randf(-2.0f, (float)H + 2.0f);
+        const Vec3 c(rand.Randf(0.0f, 8.0f), rand.Randf(0.0f, 8.0f), rand.Randf(0.0f, 8.0f));
+        compiled.AddSample(&a[0], W, H, x, y, clamp, filter, c);
+        AddSampleRestated(&b[0], W, H, x, y, clamp, filter, c);
+    }
+    int bad = 0;
+    for (size_t i = 0; i < a.size(); ++i)
+        bad += memcmp(&a[i], &b[i], sizeof(Color)) != 0;
+    return bad;
+}
 
 } // extern "C"

@@ -1,0 +1,30 @@
+#!/bin/bash
+# round 4, call B: k_walk's bottom level out of Pair128 records, second version (ONE round trip per triangle phase: a pair's five 16-B
+# words requested at once, leaf boxes computed from the vertices): parity first, then the A/B
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r4b; mkdir -p $O
+( time timeout 600 python -m pytest tests/test_gpu_walk.py tests/test_gpu_refit.py tests/test_gpu_lbvh.py -x -q 2>&1 | tail -15 ) > $O/pytest_walk.log 2>&1; tail -8 $O/pytest_walk.log
+( time timeout 600 python -m pytest tests/test_gpu_switches.py -q -k "WALK_ or defaults" 2>&1 | tail -15 ) > $O/pytest_switches.log 2>&1; tail -6 $O/pytest_switches.log
+( time timeout 600 python -m pytest tests/test_gpu_configs.py tests/test_fuzz.py -q -x 2>&1 | tail -15 ) > $O/pytest_configs.log 2>&1; tail -6 $O/pytest_configs.log
+run() { timeout 120 python bench.py "$@" --no-cpu-baseline --no-pmc --no-second-config --no-api --no-fast --no-ubench 2>/tmp/err.txt > /tmp/b.json || tail -3 /tmp/err.txt
+python - <<PY
+import json
+d=json.load(open('/tmp/b.json'))
+print('| $TAG | %s | %.1f | %s |' % (d['config']['workload'].split(',')[0], d['value'], d['roofline']['kernel_ms']), flush=True)
+PY
+}
+ab() { local S="$1"; shift; ( [ "$S" != "-" ] && export $S; TAG="$S" run "$@" ); }
+CFG3="--scene large/ajax_standin --width 1920 --height 1080 --steps 20 --warmup 2"
+GLASS="--scene glass --width 1920 --height 1080 --maxdepth 12 --steps 20 --warmup 2"
+( echo "| environment | config | Msamples/s | kernel ms of one timed block |"; echo "|---|---|---|---|"
+for S in "TINSEL_HIP_WALK_PAIRS=0 TINSEL_HIP_WALK_SINGLE=0" "TINSEL_HIP_WALK_PAIRS=0" "-" "TINSEL_HIP_WALK_SINGLE=0" "TINSEL_HIP_WALK_PAIRS=0" "-"; do ab "$S" $CFG3; done
+for L in 4 6 12 16; do ab "TINSEL_HIP_WALK_LEAFMIN=$L" $CFG3; done
+for R in 16 32; do ab "TINSEL_HIP_WALK_REFILL=$R" $CFG3; done
+ab "TINSEL_HIP_WALK_LDS_STACK=6" $CFG3; ab "TINSEL_HIP_WALK_LDS_STACK=10" $CFG3
+ab "TINSEL_HIP_WALK_PAIRS=0 TINSEL_HIP_WALK_LDS_STACK=6" $CFG3; ab "TINSEL_HIP_WALK_PAIRS=0 TINSEL_HIP_WALK_LDS_STACK=10" $CFG3
+ab "-" --scene large/ajax_standin --width 1920 --height 1080 --steps 32 --warmup 2; ab "TINSEL_HIP_WALK_PAIRS=0" --scene large/ajax_standin --width 1920 --height 1080 --steps 32 --warmup 2
+for S in "TINSEL_HIP_WALK_PAIRS=0" "-" "TINSEL_HIP_WALK_LEAFMIN=16" "TINSEL_HIP_WALK_PAIRS=0" "-"; do ab "$S" $GLASS; done
+) 2>&1 | tee $O/ab_walk_pairs2.md
+for S in "TINSEL_HIP_WALK_PAIRS=0" "-"; do
+  ( [ "$S" != "-" ] && export $S; echo "== $S"; TINSEL_HIP_LIB=$GRAFT_REPO_ROOT/scratch/libtinsel_hip_walkprof.so timeout 120 python scratch/walk_prof.py large/ajax_standin 1920 1080 4 20 2>&1 | tail -2 )
+done 2>&1 | tee $O/walk_profile.txt

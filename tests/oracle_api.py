@@ -138,6 +138,9 @@ class RefOracle(_OracleBase):
         L.ref_leaf_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 5
         L.ref_leaf_probe.restype = None
         L.ref_hardware_threads.restype = C.c_int
+        if hasattr(L, "ref_add_sample_agrees"):
+            L.ref_add_sample_agrees.restype = C.c_int
+            L.ref_add_sample_agrees.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int]
 
     def load_tin(self, path):
         h = self.lib.ref_scene_load_tin(path.encode())

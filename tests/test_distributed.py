@@ -72,3 +72,13 @@ def test_gloo_world2_reduce_equals_whole(tmp_path):
     # identical up to float summation order (each pixel sums the same terms, grouped by rank)
     np.testing.assert_allclose(reduced, whole, rtol=2e-6, atol=1e-6)
     assert oa.image_l2(reduced, whole) < 1e-6
+
+
+def test_reduce_accum_fills_out_with_one_rank():
+    # a caller that reads its own `out` buffer must find the sum there for ANY number of ranks, one included
+    import torch
+    acc = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4)
+    out = torch.full_like(acc, -1.0)
+    got = distributed.reduce_accum(acc, dst=0, out=out)
+    assert got is out and torch.equal(out, acc)
+    assert distributed.reduce_accum(acc, dst=0) is acc

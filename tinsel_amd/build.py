@@ -9,10 +9,14 @@ two floating-point contracts (tn_launch.h):
       -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -freciprocal-math -fgpu-flush-denormals-to-zero
       (never -ffinite-math-only: the traversal relies on 1/0 = inf like the reference)
 """
+import hashlib
+import json
 import os
 import shutil
 import subprocess
 import sys
+import tempfile
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -51,28 +55,78 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in DEPS)
 
 
-def build(force=False, verbose=True, extra=()):
-    if not force and up_to_date():
-        return OUT
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def _compile(obj_dir, extra=(), verbose=True):
+    """Compiles the two translation units side by side into obj_dir (always: no up-to-date shortcut)."""
+    os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
+    # (run INSIDE obj_dir with a relative output name: the object embeds the output path as given, and two compiles of the same source
+    # with the same command line are byte-identical only then -- what build_verified compares)
     jobs = [
-        [cc] + HIPCC_FLAGS + list(extra) + ["-c", SRC, "-o", os.path.join(OBJ_DIR, "tinsel_hip.o")],
-        [cc] + FAST_FLAGS + list(extra) + ["-c", SRC_FAST, "-o", os.path.join(OBJ_DIR, "tinsel_fast.o")],
+        [cc] + HIPCC_FLAGS + list(extra) + ["-c", SRC, "-o", "tinsel_hip.o"],
+        [cc] + FAST_FLAGS + list(extra) + ["-c", SRC_FAST, "-o", "tinsel_fast.o"],
     ]
     procs = []
-    for cmd in jobs:                    # the two translation units compile side by side
+    for cmd in jobs:
         if verbose:
-            print("[tinsel_amd.build]", " ".join(cmd), flush=True)
-        procs.append(subprocess.Popen(cmd))
+            print("[tinsel_amd.build] (in %s)" % obj_dir, " ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd, cwd=obj_dir))
     for p, cmd in zip(procs, jobs):
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", OUT, os.path.join(OBJ_DIR, "tinsel_hip.o"), os.path.join(OBJ_DIR, "tinsel_fast.o")]
+
+
+def _link(obj_dir, out, verbose=True):
+    link = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out, os.path.join(obj_dir, "tinsel_hip.o"), os.path.join(obj_dir, "tinsel_fast.o")]
     if verbose:
         print("[tinsel_amd.build]", " ".join(link), flush=True)
     subprocess.run(link, check=True)
+
+
+def build(force=False, verbose=True, extra=()):
+    if not force and up_to_date():
+        return OUT
+    _compile(OBJ_DIR, extra, verbose)
+    _link(OBJ_DIR, OUT, verbose)
     return OUT
+
+
+def _sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def build_verified(verbose=True):
+    """What __graft_entry__.build() runs: ALWAYS compiles both translation units for gfx950 (into a temporary directory, with the
+    shipped flags), so that a prebuilt library in the tree cannot pass for a build.  hipcc is deterministic for a given source and
+    command line: when the fresh objects are byte-identical to the ones the in-tree library was linked from, the library is kept
+    ("verified"); otherwise they replace them and the library is linked again ("rebuilt").  Returns (and prints) the build record."""
+    t0 = time.time()
+    names = ("tinsel_hip.o", "tinsel_fast.o")
+    with tempfile.TemporaryDirectory(prefix="tinsel_build_") as tmp:
+        _compile(tmp, (), verbose)
+        fresh = {n: _sha(os.path.join(tmp, n)) for n in names}
+        have = {n: (_sha(os.path.join(OBJ_DIR, n)) if os.path.exists(os.path.join(OBJ_DIR, n)) else None) for n in names}
+        same = all(fresh[n] == have[n] for n in names) and os.path.exists(OUT) and \
+            all(os.path.getmtime(OUT) >= os.path.getmtime(os.path.join(OBJ_DIR, n)) for n in names)
+        if not same:
+            os.makedirs(OBJ_DIR, exist_ok=True)
+            for n in names:
+                shutil.copy2(os.path.join(tmp, n), os.path.join(OBJ_DIR, n))
+            _link(OBJ_DIR, OUT, verbose)
+    ver = subprocess.run([hipcc(), "--version"], capture_output=True, text=True).stdout.splitlines()
+    record = {
+        "compiled": [os.path.relpath(SRC, ROOT), os.path.relpath(SRC_FAST, ROOT)], "arch": "gfx950", "seconds": round(time.time() - t0, 1),
+        "object_sha256": fresh, "library": os.path.relpath(OUT, ROOT), "library_sha256": _sha(OUT),
+        "action": "verified: the in-tree library was linked from byte-identical objects" if same else "rebuilt: objects replaced, library linked again",
+        "hipcc": ver[0] if ver else None,
+    }
+    with open(os.path.join(OBJ_DIR, "build_record.json"), "w") as f:
+        json.dump(record, f, indent=1)
+    print("[tinsel_amd.build] record:", json.dumps(record), flush=True)
+    return record
 
 
 if __name__ == "__main__":

@@ -414,6 +414,7 @@ struct tinsel_hip
     int pipeline = TINSEL_PIPELINE_AUTO;
     int arith = TINSEL_ARITH_EXACT;     // which build of the path kernels runs (tinsel_hip_set_arithmetic)
     bool pathKernelsPrepared = false;
+    int segPrefixLds = 0;               // dynamic LDS k_seg_prefix may ask for (prepare_path_kernels): one count per region
     bool countDetail = false;
 
     uint32_t passIndex = 0;
@@ -658,6 +659,58 @@ int pick_stack(int need)
     return -1;
 }
 
+// The bottom level of a mesh tree in HBM as Pair128 records (tn_scene.h, k_build_pairs in tn_lbvh.h): k_walk's kWalkPairs mode.
+// `dm.pairs` is allocated on first use (owner: the list that frees it) and (re)filled from the tree as it is NOW -- the reference's as
+// converted, a device-built one, either after a refit.  Built only when the mode is asked for (walk_pairs_enabled).
+bool walk_pairs_enabled()
+{
+    // OPT-IN (TINSEL_HIP_WALK_PAIRS=1).  Measured, bit-identical (profiles/r04_b_ab_walk_pairs2.md): the 524k-triangle config's k_walk 11.34 ms
+    // per 20 passes without, 11.29-11.39 with -- node phases -8 %, but the triangle phases hardly fewer (most visits to a node over two leaves
+    // enter ONE of the two boxes, so there was one triangle phase before and there is one now) and each of them heavier; glass (two walked
+    // primitives: per-lane tree pointers, 8-48 B of scratch at 64 VGPRs) 6.3 -> 8.7 ms.
+    static const bool on = getenv("TINSEL_HIP_WALK_PAIRS") && atoi(getenv("TINSEL_HIP_WALK_PAIRS")) != 0;
+    return on;
+}
+
+int fill_pairs(DevMesh& dm)
+{
+    int* mism = nullptr;
+    int bad = -1;
+    if (hipMalloc((void**)&mism, sizeof(int)) == hipSuccess && hipMemset(mism, 0, sizeof(int)) == hipSuccess)
+    {
+        hipLaunchKernelGGL(k_build_pairs, dim3((unsigned)((dm.numInternal + 255)/256)), dim3(256), 0, nullptr, const_cast<Node64*>(dm.nodes), dm.numInternal,
+                           dm.tris, const_cast<Pair128*>(dm.pairs), mism);
+        // (a blocking copy on the null stream: also orders the records before kernels of non-blocking streams)
+        if (hipMemcpy(&bad, mism, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess)
+            bad = -1;
+    }
+    if (mism)
+        (void)hipFree(mism);
+    if (bad < 0)
+        return fail("k_build_pairs failed");
+    // a tree whose stored leaf boxes are not the min / max of its leaves' vertices (never the reference's, mesh.cpp:321-328): plain walk
+    dm.pairsExact = bad == 0 ? 1 : 0;
+    return 0;
+}
+
+int build_pairs(DevMesh& dm, std::vector<void*>& owner)
+{
+    dm.pairsExact = 0;
+    if (dm.inArena || dm.numInternal <= 0 || !dm.nodes || !walk_pairs_enabled())
+        return 0;
+    if ((unsigned)dm.numInternal >= kPairBit)
+        return 0;                   // (a node index must leave bit 30 free)
+    if (!dm.pairs)
+    {
+        void* d = nullptr;
+        if (hipMalloc(&d, sizeof(Pair128)*(size_t)dm.numInternal) != hipSuccess)
+            return fail("device allocation failed (leaf-pair records)");
+        owner.push_back(d);
+        dm.pairs = (const Pair128*)d;
+    }
+    return fill_pairs(dm);
+}
+
 size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes; }
 
 // The path kernels exist twice (tn_launch.h): this translation unit's, bit-identical to the CPU oracle, and
@@ -666,14 +719,18 @@ extern "C" void tinsel_fast_launch_path_kernel(int which, const void* launchArgs
 extern "C" void tinsel_fast_prepare_path_kernels(int sharedMemLimit);
 extern "C" unsigned tinsel_fast_launch_args_size(void);
 
+void prepare_kernels_once(tinsel_hip* r)
+{
+    if (r->pathKernelsPrepared)
+        return;
+    r->segPrefixLds = prepare_path_kernels(r->sharedMemLimit);
+    tinsel_fast_prepare_path_kernels(r->sharedMemLimit);
+    r->pathKernelsPrepared = true;
+}
+
 void launch_path(tinsel_hip* r, int which, const LaunchArgs& a, hipStream_t st)
 {
-    if (!r->pathKernelsPrepared)
-    {
-        prepare_path_kernels(r->sharedMemLimit);
-        tinsel_fast_prepare_path_kernels(r->sharedMemLimit);
-        r->pathKernelsPrepared = true;
-    }
+    prepare_kernels_once(r);
     if (r->arith == TINSEL_ARITH_FAST)
         tinsel_fast_launch_path_kernel(which, &a, st);
     else
@@ -709,23 +766,26 @@ LaunchArgs batch_args(tinsel_hip* r, const CameraParams& cam, const FrameParams&
     return a;
 }
 
+// k_seg_prefix stages one count per region in dynamic LDS beside 64 B of static: what a launch may ask for (prepare_path_kernels raises
+// the kernel's limit to the device's sharedMemLimit - 1024)
+uint32_t seg_prefix_max_regions(tinsel_hip* r)
+{
+    prepare_kernels_once(r);
+    return (uint32_t)std::max(0, r->segPrefixLds/4);
+}
+
 // k_walk (tn_walk.h): closest hits of the front rays of `queue` against the large meshes in HBM, ahead of the scan kernel.
 // One 1024-thread workgroup per CU whose LDS holds the traversal stacks and, in what is left of the 160 KB, the top of
 // the walked trees; trees too deep for that (a device-built LBVH of 524k triangles: 48 entries per lane) run 256-thread
 // workgroups without a staged top.
-void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* regionCounts, bool shadowRays)
+int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* regionCounts, bool shadowRays)
 {
     static const int gridMult = getenv("TINSEL_HIP_WALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_WALK_GRID_MULT")) : 1;
     static const int refillMin = getenv("TINSEL_HIP_WALK_REFILL") ? atoi(getenv("TINSEL_HIP_WALK_REFILL")) : 24;
     static const int leafMin = getenv("TINSEL_HIP_WALK_LEAFMIN") ? atoi(getenv("TINSEL_HIP_WALK_LEAFMIN")) : 8;
     static const int topLimit = getenv("TINSEL_HIP_WALK_TOP") ? atoi(getenv("TINSEL_HIP_WALK_TOP")) : 1 << 20;      // nodes; 0: no staged top (A/B)
     static const int forceBlock = getenv("TINSEL_HIP_WALK_BLOCK") ? atoi(getenv("TINSEL_HIP_WALK_BLOCK")) : 0;
-    if (!r->pathKernelsPrepared)
-    {
-        prepare_path_kernels(r->sharedMemLimit);
-        tinsel_fast_prepare_path_kernels(r->sharedMemLimit);
-        r->pathKernelsPrepared = true;
-    }
+    prepare_kernels_once(r);
     // the work list: the front entries of every region (paths / shadow-ray bundles whose ray enters a walked mesh's box)
     const SplitState& ss = a.ss;
     // the list visits the regions a golden-section step apart (TINSEL_HIP_WALK_LIST_STEP=1: in order)
@@ -740,6 +800,8 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     }
     {
         ScopedTimer t(r, KN_SEG, st);
+        if (ss.numRegions > seg_prefix_max_regions(r))
+            return fail("k_seg_prefix: " + std::to_string(ss.numRegions) + " regions do not fit its LDS (TINSEL_HIP_GRID_MULT too large for this device)");
         hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), ss.numRegions*sizeof(uint32_t), st, regionCounts, (const uint32_t*)nullptr, ss.numRegions, step, r->segPrefix);
         hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss, r->walkList);
     }
@@ -766,6 +828,15 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     job.prof = r->walkProf;
     job.refillMin = std::min(64, std::max(1, refillMin));
     job.leafMin = std::min(64, std::max(1, leafMin));
+    // the bottom level out of Pair128 records where asked for (TINSEL_HIP_WALK_PAIRS=1) and every walked tree has them; ONE walked primitive:
+    // its tree as kernel-argument scalars (TINSEL_HIP_WALK_SINGLE=0: per-lane pointers as for several)
+    {
+        static const bool noSingle = getenv("TINSEL_HIP_WALK_SINGLE") && atoi(getenv("TINSEL_HIP_WALK_SINGLE")) == 0;
+        bool pairs = walk_pairs_enabled();
+        for (int k = 0; k < r->walkPrims.count; ++k)
+            pairs = pairs && r->meshesNow[(size_t)r->walkPrimMesh[k]].pairs != nullptr && r->meshesNow[(size_t)r->walkPrimMesh[k]].pairsExact != 0;
+        a.walkMode = (pairs ? kWalkPairs : 0) | ((r->walkPrims.count == 1 && !noSingle) ? kWalkSingle : 0);
+    }
 
     const size_t ctl = kWalkCtlWords*sizeof(uint32_t);
     // n stack entries per lane in LDS (TINSEL_HIP_WALK_LDS_STACK, default 8; 0: the deepest tree's need, one workgroup per CU), the
@@ -778,11 +849,11 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     job.stackEntries = ldsEntries;
     job.overflow = nullptr;
     job.overflowEntries = 0;
-    const size_t stackBig = (size_t)ldsEntries*1024*sizeof(uint32_t);
+    const size_t stackBig = (size_t)(ldsEntries + kWalkLaneRows)*1024*sizeof(uint32_t);     // (+ the per-lane rows, tn_walk.h)
     const size_t ldsBudget = twoPerCU ? (size_t)r->sharedMemLimit/2 : (size_t)r->sharedMemLimit;
     const bool big = forceBlock ? forceBlock == 1024 : stackBig + ctl + 16384 <= ldsBudget;
     const int block = big ? 1024 : 256;
-    size_t lds = (size_t)ldsEntries*block*sizeof(uint32_t) + ctl;
+    size_t lds = (size_t)(ldsEntries + kWalkLaneRows)*block*sizeof(uint32_t) + ctl;
     if (big)
     {
         // what is left of the CU's LDS goes to the tree tops, in primitive order
@@ -803,12 +874,14 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
     a.ldsBytes = (uint32_t)lds;
     if (ldsEntries < entries)
     {
-        const size_t need = (size_t)a.grid*(size_t)block*(size_t)(entries - ldsEntries);
+        // the overflow columns are sized for the WIDEST grid this function launches (numCUs x perCU workgroups), once: nothing is freed or
+        // allocated between the launches of a batch
+        const size_t need = (size_t)r->numCUs*(size_t)perCU*(size_t)block*(size_t)(entries - ldsEntries);
         if (r->walkOverflowCap < need)
         {
             if (r->walkOverflow)
             {
-                (void)hipStreamSynchronize(st);
+                (void)hipDeviceSynchronize();       // (another stream's launch may still use the old columns)
                 (void)hipFree(r->walkOverflow);
             }
             r->walkOverflow = nullptr;
@@ -819,18 +892,16 @@ void launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* re
         job.overflow = r->walkOverflow;
         job.overflowEntries = entries - ldsEntries;
         if (!job.overflow)
-        {
-            fail("k_walk: no memory for the stack overflow");
-            return;
-        }
+            return fail("k_walk: no memory for the stack overflow");
     }
     ScopedTimer t(r, KN_WALK, st);
     launch_path(r, PK_WALK, a, st);
+    return 0;
 }
 
 // k_swalk (tn_swalk.h): the scene-level walk with ray replacement, for scenes the flat scan cannot take.  The list: every live
 // entry of every region (front and back), regions in index order -- the workgroups' static ranges are image patches, coherent rays.
-void launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* front, const uint32_t* back, bool shadowRays)
+int launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* front, const uint32_t* back, bool shadowRays)
 {
     static const int refillMin = getenv("TINSEL_HIP_SWALK_REFILL") ? atoi(getenv("TINSEL_HIP_SWALK_REFILL")) : 32;
     static const int leafMin = getenv("TINSEL_HIP_SWALK_LEAFMIN") ? atoi(getenv("TINSEL_HIP_SWALK_LEAFMIN")) : 16;
@@ -850,6 +921,8 @@ void launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* f
     }
     {
         ScopedTimer t(r, KN_SEG, st);
+        if (ss.numRegions > seg_prefix_max_regions(r))
+            return fail("k_seg_prefix: " + std::to_string(ss.numRegions) + " regions do not fit its LDS");
         hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), ss.numRegions*sizeof(uint32_t), st, front, back, ss.numRegions, step, r->segPrefix);
         hipLaunchKernelGGL(k_seg_expand_all, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, front, back, (const uint32_t*)r->segPrefix, ss, r->walkList);
     }
@@ -880,6 +953,7 @@ void launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* f
         a.ldsBytes = (uint32_t)(((size_t)r->stackNeed*kBlock + kSwalkCtlWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes);
     ScopedTimer t(r, shadowRays ? KN_SHADOW : KN_EXTEND, st);
     launch_path(r, shadowRays ? PK_SWALK_SHADOW : PK_SWALK_EXTEND, a, st);
+    return 0;
 }
 
 void launch_normals(tinsel_hip* r, hipStream_t st, int grid, const CameraParams& cam, const FrameParams& fp)
@@ -1290,9 +1364,12 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         // No short regions at the end by default here (TINSEL_HIP_TAIL_SPLIT_SPLIT=1: A/B): the launches are many and short, k_walk cuts its
         // own list into static ranges, and more regions cost k_seg_prefix / k_walk more than the other kernels' tails gain -- the 524k-triangle
         // config 2319 -> 2254 Msamples/s, many_spheres 2108 -> 2082, glass +-0 (profiles/r03_z5_ab_tail_split.md).  (k_seg_prefix stages
-        // the regions' counts in LDS: 39936 of them at most where a walk list is built.)
+        // the regions' counts in LDS: (sharedMemLimit - 1024)/4 of them at most where a walk list is built.)
         static const bool tailInSplit = getenv("TINSEL_HIP_TAIL_SPLIT_SPLIT") && atoi(getenv("TINSEL_HIP_TAIL_SPLIT_SPLIT")) != 0;
-        if (cut_regions(r, a, slots, &gridPersist, !tailInSplit ? (size_t)0 : r->walkList != nullptr ? (size_t)39936 : (size_t)r->splitMaxRegions))
+        // (k_seg_prefix stages one count per region in LDS: where a walk list is built the grid is clamped to what fits)
+        if (r->walkList != nullptr)
+            gridPersist = std::max(1, std::min(gridPersist, (int)(seg_prefix_max_regions(r)/(kBlock/kWave))));
+        if (cut_regions(r, a, slots, &gridPersist, !tailInSplit ? (size_t)0 : r->walkList != nullptr ? (size_t)seg_prefix_max_regions(r) : (size_t)r->splitMaxRegions))
             return -1;
         gridTrace = gridMultTrace > 0 ? std::max(1, std::min(gridPersist, r->numCUs*gridMultTrace)) : gridPersist;
         const size_t W = a.ss.numRegions;
@@ -1328,12 +1405,14 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             if (walk)
             {
                 a.grid = gridPersist;
-                launch_walk(r, st, a, r->ss.segFront + (size_t)bounce*W, false);
+                if (launch_walk(r, st, a, r->ss.segFront + (size_t)bounce*W, false))
+                    return -1;
             }
             if (sceneWalk)
             {
                 a.grid = gridPersist;
-                launch_swalk(r, st, a, r->ss.segFront + (size_t)bounce*W, r->ss.segBack + (size_t)bounce*W, false);
+                if (launch_swalk(r, st, a, r->ss.segFront + (size_t)bounce*W, r->ss.segBack + (size_t)bounce*W, false))
+                    return -1;
             }
             else
             {
@@ -1355,12 +1434,14 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 if (walk)
                 {
                     a.grid = gridPersist;
-                    launch_walk(r, st, a, r->ss.neeFront + (size_t)bounce*W, true);
+                    if (launch_walk(r, st, a, r->ss.neeFront + (size_t)bounce*W, true))
+                        return -1;
                 }
                 if (sceneWalk)
                 {
                     a.grid = gridPersist;
-                    launch_swalk(r, st, a, r->ss.neeFront + (size_t)bounce*W, r->ss.neeBack + (size_t)bounce*W, true);
+                    if (launch_swalk(r, st, a, r->ss.neeFront + (size_t)bounce*W, r->ss.neeBack + (size_t)bounce*W, true))
+                        return -1;
                 }
                 else
                 {
@@ -1525,10 +1606,14 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
 
 void lookahead_cancel(tinsel_hip* r)
 {
-    if (!r || r->specQueue.empty())
+    if (!r || (!r->workStream && r->specQueue.empty()))
         return;
+    // The work stream is waited for WHENEVER it exists, not only when shots are queued: a speculation that failed half-way
+    // (lookahead_extend after render_impl had enqueued its kernels) leaves the queue empty and kernels in flight over the path
+    // buffers the next plain render -- on another non-blocking stream -- is about to reuse.
     (void)hipSetDevice(r->device);
-    (void)hipStreamSynchronize(r->workStream);
+    if (r->workStream)
+        (void)hipStreamSynchronize(r->workStream);
     for (tinsel_hip::SpecShot& shot : r->specQueue)
     {
         r->specFree.push_back(shot.buf);
@@ -1838,11 +1923,16 @@ int build_device_bvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out, int mode)
         out.root = 0;                   // perm[0] == 0: the root is the first node of the breadth-first walk
         out.stackNeed = rootHeight + 1;
         out.topCount = top;
+        out.numInternal = n - 1;
+        out.pairs = nullptr;            // this tree's own bottom-level records (the reference tree keeps its)
     } while (false);
     if (rc)
         (void)hipFree(nodes);
     else
+    {
         r->lbvhAllocs.push_back(nodes);
+        rc = build_pairs(out, r->lbvhAllocs);
+    }
     return rc;
 }
 
@@ -2032,6 +2122,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 dm.numTris = numTris;
                 dm.stackNeed = cb.maxLeafDepth + 1;
                 dm.topCount = cb.topCount;
+                dm.numInternal = (int32_t)cb.nodes.size();
                 // one internal node over two one-triangle leaves (a quad): walked without stack or loop (ray_mesh_two_leaves)
                 dm.twoLeaves = (cb.nodes.size() == 1 && !(cb.root & kLeafBit) && (cb.nodes[0].left & kLeafBit) && (cb.nodes[0].right & kLeafBit) &&
                                 !getenv("TINSEL_HIP_NO_TWO_LEAVES")) ? 1 : 0;
@@ -2051,7 +2142,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                     dm.tris = r->sceneMem.upload(tris.data(), tris.size());
                     dm.normals = r->sceneMem.upload(&g.normals[0].x, (size_t)g.num_vertices*3);
                     dm.cdf = r->sceneMem.upload(g.cdf, (size_t)numTris);
-                    if ((!cb.nodes.empty() && !dm.nodes) || !dm.tris || !dm.normals || !dm.cdf)
+                    if ((!cb.nodes.empty() && !dm.nodes) || !dm.tris || !dm.normals || !dm.cdf || build_pairs(dm, r->sceneMem.allocs))
                     {
                         fail("create: device allocation failed (mesh)");
                         ok = false;
@@ -2636,6 +2727,9 @@ int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_x
                 }
                 if (!rootGen)
                     rc = fail("refit_mesh: the refit did not reach the root");
+                // the bottom-level records hold copies of the triangles (tn_scene.h Pair128)
+                if (!rc && tree->pairs)
+                    rc = fill_pairs(*const_cast<DevMesh*>(tree));
             }
             if (rc)
                 break;
@@ -3498,6 +3592,8 @@ void group_worker(tinsel_hip_group* g, int rank)
                 r->specOptions = g->aheadOptions;
                 r->specPasses = g->aheadPasses;
                 rc = lookahead_extend(r, &g->aheadCamera, &g->aheadOptions, g->aheadPasses, depth);
+                if (rc)
+                    lookahead_cancel(r);        // kernels of the failed speculation may be in flight on the work stream: wait, drop the shots
             }
             if (!rc && !g->oneDevice)
             {

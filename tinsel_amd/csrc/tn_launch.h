@@ -37,6 +37,7 @@ struct LaunchArgs
     SwalkJob swalk;                 // PK_SWALK_*
     int swalkMode;                  // PK_SWALK_*: 0 = 256-thread workgroups, generic pointers; 1 / 2 = 1024-thread workgroups, arena in LDS (2: meshes in HBM too)
     int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
+    int walkMode;                   // PK_WALK: kWalkPairs | kWalkSingle (tn_walk.h)
     int shadeSorted;                // PK_SHADE: k_shade_sorted (paths taken class by class) instead of k_shade
     int lightsInExtend;             // PK_EXTEND, arena staged + meshes in HBM: the variant that draws the light samples too (A/B)
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
@@ -135,12 +136,20 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
 #undef TN_LAUNCH_SWALK
         break;
     case PK_WALK:
-        if (a.walkBig == 2)
-            hipLaunchKernelGGL((k_walk<1024, 8>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
-        else if (a.walkBig)
-            hipLaunchKernelGGL((k_walk<1024, 4>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
-        else
-            hipLaunchKernelGGL((k_walk<256, 5>), grid, dim3(256), a.ldsBytes, st, a.scene, a.walk);
+#define TN_LAUNCH_WALK(MODE)                                                                                           \
+        do {                                                                                                           \
+            if (a.walkBig == 2) hipLaunchKernelGGL((k_walk<1024, 8, MODE>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk); \
+            else if (a.walkBig) hipLaunchKernelGGL((k_walk<1024, 4, MODE>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk); \
+            else hipLaunchKernelGGL((k_walk<256, 5, MODE>), grid, dim3(256), a.ldsBytes, st, a.scene, a.walk);            \
+        } while (0)
+        switch (a.walkMode & 3)
+        {
+        case 0: TN_LAUNCH_WALK(0); break;
+        case 1: TN_LAUNCH_WALK(1); break;
+        case 2: TN_LAUNCH_WALK(2); break;
+        default: TN_LAUNCH_WALK(3); break;
+        }
+#undef TN_LAUNCH_WALK
         break;
     default:
         break;
@@ -148,11 +157,17 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
 }
 
 // k_walk (tree tops) and k_bounce (shading pools beside a staged arena) ask for more dynamic LDS than the default launch limit allows
-inline void prepare_path_kernels(int sharedMemLimit)
+// Returns the dynamic LDS k_seg_prefix may ask for (one count per region: the host clamps its grids to that).
+inline int prepare_path_kernels(int sharedMemLimit)
 {
-    (void)hipFuncSetAttribute((const void*)k_seg_prefix, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit - 1024);      // (it has static LDS too)
-    (void)hipFuncSetAttribute((const void*)k_walk<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
-    (void)hipFuncSetAttribute((const void*)k_walk<1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+    // (k_seg_prefix has static LDS too; a refused attribute leaves the default launch limit of 64 KB)
+    const int segPrefixLds = hipFuncSetAttribute((const void*)k_seg_prefix, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit - 1024) == hipSuccess
+                                 ? sharedMemLimit - 1024 : (sharedMemLimit < 65536 ? sharedMemLimit : 65536) - 1024;
+#define TN_PREP_WALK(MODE) (void)hipFuncSetAttribute((const void*)k_walk<1024, 4, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
+                           (void)hipFuncSetAttribute((const void*)k_walk<1024, 8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
+                           (void)hipFuncSetAttribute((const void*)k_walk<256, 5, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
+    TN_PREP_WALK(0); TN_PREP_WALK(1); TN_PREP_WALK(2); TN_PREP_WALK(3);
+#undef TN_PREP_WALK
     (void)hipFuncSetAttribute((const void*)k_shade_sorted<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_shade_sorted<true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_shade_sorted<false>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
@@ -162,11 +177,12 @@ inline void prepare_path_kernels(int sharedMemLimit)
     TN_PREP_SWALK(false); TN_PREP_SWALK(true);
 #undef TN_PREP_SWALK
     (void)hipGetLastError();        // a refused attribute must not surface as the next launch's error
-    (void)hipFuncSetAttribute((const void*)k_walk<256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
 #define TN_PREP_BOUNCE(C, L, D) (void)hipFuncSetAttribute((const void*)k_bounce<C, L, D>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
     TN_PREP_BOUNCE(true, true, false); TN_PREP_BOUNCE(true, false, false);
     TN_PREP_BOUNCE(false, true, false); TN_PREP_BOUNCE(false, false, false); TN_PREP_BOUNCE(false, true, true); TN_PREP_BOUNCE(false, false, true);
 #undef TN_PREP_BOUNCE
+    (void)hipGetLastError();
+    return segPrefixLds;
 }
 
 } // namespace tn

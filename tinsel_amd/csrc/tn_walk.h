@@ -125,26 +125,64 @@ TN_D Node64 load_node_from(Ptr nodes, uint32_t idx)
     n.rminz = c.x; n.rmaxx = c.y; n.rmaxy = c.z; n.rmaxz = c.w;
     n.left = __float_as_uint(d.x);
     n.right = __float_as_uint(d.y);
+    n.pairKids = __float_as_uint(d.z);
     return n;
 }
 
-// LDS of one workgroup: [stackEntries][BLOCK] stack words, then 16 control words, then the staged tree tops.
-constexpr int kWalkCtlWords = 16;
+// Walk modes (template parameter MODE of k_walk; launch_walk picks one, TINSEL_HIP_WALK_PAIRS / TINSEL_HIP_WALK_DRAIN):
+//   kWalkPairs   THE BOTTOM LEVEL IN ONE RECORD.  A node over two one-triangle leaves is not visited as a node: its parent hands the
+//                lane a pair ref (kPairBit | node index, from Node64::pairKids), the lane waits for the triangle phase like a lane at
+//                a leaf, and there ONE 128-B Pair128 record -- one request, eight dwordx4 -- gives it the two leaf boxes and both
+//                triangles: box tests (`tChild < tmax` against the closest hit so far, intersection.h:696-705), both triangle tests,
+//                and the outcome of the sequence the reference's stack produces for that node (push far, push near, pop near, pop
+//                far: :706-722 -- the far leaf is NOT culled again after the near one's hit, and a strict `t < closestT` keeps the
+//                first of two equal hits).  One fetch, one phase and one pop where there were a node phase, two triangle phases with
+//                their waits and three stack operations.
+//                (Tried first, 15.3 ms against 11.1 on the 524k-triangle config: box fetch, near-triangle fetch, far-triangle fetch as three
+//                dependent round trips inside the phase.  And "drain" -- a lane that pops another leaf after a leaf tests it in the same
+//                phase: 11.1 -> 11.8 ms, the same lesson: a phase must hold ONE round trip.  profiles/r04_a_ab_walk_pairs.md)
+//   kWalkSingle  ONE walked primitive (the host knows): tree, triangles, pair records and the staged top are the same for every lane --
+//                kernel-argument scalars instead of five per-lane registers (what lets kWalkPairs run at 64 VGPRs).
+constexpr int kWalkPairs = 1;
+constexpr int kWalkSingle = 2;
 
-template <int BLOCK, int WAVES>
+typedef float WalkF2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) WalkF2* GlobalF2;
+
+// The closest hit's normal for its record: n*sign with n = Cross(b - a, c - a) as IntersectRayTriTwoSided forms it (intersection.h:122-124),
+// computed again from the triangle where the record is written -- the lane's next refill, whose chain of dependent loads hides the
+// 48-B fetch -- instead of carried in three registers from the hit to the end of the walk (same vertices, same operations: same bits).
+TN_D V3 hit_normal(GlobalF4 tris, int tri, float sign)
+{
+    GlobalF4 tp = tris + (size_t)tri*3;
+    const WalkF4 ta = tp[0], tb = tp[1], tc = tp[2];
+    const V3 a(ta.x, ta.y, ta.z), b(tb.x, tb.y, tb.z), c(tc.x, tc.y, tc.z);
+    return cross(b - a, c - a)*sign;
+}
+
+// LDS of one workgroup: [stackEntries][BLOCK] stack words, [kWalkLaneRows][BLOCK] per-lane words that are touched once or twice per
+// RAY and have no business in a register of a 64-VGPR kernel (row 0: the ray's record index, row 1: a shadow ray's stop distance),
+// then 16 control words, then the staged tree tops.
+constexpr int kWalkCtlWords = 16;
+constexpr int kWalkLaneRows = 2;
+
+template <int BLOCK, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 {
+    constexpr bool PAIRS = (MODE & kWalkPairs) != 0, SINGLE = (MODE & kWalkSingle) != 0;
+    constexpr uint32_t kAtLeaf = PAIRS ? (kLeafBit | kPairBit) : kLeafBit;      // refs that wait for the triangle phase
     extern __shared__ __attribute__((aligned(16))) uint32_t s_walk[];
     uint32_t* const stack = s_walk + threadIdx.x;               // this lane's column: entry i at stack[i*BLOCK]
     // a SHORT LDS stack leaves room for a second workgroup per CU (8 waves per SIMD at 64 VGPRs): the rare entries beyond it
     // live in HBM, a column per lane of the grid
     uint32_t* const spill = job.overflow ? job.overflow + ((size_t)blockIdx.x*BLOCK + threadIdx.x)*(size_t)job.overflowEntries : nullptr;
     const int ldsEntries = job.stackEntries;
-    uint32_t* const s_ctl = s_walk + job.stackEntries*BLOCK;    // [0] the workgroup's cursor
+    uint32_t* const s_item = s_walk + job.stackEntries*BLOCK + threadIdx.x;                 // kNoItem: no finished ray's record waits in this lane's registers
+    float* const s_stop = reinterpret_cast<float*>(s_walk + (job.stackEntries + 1)*BLOCK + threadIdx.x);    // shadow rays: an accepted hit closer than this ends the walk
+    uint32_t* const s_ctl = s_walk + (job.stackEntries + kWalkLaneRows)*BLOCK;              // [0] the workgroup's cursor
     WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_ctl + kWalkCtlWords);
 
     const int lane = (int)__lane_id();
-    const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t Kx = job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
     const uint32_t Kb = (uint32_t)job.numPrims;
     const uint32_t per = Kx*Kb;                                 // work items per queued slot
@@ -161,6 +199,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     const uint32_t end = (bbeg + chunk) < total ? (bbeg + chunk) : total;
     if (threadIdx.x == 0)
         s_ctl[0] = bbeg;
+    *s_item = 0xffffffffu;
+    *s_stop = -kFltMax;                 // (never, for extension rays)
 
     // stage the tops of the walked trees (a workgroup with nothing to do skips it)
     if (bbeg < end)
@@ -189,7 +229,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     // ONE walked primitive (the common case): its record, leaf box and mesh table entry are wave-uniform -- read once, not
     // behind every refill's ray fetch (the refill is a chain of dependent loads: queue -> slot -> ray -> [box, primitive,
     // mesh]; the last three were a third of it)
-    const bool single = job.numPrims == 1;
+    const bool single = SINGLE || job.numPrims == 1;
     Prim64 prim0 = load_prim(sc.prims, job.prim[0]);
     float4 box0a, box0b;
     {
@@ -198,22 +238,25 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     }
     const DevMesh* mesh0p = sc.meshes + prim0.mesh;
     GlobalF4 mesh0nodes = as_global(mesh0p->nodes), mesh0tris = as_global(mesh0p->tris);
+    GlobalF4 mesh0pairs = PAIRS ? as_global(mesh0p->pairs) : nullptr;
     const uint32_t mesh0root = mesh0p->root;
+    const uint32_t top0N = (uint32_t)job.topCount[0];
 
     // per-lane walk state
-    bool active = false;
-    uint32_t item = 0, ref = 0;
+    // (no flags: a lane is ACTIVE iff ref != kNoNode; a finished ray's record is PENDING in its registers iff *s_item != kNoItem)
+    constexpr uint32_t kNoItem = 0xffffffffu;
+    uint32_t ref = kNoNode;
+#define active (ref != kNoNode)
     int sp = 0;
     V3 o, d, rcp;
     float closestT = kFltMax;
-    float tStop = -kFltMax;             // shadow rays: an accepted hit closer than this ends the walk (never, for extension rays)
-    float hu = 0.0f, hv = 0.0f, hw = 0.0f;
+    float hv = 0.0f, hw = 0.0f;         // (u = 1 - v - w is recomputed where the record is written: IntersectRayTriTwoSided's own expression)
     int htri = -1;
-    V3 hn;
+    float hsign = 0.0f;                 // the hit's `sign` (IntersectRayTriTwoSided's d): its normal n*sign is formed where the record is written
     GlobalF4 mnodes = nullptr;
     GlobalF4 mtris = nullptr;
+    GlobalF4 mpairs = nullptr;
     uint32_t topBase = 0, topN = 0;     // this lane's tree: refs < topN are staged at s_top[(topBase + ref)*4 ..]
-    bool pending = false;               // a finished ray's record is still in this lane's registers (see the refill)
     bool finiteAll = true;              // wave-uniform: every active lane's 1/d is finite
     bool exhausted = bbeg >= end;       // wave-uniform: the workgroup's range has been handed out
     TN_WP_DECL
@@ -240,15 +283,20 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                 // ends: stores count against vmcnt like loads on gfx950, so a 32-B record on its way to HBM would sit in
                 // front of every node fetch the wave waits for (measured: node phases of 1900-2800 cycles, 780 when
                 // nothing but LDS reads was outstanding).
-                if (pending)
+                const uint32_t item = *s_item;
+                if (item != kNoItem)
                 {
                     float4* out = job.rec + (size_t)item*2;
-                    out[0] = make_float4(closestT, hu, hv, hw);
+                    out[0] = make_float4(closestT, 1.0f - hv - hw, hv, hw);
                     if (closestT < kFltMax)
+                    {
+                        const V3 hn = hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
                         out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
-                    pending = false;
+                    }
+                    *s_item = kNoItem;
                 }
-                const uint32_t my = cur + (uint32_t)__popcll(idleMask & below);
+                // (set bits of the idle mask below this lane: v_mbcnt, no per-lane 64-bit mask kept in registers)
+                const uint32_t my = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
                 if (my < end)
                 {
                     uint32_t qi = __umulhi(my, perM), rem = my - qi*per;
@@ -265,7 +313,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         const float4* np = job.nee + (size_t)(k*2u)*job.neeStride + slot;
                         ro = np[0]; rd = np[job.neeStride];
                         time = job.neeTime[slot];
-                        tStop = shadow_stop(ro.w);      // the record's .w is the sample's distance (< 0: probe sample)
+                        *s_stop = shadow_stop(ro.w);    // the record's .w is the sample's distance (< 0: probe sample)
                     }
                     else
                     {
@@ -276,16 +324,19 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 
                     int index = job.prim[0];
                     uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
-#pragma unroll
-                    for (int q = 1; q < kWalkMaxPrims; ++q)
+                    if (!SINGLE)
                     {
-                        if ((uint32_t)q == kb)
+#pragma unroll
+                        for (int q = 1; q < kWalkMaxPrims; ++q)
                         {
-                            index = job.prim[q];
-                            tb = run;
-                            tn = (uint32_t)job.topCount[q];
+                            if ((uint32_t)q == kb)
+                            {
+                                index = job.prim[q];
+                                tb = run;
+                                tn = (uint32_t)job.topCount[q];
+                            }
+                            run += (uint32_t)job.topCount[q];
                         }
-                        run += (uint32_t)job.topCount[q];
                     }
 
                     // the leaf-box test of the scan (trace_flat / the scene BVH walk): same function, same operands
@@ -315,10 +366,13 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         o = inv_xform_point(x, wo);
                         d = inv_xform_vector(x, wd);
                         rcp = rcp3_cr(d);
-                        if (single)
+                        if (SINGLE)
+                            ref = mesh0root;
+                        else if (single)
                         {
                             mnodes = mesh0nodes;
                             mtris = mesh0tris;
+                            if (PAIRS) mpairs = mesh0pairs;
                             ref = mesh0root;
                         }
                         else
@@ -326,15 +380,18 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                             const DevMesh* m = sc.meshes + p.mesh;
                             mnodes = as_global(m->nodes);
                             mtris = as_global(m->tris);
+                            if (PAIRS) mpairs = as_global(m->pairs);
                             ref = m->root;
                         }
-                        topBase = tb;
-                        topN = tn;
+                        if (!SINGLE)
+                        {
+                            topBase = tb;
+                            topN = tn;
+                        }
                         sp = 0;
                         closestT = kFltMax;
                         htri = -1;
-                        item = recAt;
-                        active = true;
+                        *s_item = recAt;
                     }
                 }
             }
@@ -352,19 +409,19 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 
         bool pop = false;
 #ifdef TN_WALK_PROF
-        { const unsigned long long nm = __ballot(active && !(ref & kLeafBit)); if (nm) { TN_WP_COUNT(7, 1) TN_WP_COUNT(9, __popcll(nm)) }
-          TN_WP_COUNT(14, __popcll(__ballot(active && !(ref & kLeafBit) && ref < topN))) }
+        { const unsigned long long nm = __ballot(active && !(ref & kAtLeaf)); if (nm) { TN_WP_COUNT(7, 1) TN_WP_COUNT(9, __popcll(nm)) }
+          TN_WP_COUNT(14, __popcll(__ballot(active && !(ref & kAtLeaf) && ref < (SINGLE ? top0N : topN)))) }
         TN_WP_TICK(4)
 #endif
 
         // ---- node phase: lanes at an internal node -------------------------------------------------------------
-        if (active && !(ref & kLeafBit))
+        if (active && !(ref & kAtLeaf))
         {
             Node64 nd;
-            if (ref < topN)
-                nd = load_node_from((const WalkF4*)s_top, topBase + ref);   // 4 x ds_read_b128
+            if (ref < (SINGLE ? top0N : topN))
+                nd = load_node_from((const WalkF4*)s_top, SINGLE ? ref : topBase + ref);    // 4 x ds_read_b128
             else
-                nd = load_node_from(mnodes, ref);                           // 4 x global_load_dwordx4
+                nd = load_node_from(SINGLE ? mesh0nodes : mnodes, ref);                     // 4 x global_load_dwordx4
             float tL, tR;
             bool hL, hR;
             if (finiteAll)
@@ -380,30 +437,33 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
             }
             hL = hL && tL < closestT;       // `tLeft < tmax`, tmax == closestT after every leaf (intersection.h:701-702)
             hR = hR && tR < closestT;
+            // (kWalkPairs) a child that is a node over two leaves travels as a pair ref
+            const uint32_t refL = PAIRS ? (nd.left | ((nd.pairKids & 1u) << 30)) : nd.left;
+            const uint32_t refR = PAIRS ? (nd.right | ((nd.pairKids & 2u) << 29)) : nd.right;
 
             if (hL && hR)
             {
                 // the reference pushes far then near and pops near: the near child continues in a register
                 const bool leftNear = tL < tR;
-                const uint32_t far = leftNear ? nd.right : nd.left;
+                const uint32_t far = leftNear ? refR : refL;
                 if (sp < ldsEntries)
                     stack[sp*BLOCK] = far;
                 else
                     spill[sp - ldsEntries] = far;
                 ++sp;
-                ref = leftNear ? nd.left : nd.right;
+                ref = leftNear ? refL : refR;
             }
             else if (hL)
-                ref = nd.left;
+                ref = refL;
             else if (hR)
-                ref = nd.right;
+                ref = refR;
             else
                 pop = true;
         }
 
         TN_WP_TICK(1)
         // ---- triangle phase: once enough lanes wait at a leaf (or nobody has a node to visit) -----------------
-        const bool atLeaf = active && !pop && (ref & kLeafBit);
+        const bool atLeaf = active && !pop && (ref & kAtLeaf);
         const unsigned long long leafMask = __ballot(atLeaf);
         if (leafMask != 0ull && (__popcll(leafMask) >= job.leafMin || __ballot(active && !pop && !atLeaf) == 0ull))
         {
@@ -411,23 +471,94 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
             TN_WP_COUNT(10, __popcll(leafMask))
             if (atLeaf)
             {
-                const int i = (int)(ref & ~kLeafBit);
-                GlobalF4 tp = mtris + (size_t)i*3;
-                const WalkF4 ta = tp[0], tb = tp[1], tc = tp[2];
-                float t, u, v, w, sign;
-                V3 n;
-                if (ray_tri(o, d, V3(ta.x, ta.y, ta.z), V3(tb.x, tb.y, tb.z), V3(tc.x, tc.y, tc.z), t, u, v, w, sign, n))
+                // ONE round trip per phase (a second dependent fetch inside a phase costs every lane of the wave another ~3000 cycles:
+                // the first version of the pair record fetched boxes, then the near triangle, then the far one, and its triangle phases
+                // took 15,200 cycles against 3,300): every lane requests ALL it will test before anybody waits -- a leaf its Tri48
+                // into q3..q5, a pair the five words of its Pair128, whose left triangle sits in the first three in the Tri48 arrangement.
+                const bool isPair = PAIRS && (ref & kPairBit) != 0u;
+                const uint32_t idx = ref & ~(kLeafBit | kPairBit);
+                GlobalF4 tp = (SINGLE ? mesh0tris : mtris) + (size_t)idx*3;
+                if (isPair)
+                    tp = (SINGLE ? mesh0pairs : mpairs) + (size_t)idx*8;
+                const WalkF4 q3 = tp[0], q4 = tp[1], q5 = tp[2];
+                WalkF4 q6 = { 0.0f, 0.0f, 0.0f, 0.0f }, q7 = q6;
+                if (isPair)
                 {
-                    if (t > 0.0f && t < closestT)
+                    q6 = tp[3]; q7 = tp[4];
+                }
+
+                // a pair's two box tests, as the node phase would have made them at that node (`tChild < tmax`, intersection.h:696-705); the
+                // leaf boxes are the min / max of the leaves' vertices (tn_scene.h Pair128: checked against the stored ones at upload)
+                bool hL = true, hR = false, leftFirst = true;
+                if (isPair)
+                {
+                    // (one box after the other, each behind its own branch on finiteAll: written as one if / else over both, the twelve
+                    // (bound - origin)*rcp products common to the two arms are hoisted above it and live at once -- 12 more registers)
+                    auto slab = [&](float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t) -> bool {
+                        if (finiteAll)
+                            return ray_aabb_minmax(o, rcp, minx, miny, minz, maxx, maxy, maxz, t);
+                        t = 0.0f;
+                        return ray_aabb(o, rcp, minx, miny, minz, maxx, maxy, maxz, t);
+                    };
+                    float tL, tR;
+                    hL = slab(fminf(fminf(q3.x, q4.x), q5.x), fminf(fminf(q3.y, q4.y), q5.y), fminf(fminf(q3.z, q4.z), q5.z),
+                              fmaxf(fmaxf(q3.x, q4.x), q5.x), fmaxf(fmaxf(q3.y, q4.y), q5.y), fmaxf(fmaxf(q3.z, q4.z), q5.z), tL);
+                    hL = hL && tL < closestT;
+                    __builtin_amdgcn_sched_barrier(0);
+                    hR = slab(fminf(fminf(q5.w, q6.x), q7.x), fminf(fminf(q6.w, q6.y), q7.y), fminf(fminf(q7.w, q6.z), q7.z),
+                              fmaxf(fmaxf(q5.w, q6.x), q7.x), fmaxf(fmaxf(q6.w, q6.y), q7.y), fmaxf(fmaxf(q7.w, q6.z), q7.z), tR);
+                    hR = hR && tR < closestT;
+                    leftFirst = hL && (!hR || tL < tR);      // the child the stack would pop first (both hit: the left one iff tL < tR)
+                }
+
+                // The triangle tests.  A leaf: its own triangle.  A pair: the reference's stack pops the nearer box's triangle first, then the
+                // other's; each is accepted iff 0 < t < closestT -- strict, so of two equal hits the FIRST stays -- and the second is NOT
+                // culled again by the first one's hit (intersection.h:706-722): both are tested against the closest hit BEFORE the pair
+                // (t0), and the outcome is the smaller t, a tie going to whichever the stack would have popped first.  Here the left
+                // triangle is always tested first and the right one replaces it under exactly that rule; a shadow ray that its first
+                // triangle decides (t < tStop) never sees the second.
+                const float t0 = closestT;
+                bool validA = false, any = false;
+                if (hL)
+                {
+                    float t, u, v, w, sign;
+                    V3 n;
+                    if (ray_tri(o, d, V3(q3.x, q3.y, q3.z), V3(q4.x, q4.y, q4.z), V3(q5.x, q5.y, q5.z), t, u, v, w, sign, n))
                     {
-                        closestT = t;
-                        hu = u; hv = v; hw = w;
-                        htri = i;
-                        hn = n*sign;
-                        if (t < tStop)
-                            sp = 0;     // shadow ray decided (shadow_stop, tn_isect.h): drop what is left on the stack
+                        if (t > 0.0f && t < t0)
+                        {
+                            validA = any = true;
+                            closestT = t;
+                            hv = v; hw = w;
+                            htri = isPair ? __float_as_int(q3.w) : (int)idx;
+                            hsign = sign;
+                        }
                     }
                 }
+                if (PAIRS && hR)
+                {
+                    float t, u, v, w, sign;
+                    V3 n;
+                    if (ray_tri(o, d, V3(q5.w, q6.w, q7.w), V3(q6.x, q6.y, q6.z), V3(q7.x, q7.y, q7.z), t, u, v, w, sign, n))
+                    {
+                        if (t > 0.0f && t < t0)
+                        {
+                            // (closestT is the left triangle's t when validA)
+                            const float tStop = *s_stop;
+                            const bool take = !validA || (leftFirst ? (t < closestT && !(closestT < tStop)) : (!(closestT < t) || t < tStop));
+                            if (take)
+                            {
+                                any = true;
+                                closestT = t;
+                                hv = v; hw = w;
+                                htri = __float_as_int(q4.w);
+                                hsign = sign;
+                            }
+                        }
+                    }
+                }
+                if (any && closestT < *s_stop)
+                    sp = 0;             // shadow ray decided (shadow_stop, tn_isect.h): drop what is left on the stack
                 pop = true;
             }
         }
@@ -443,20 +574,23 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
             }
             else
             {
-                active = false;
-                pending = true;         // the record stays in registers until the lane's next refill
+                ref = kNoNode;          // done; the record stays in registers until the lane's next refill (*s_item says which)
             }
         }
         TN_WP_TICK(3)
     }
-    if (pending)
+    if (const uint32_t item = *s_item; item != kNoItem)
     {
         float4* out = job.rec + (size_t)item*2;
-        out[0] = make_float4(closestT, hu, hv, hw);
+        out[0] = make_float4(closestT, 1.0f - hv - hw, hv, hw);
         if (closestT < kFltMax)
+        {
+            const V3 hn = hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
             out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
+        }
     }
     TN_WP_FLUSH
+#undef active
 }
 
 } // namespace tn

@@ -33,13 +33,17 @@ def reduce_accum(accum, dst=0, group=None, out=None):
     (None elsewhere).  `accum` itself is left untouched on every rank -- it keeps the rank's OWN partial sums since
     Init, so a later render + reduce_accum cannot count earlier samples twice (an in-place reduce would leave rank
     dst holding everyone's samples, and the gloo backend also overwrites the non-dst inputs).  The price is one
-    accumulator-sized scratch tensor: `out` (same shape, dtype and device) when the caller keeps one, else a new one
-    per call.  With the `nccl` backend (RCCL) the copy and the reduce are enqueued on the current stream, nothing
+    accumulator-sized scratch tensor: `out` (same shape, dtype and device) when the caller keeps one -- it is filled
+    and returned for any number of ranks, one included -- else a new one per call (one rank: `accum` itself).  With the `nccl` backend (RCCL) the copy and the reduce are enqueued on the current stream, nothing
     synchronises; a device tensor under a CPU backend (`gloo`: the one-device stand-in of bench.py) travels through
     host memory."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return accum
+        # one rank: the sum is the rank's own accumulator; a caller's `out` is filled like in the multi-rank paths
+        if out is None:
+            return accum
+        out.copy_(accum)
+        return out
     backend = dist.get_backend(group)
     if accum.is_cuda and backend != "nccl":
         host = accum.cpu()
