@@ -138,6 +138,8 @@ PMC_SETS = {
 }
 # kernels whose memory traffic is random record gathers (BVH walks); every other kernel of the path streams
 GATHER_KERNELS = ("k_walk", "k_extend", "k_shadow")
+# kernels that run only when the whole scene is LDS-resident: their bytes never leave the CU, what binds them is instruction issue
+LDS_SCENE_KERNELS = ("k_bounce", "k_mega")
 UB_COPY_BYTES = 256 << 20           # per buffer
 UB_BIG_TABLE = 1 << 30              # beyond the 256 MiB Infinity Cache
 UB_TREE_TABLE = 32 << 20            # the 524,288-triangle tree: 33.5 MB of Node64
@@ -146,14 +148,24 @@ UB_STEPS = 64
 
 
 def _kernel_key(name):
+    """rocprofv3's kernel name -> the name the library's own timers file the launch under (tinsel_hip_kernel_times)"""
     m = re.search(r"(k_\w+)(<[^>]*>)?", name)
     if not m:
         return None
-    if m.group(1) in ("k_extend", "k_shadow", "k_bounce", "k_mega") and m.group(2) and m.group(2).startswith("<true"):
+    k, targs = m.group(1), m.group(2) or ""
+    if k in ("k_extend", "k_shadow", "k_bounce", "k_mega") and targs.startswith("<true"):
         return None                         # detail-counting variants (COUNT = true, their first template argument) are not the product kernels
-    if m.group(1) == "k_ub_gather":
-        return "k_ub_gather" + (m.group(2) or "")
-    return "k_accumulate" if m.group(1).startswith("k_accumulate") else m.group(1)
+    if k == "k_ub_gather":
+        return "k_ub_gather" + targs
+    if k.startswith("k_accumulate"):
+        return "k_accumulate"
+    if k in ("k_seg_prefix", "k_seg_expand", "k_seg_expand_all", "k_region_order"):
+        return "k_seg"
+    if k == "k_swalk":                      # the scene-level walk stands in for k_extend / k_shadow (its first template argument: shadow rays)
+        return "k_shadow" if targs.startswith("<true") else "k_extend"
+    if k == "k_shade_sorted":
+        return "k_shade"
+    return k
 
 
 def pmc_pass(args, scene, width, height, maxdepth, steps, counters, timeout=150):
@@ -372,6 +384,15 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     else:
         tot_rays, tot_samples, tot_shadow = float(st["rays"]), float(st["samples"]), float(st["shadow_rays"])
 
+    # per-rank view of the run (load balance of the pixel tiles): every rank's samples, rays, kernel time and median block
+    per_rank = None
+    if world > 1:
+        mine = {"rank": rank, "samples": int(st["samples"]), "rays": int(st["rays"]), "kernel_ms": round(sum(v[1] for v in ktimes.values()), 3),
+                "median_block_ms": round(statistics.median(blocks)*1e3, 3), "device": int(local)}
+        gathered = [None]*world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+
     if rank != 0:
         r.close()
         return None
@@ -470,15 +491,15 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         except Exception as e:
             fast = {"msamples_s": None, "error": str(e)}
 
-    # ---- roofline of the dominant kernel ----------------------------------------------------------
+    # ---- roofline: every kernel of the block, the dominant one (by time, over ALL kernels) in the headline fields ------------
     gpu_ms = sum(v[1] for v in ktimes.values())
-    trace_kernels = ("k_walk", "k_extend", "k_shadow", "k_mega", "k_bounce")
-    dom = max(((k, v) for k, v in ktimes.items() if k in trace_kernels), key=lambda kv: kv[1][1], default=(None, (0, 0.0)))
+    dom = max(ktimes.items(), key=lambda kv: kv[1][1], default=(None, (0, 0.0)))
     dom_name, (dom_launches, dom_ms) = dom
     avg_launch_s = dom_ms*1e-3/max(1, dom_launches)
     rays = st["rays"]
-    # algorithmic bytes by kernel (SURVEY.md 8d's B_ray split over the kernels that do the work):
-    #   the mesh walk (Node64 visits + triangle tests) belongs to k_walk when it runs, the primitive tests and ray/hit records to the scan kernels
+    # algorithmic bytes by kernel (SURVEY.md 8d's B_ray split over the kernels that do the work): the mesh walk (Node64 visits + triangle
+    # tests) belongs to k_walk when it runs, the primitive tests and ray/hit records to the scan kernels; path-state streaming (k_shade,
+    # k_lights, k_generate, k_seg) and the framebuffer gather have no algorithmic figure in that model (8d: "an implementation artefact")
     alg = {"k_bounce": rays*B_ray, "k_mega": rays*B_ray}
     if "k_walk" in ktimes:
         alg["k_walk"] = rays*(64.0*I_bar + 48.0*T_bar)
@@ -487,9 +508,10 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     else:
         alg["k_extend"] = (rays - st["shadow_rays"])*B_ray
         alg["k_shadow"] = st["shadow_rays"]*B_ray
-    dom_bytes = alg.get(dom_name, 0.0)
-    alg_gbs = dom_bytes/(dom_ms*1e-3)/1e9 if dom_ms > 0 else 0.0
+    alg["k_accumulate"] = st["samples"]*B_fb
     job_bytes = rays*B_ray + st["samples"]*B_fb
+    # what a wavefront path tracer with the scene on chip MUST move through HBM: ray in / hit out per ray, the footprint's RMW per sample
+    job_compulsory = rays*48.0 + st["samples"]*B_fb
 
     pmc = {"sq": None, "fetch": None, "write": None, "tcc": None}
     if world == 1 and not args.no_pmc and dom_name:
@@ -510,56 +532,98 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         ff = f_gather if name in GATHER_KERNELS else f_stream
         return (ff*f["FETCH_SIZE"]/f["launches"] + f_write*w["WRITE_SIZE"]/w["launches"])*1024.0
 
-    traffic = kernel_traffic(dom_name) if dom_name else None
-    valu_per_launch = lanes = wait = l2_hit = None
-    if pmc["sq"] and dom_name in pmc["sq"]:
-        q = pmc["sq"][dom_name]
-        valu_per_launch = q.get("SQ_INSTS_VALU", 0.0)/q["launches"]
-        if q.get("SQ_INSTS_VALU"):
-            lanes = q.get("SQ_THREAD_CYCLES_VALU", 0.0)/(64.0*q["SQ_INSTS_VALU"])
-        if q.get("SQ_WAVE_CYCLES"):
-            wait = q.get("SQ_WAIT_ANY", 0.0)/q["SQ_WAVE_CYCLES"]
-    if pmc["tcc"] and dom_name in pmc["tcc"]:
-        q = pmc["tcc"][dom_name]
-        if q.get("TCC_HIT_sum", 0.0) + q.get("TCC_MISS_sum", 0.0) > 0:
-            l2_hit = q["TCC_HIT_sum"]/(q["TCC_HIT_sum"] + q["TCC_MISS_sum"])
+    copy_gbs = YARD[0].get("stream_copy_GBs") if YARD[0] else None
 
-    scene_in_lds = "k_bounce" in ktimes or "k_mega" in ktimes       # the fused arms run only when the whole scene is LDS-resident
+    def kernel_row(name):
+        """one row of roofline.kernels[]: time from the library's HIP events (this block), counters from this run's rocprofv3 passes"""
+        launches, ms = ktimes[name]
+        row = {"kernel": name, "launches": launches, "ms": round(ms, 4), "share_of_gpu_time": (ms/gpu_ms) if gpu_ms > 0 else None,
+               "frac_model": None, "frac": None, "counter_GB": None, "counter_GBs": None, "frac_hbm_counter": None, "frac_of_stream_copy": None,
+               "algorithmic_GBs": None, "valu_frac_of_issue_peak": None, "valu_lanes_active": None, "wave_cycles_waiting": None, "waves_per_simd": None, "l2_hit_rate": None}
+        t = kernel_traffic(name)
+        if t and ms > 0:
+            row["counter_GB"] = t*launches/1e9
+            row["counter_GBs"] = t*launches/(ms*1e-3)/1e9
+            row["frac_hbm_counter"] = row["counter_GBs"]/HBM_PEAK_GBS
+            if copy_gbs:
+                row["frac_of_stream_copy"] = row["counter_GBs"]/copy_gbs
+        if name in alg and ms > 0:
+            row["algorithmic_GBs"] = alg[name]/(ms*1e-3)/1e9
+        if pmc["sq"] and name in pmc["sq"]:
+            q = pmc["sq"][name]
+            iv = q.get("SQ_INSTS_VALU", 0.0)
+            if iv and ms > 0:
+                # (the profiled pass launches what the timed block launches: per-launch counts x this block's launches / this block's time)
+                row["valu_frac_of_issue_peak"] = iv/q["launches"]*launches/(ms*1e-3)/VALU_PEAK
+                row["valu_lanes_active"] = q.get("SQ_THREAD_CYCLES_VALU", 0.0)/(64.0*iv)
+            if q.get("SQ_WAVE_CYCLES"):
+                row["wave_cycles_waiting"] = q.get("SQ_WAIT_ANY", 0.0)/q["SQ_WAVE_CYCLES"]
+                if q.get("GRBM_GUI_ACTIVE"):
+                    row["waves_per_simd"] = 4.0*q["SQ_WAVE_CYCLES"]/(q["GRBM_GUI_ACTIVE"]/8.0*SIMDS)
+        if pmc["tcc"] and name in pmc["tcc"]:
+            q = pmc["tcc"][name]
+            if q.get("TCC_HIT_sum", 0.0) + q.get("TCC_MISS_sum", 0.0) > 0:
+                row["l2_hit_rate"] = q["TCC_HIT_sum"]/(q["TCC_HIT_sum"] + q["TCC_MISS_sum"])
+        # which model the kernel's `frac` comes from: instruction issue where the scene never leaves the CU, else HBM bytes (counter
+        # bytes when this run measured them, the algorithmic figure otherwise)
+        if name in LDS_SCENE_KERNELS:
+            row["frac_model"], row["frac"] = "valu_issue", row["valu_frac_of_issue_peak"]
+        elif row["frac_hbm_counter"] is not None:
+            row["frac_model"], row["frac"] = "hbm_counter", row["frac_hbm_counter"]
+        elif row["algorithmic_GBs"] is not None:
+            row["frac_model"], row["frac"] = "hbm_algorithmic", row["algorithmic_GBs"]/HBM_PEAK_GBS
+        return row
+
+    kernels = sorted((kernel_row(k) for k in ktimes), key=lambda r: -r["ms"])
+    drow = kernels[0] if kernels else {}
+    traffic = kernel_traffic(dom_name) if dom_name else None
+    alg_gbs = drow.get("algorithmic_GBs") or 0.0
+    valu_per_launch = None
+    if pmc["sq"] and dom_name in pmc["sq"] and pmc["sq"][dom_name].get("SQ_INSTS_VALU"):
+        valu_per_launch = pmc["sq"][dom_name]["SQ_INSTS_VALU"]/pmc["sq"][dom_name]["launches"]
+    counter_job = sum(r["counter_GB"] for r in kernels if r["counter_GB"]) if any(r["counter_GB"] for r in kernels) else None
+
     common = {
         "kernel": dom_name, "launches": dom_launches, "avg_launch_ms": avg_launch_s*1e3, "traffic": traffic,
-        "algorithmic_GBs": alg_gbs, "frac_hbm_algorithmic": alg_gbs/HBM_PEAK_GBS,
-        "counter_GBs": (traffic/avg_launch_s/1e9) if (traffic and avg_launch_s > 0) else None,
-        "frac_hbm_counter": (traffic/avg_launch_s/1e9/HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
-        "l2_hit_rate": l2_hit,
-        "valu_wave_insts_per_launch": valu_per_launch, "valu_lanes_active": lanes, "wave_cycles_waiting": wait,
+        "frac_model": drow.get("frac_model"),
+        "algorithmic_GBs": drow.get("algorithmic_GBs"), "frac_hbm_algorithmic": (alg_gbs/HBM_PEAK_GBS) if alg_gbs else None,
+        "counter_GBs": drow.get("counter_GBs"), "frac_hbm_counter": drow.get("frac_hbm_counter"),
+        "l2_hit_rate": drow.get("l2_hit_rate"),
+        "valu_wave_insts_per_launch": valu_per_launch, "valu_lanes_active": drow.get("valu_lanes_active"), "wave_cycles_waiting": drow.get("wave_cycles_waiting"),
+        "waves_per_simd": drow.get("waves_per_simd"),
         "B_ray": B_ray, "I": I_bar, "T": T_bar, "P": P_bar, "B_fb": B_fb, "K_fp": K_fp,
         "job_algorithmic_GBs": job_bytes/(gpu_ms*1e-3)/1e9 if gpu_ms > 0 else 0.0,
+        # the job as a whole: HBM bytes the counters saw over what it must move with the scene on chip (48 B per ray + the footprint per sample)
+        "job_counter_GB": counter_job, "job_compulsory_GB": job_compulsory/1e9,
+        "job_counter_over_compulsory": (counter_job*1e9/job_compulsory) if (counter_job and job_compulsory > 0) else None,
+        "kernels": kernels,
         "kernel_ms": {k: round(v[1], 3) for k, v in ktimes.items()},
-        "kernel_traffic_GB": {k: (round(kernel_traffic(k)*v[0]/1e9, 3) if kernel_traffic(k) else None) for k, v in ktimes.items()} if any(pmc.values()) else None,
+        "kernel_traffic_GB": {r["kernel"]: (round(r["counter_GB"], 3) if r["counter_GB"] else None) for r in kernels} if any(pmc.values()) else None,
         "counter_calibration": dict(cal, source=("k_ub_copy / k_ub_gather<0> in the same rocprofv3 passes" if any(cal.values()) else
                                                  "none measured: FETCH_SIZE x2 on streaming kernels (the guide), x1 elsewhere"),
                                     gather_kernels=list(GATHER_KERNELS)),
         "counters": "rocprofv3 --pmc passes of this run (same workload, same passes per launch)" if any(pmc.values()) else None,
     }
-    if YARD[0]:
-        common["stream_copy_GBs"] = YARD[0].get("stream_copy_GBs")
-        if traffic and avg_launch_s > 0 and YARD[0].get("stream_copy_GBs"):
-            common["frac_of_stream_copy"] = traffic/avg_launch_s/1e9/YARD[0]["stream_copy_GBs"]
-    if dom_name == "k_walk" and dom_ms > 0:
+    if copy_gbs:
+        common["stream_copy_GBs"] = copy_gbs
+        common["frac_of_stream_copy"] = drow.get("frac_of_stream_copy")
+    wrow = next((r for r in kernels if r["kernel"] == "k_walk"), None)
+    if wrow and wrow["ms"] > 0:
         # what the walk is made of: Node64 visits (and triangle tests) per second, next to the record-chase rates this GPU
         # sustains on a table of the tree's size and on one that fits an XCD's L2 (tinsel_hip_ubench, this run)
-        common["node_visits_G_s"] = rays*I_bar/(dom_ms*1e-3)/1e9
-        common["triangle_tests_G_s"] = rays*T_bar/(dom_ms*1e-3)/1e9
+        walk = {"node_visits_G_s": rays*I_bar/(wrow["ms"]*1e-3)/1e9, "triangle_tests_G_s": rays*T_bar/(wrow["ms"]*1e-3)/1e9}
         if YARD[0]:
-            common["record_chase_ceilings_G_s"] = {k: YARD[0].get(k) for k in ("gather_beyond_cache_Grecords_s", "gather_tree_sized_Grecords_s", "gather_l2_resident_Grecords_s")}
+            walk["record_chase_ceilings_G_s"] = {k: YARD[0].get(k) for k in ("gather_beyond_cache_Grecords_s", "gather_tree_sized_Grecords_s", "gather_l2_resident_Grecords_s")}
             # records per second (a 48-B triangle = 0.75 of a 64-B record) against the two ceilings: above the first (the tree top in
             # LDS and the L2 serve most visits), below the second (what a CU's vector-memory front end retires from L2)
-            recs = common["node_visits_G_s"] + 0.75*common["triangle_tests_G_s"]
+            recs = walk["node_visits_G_s"] + 0.75*walk["triangle_tests_G_s"]
             if YARD[0].get("gather_tree_sized_Grecords_s"):
-                common["frac_of_tree_sized_chase"] = recs/YARD[0]["gather_tree_sized_Grecords_s"]
+                walk["frac_of_tree_sized_chase"] = recs/YARD[0]["gather_tree_sized_Grecords_s"]
             if YARD[0].get("gather_l2_resident_Grecords_s"):
-                common["frac_of_l2_resident_chase"] = recs/YARD[0]["gather_l2_resident_Grecords_s"]
-    if scene_in_lds:
+                walk["frac_of_l2_resident_chase"] = recs/YARD[0]["gather_l2_resident_Grecords_s"]
+        common.update(walk)         # (flat, as before) ...
+        common["k_walk"] = walk     # ... and under the kernel's name, whichever kernel is the dominant one
+    if drow.get("frac_model") == "valu_issue":
         # the scene never leaves the CU: the HBM model counts bytes that are LDS reads.  What binds is instruction issue.
         ach = (valu_per_launch/avg_launch_s/1e9) if (valu_per_launch and avg_launch_s > 0) else None
         roofline = dict({"bound": "valu", "achieved": ach, "peak": VALU_PEAK/1e9, "unit": "G wave-instructions/s",
@@ -567,7 +631,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     else:
         # counter bytes when this run measured them, else the algorithmic figure (never a stored constant)
         ach = common["counter_GBs"] if common["counter_GBs"] else alg_gbs
-        roofline = dict({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach/HBM_PEAK_GBS,
+        roofline = dict({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach/HBM_PEAK_GBS) if ach else None,
                          "achieved_is": "counter bytes (calibrated)" if common["counter_GBs"] else "algorithmic bytes"}, **common)
 
     cpu = None
@@ -599,10 +663,14 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         "arithmetic": args.arith,
         "fast_msamples_s": fast["msamples_s"] if fast else None,
         "fast_l2": fast["l2_vs_exact_at_spp"][0] if (fast and fast.get("l2_vs_exact_at_spp")) else None,
+        # what bit-exactness costs: the opt-in tolerance arm's rate over the timed (exact) arm's, same workload
+        "fast_over_exact": (fast["msamples_s"]/msamples) if (fast and fast.get("msamples_s") and args.arith == "exact") else None,
         "fast": fast,
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if world > 1:
+        res["ranks"] = {"communicator_world_size": dist.get_world_size(), "backend": backend, "per_rank": per_rank}
     r.close()
     return res
 
@@ -660,14 +728,16 @@ def group_bench(args):
         "calls": calls}), flush=True)
 
 
-def group_leg(args, world):
+def group_leg(args, world, scene=None, width=None, height=None, maxdepth=None):
     """N > 1, rank 0, before the ranks meet: the same N devices through tinsel_hip_group in a child process with a time limit
-    (a hung collective must not take the scaling run with it)."""
+    (a hung collective must not take the scaling run with it).  Default: the run's own workload; main() also asks for BASELINE
+    configs[4] (veach.tin at 4K: north_star's 8-GPU configuration)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
     if os.environ.get("TINSEL_BENCH_ONE_DEVICE"):
         env["TINSEL_HIP_GROUP_ONE_DEVICE"] = "1"
     cmd = [sys.executable, os.path.abspath(__file__), "--group", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--scene", args.scene, "--width", str(args.width), "--height", str(args.height), "--maxdepth", str(args.maxdepth), "--tile", str(args.tile)]
+           "--scene", scene or args.scene, "--width", str(width or args.width), "--height", str(height or args.height),
+           "--maxdepth", str(args.maxdepth if maxdepth is None else maxdepth), "--tile", str(args.tile)]
     try:
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -680,12 +750,58 @@ def group_leg(args, world):
         return {"unavailable": str(e)}
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no RANK in the environment): re-executes itself under torch.distributed.run
+    with one process per GPU, exactly as the driver's own N-rank command line would -- so both launch styles give N ranks and one JSON
+    line with n_gpus = N."""
+    import socket
+    import torch
+    n = args.gpus
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not os.environ.get("TINSEL_BENCH_ONE_DEVICE"):
+        raise SystemExit("bench.py --gpus %d: %d GPU(s) visible (TINSEL_BENCH_ONE_DEVICE=1 + TINSEL_BENCH_BACKEND=gloo run the N-rank code "
+                         "path on one device: a validation of the path, not a measurement)" % (n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher in the environment -- starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def first_collective_watchdog(args, rank, world, backend, seconds=None):
+    """A timer around the rendezvous + first all-reduce.  When it fires, rank 0 prints the contract's JSON line with value null and a
+    readable `unavailable` reason, and every rank leaves (os._exit: a hung collective cannot be interrupted)."""
+    import threading
+    # rank 0 may spend up to 2 x 240 s in the tinsel_hip_group legs before it joins: the other ranks' timers allow for that
+    limit = seconds if seconds is not None else (60.0 if args.no_group_leg else 60.0 + 2*240.0)
+
+    def fire():
+        if rank == 0:
+            print(json.dumps({
+                "metric": "Msamples/s (%s.tin %dx%d, wavefront path)" % (args.scene, args.width, args.height), "value": None, "unit": "Msamples/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32",
+                "unavailable": "the %d ranks did not complete their rendezvous + first all-reduce (%s backend%s) within %.0f s: a rank that never "
+                               "started, or a collective that does not come up on this node" % (world, backend, " = RCCL over xGMI" if backend == "nccl" else "", limit)}), flush=True)
+        os._exit(4)
+
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     args = parse()
     if args.inner_pmc:
         return inner_pmc(args)
     if args.group:
         return group_bench(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -703,22 +819,36 @@ def main():
     if os.environ.get("TINSEL_BENCH_ONE_DEVICE"):
         local = 0
     torch.cuda.set_device(local)
-    group = None
+    group = group5 = None
+    default_headline = (args.scene, args.width, args.height) == ("cornell", 1024, 1024)
     if world > 1 and rank == 0 and not args.no_group_leg:
         group = group_leg(args, world)
+        if default_headline and not args.no_more_configs:
+            group5 = group_leg(args, world, "veach", 3840, 2160, 0)
     if world == 1 and not args.no_ubench:
         YARD[0] = yard_sticks()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the FIRST collective under a watchdog: if the ranks cannot meet (a rank that never started, an RCCL ring that does not come up),
+        # rank 0 still prints ONE readable JSON line instead of hanging until the driver's clock runs out
+        dog = first_collective_watchdog(args, rank, world, backend)
+        import datetime
+        # (the other ranks may wait for rank 0's group legs: up to 2 x 240 s before it joins)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=900))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+        hello = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(hello)
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        dog.cancel()
+        if int(hello.item()) != world:
+            raise SystemExit("bench.py: the first all-reduce over %d ranks summed to %d" % (world, int(hello.item())))
 
     head = run_config(args, args.scene, args.width, args.height, args.maxdepth, rank, world, local, dist, backend, torch, with_extras=True)
 
     more = []
-    default_headline = (args.scene, args.width, args.height) == ("cornell", 1024, 1024)
     if world == 1 and default_headline and not args.no_second_config:
         # BASELINE configs[2]: the scene that lives in HBM
         what = "ajax stand-in (524,288 triangles) 1920x1080 maxDepth=4"
@@ -744,8 +874,8 @@ def main():
             "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic: camera samples, seeds and everything downstream generated on the GPU; scenes are the reference's own files as written by "
-                    "its loader (scene packs), the ajax mesh a procedural 524,288-triangle stand-in (ajax.obj is not in the reference tree)",
+            "data": "the reference's own scene files, as written by its loader into scene packs (no dataset, no checkpoint; the ajax mesh is a procedural "
+                    "524,288-triangle stand-in: ajax.obj is not in the reference tree); camera samples, RNG seeds and everything downstream are generated on the GPU",
         }
         for k, v in head.items():
             if k not in line:
@@ -754,6 +884,8 @@ def main():
             line["yard_sticks"] = YARD[0]
         if group is not None:
             line["group"] = group
+        if group5 is not None:
+            line["group_cfg5"] = group5
         if more:
             line["configs"] = [{k: head[k] for k in ("metric", "value", "unit", "ms_per_step", "mrays_per_s", "config", "roofline", "cpu_baseline", "timed_blocks", "fast_msamples_s", "fast_l2")}] + more
         print(json.dumps(line), flush=True)

@@ -242,6 +242,24 @@ int tinsel_hip_set_mesh_bvh(tinsel_hip* r, int mode, double* build_ms);
  * small enough for the LDS-staged arena are refused (create a new renderer: it costs less than the refit). */
 int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_xyz, int num_vertices, const float* normals_xyz);
 
+/* Primitives that MOVE between renders, and the scene-level BVH that follows them.  The reference mutates Scene::primitives and
+ * re-runs Scene::Build (scene.cpp:4-16: its host BVHBuilder over PrimitiveBounds(p), intersection.h:906-939), or re-loads an animated
+ * scene file and re-creates the renderer per batch frame (main.cpp:318-327) -- re-uploading every mesh.  Here:
+ *   tinsel_hip_set_primitive_transform   new start / end transforms of primitive `index` (the pose used by every intersection, the
+ *       motion-blur interpolation when they differ, PrimitiveArea of a mesh light).  Takes effect with the next rebuild_scene: until
+ *       then the renderer must not be asked to render.
+ *   tinsel_hip_rebuild_scene             the scene BVH, the primitives' leaf boxes and the traversal stack depth, from PrimitiveBounds
+ *       of the primitives as they are NOW.  TINSEL_SCENE_BVH_NODES: `nodes` (2P-1 reference-format nodes, e.g. the reference's own
+ *       Scene::Build run on the host) is validated like at create and used as it is -- bit-identical to a renderer created from the moved
+ *       scene.  TINSEL_SCENE_BVH_DEVICE: built on the device (the mesh builders' kernels, tn_lbvh.h: Morton order over the boxes'
+ *       centroids, agglomerative clustering by surface area); nodes / num_nodes are ignored.  At the scene level the reference's
+ *       QueryBVH has no closest-t cull (intersection.h:751-799), so the SET of primitives a ray tests does not depend on the tree:
+ *       another tree changes the visit order only, which decides nothing but exact-t ties.  *build_ms (may be NULL): device time.
+ * Meshes keep their own trees (tinsel_hip_refit_mesh / tinsel_hip_set_mesh_bvh for those). */
+enum { TINSEL_SCENE_BVH_NODES = 0, TINSEL_SCENE_BVH_DEVICE = 1 };
+int tinsel_hip_set_primitive_transform(tinsel_hip* r, int index, const tinsel_transform* start, const tinsel_transform* end);
+int tinsel_hip_rebuild_scene(tinsel_hip* r, int mode, const tinsel_bvh_node* nodes, int num_nodes, double* build_ms);
+
 /* Importance sampling of the environment probe.  TINSEL_PROBE_CDF (default): the reference's two binary searches over
  * the row and column CDFs (ProbeSample, probe.h:205-236; ~21 dependent loads per sample on the 1600x800 loft.hdr) --
  * sample-identical to the reference.  TINSEL_PROBE_ALIAS (opt-in): an alias table over the W*H texels built once on the

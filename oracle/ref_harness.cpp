@@ -50,6 +50,7 @@
 static_assert(sizeof(Primitive) == sizeof(tinsel_primitive), "Primitive mirror");
 static_assert(sizeof(BVHNode) == sizeof(tinsel_bvh_node), "BVHNode mirror");
 static_assert(sizeof(Camera) == sizeof(tinsel_camera), "Camera mirror");
+static_assert(sizeof(Transform) == sizeof(tinsel_transform), "Transform mirror");
 static_assert(sizeof(Options) == sizeof(tinsel_options), "Options mirror");
 static_assert(sizeof(Material) == sizeof(tinsel_material), "Material mirror");
 static_assert(sizeof(MeshGeometry) == sizeof(tinsel_mesh_geometry), "MeshGeometry mirror");
@@ -208,6 +209,31 @@ int ref_scene_add_standin_mesh(void* h, int slices, int segments, float scale, c
     rs->scene.bvh.nodes = NULL;
     rs->scene.Build();
     return 0;
+}
+
+// A primitive moves: new start / end transforms, then the reference's own Scene::Build (scene.cpp:4-16: BVHBuilder over
+// PrimitiveBounds, intersection.h:906-939) -- what main.cpp:318-327 gets by re-loading an animated scene file per batch frame.
+int ref_scene_set_transform(void* h, int index, const tinsel_transform* start, const tinsel_transform* end)
+{
+    RefScene* rs = (RefScene*)h;
+    if (index < 0 || index >= (int)rs->scene.primitives.size())
+        return -1;
+    memcpy(&rs->scene.primitives[index].startTransform, start, sizeof(Transform));
+    memcpy(&rs->scene.primitives[index].endTransform, end, sizeof(Transform));
+    delete[] rs->scene.bvh.nodes;
+    rs->scene.bvh.nodes = NULL;
+    rs->scene.Build();
+    return 0;
+}
+
+// the scene BVH as Scene::Build left it (2P-1 nodes; returns the count, copies at most `max_nodes`)
+int ref_scene_get_bvh(void* h, tinsel_bvh_node* out, int max_nodes)
+{
+    RefScene* rs = (RefScene*)h;
+    const int n = rs->scene.bvh.numNodes;
+    if (out)
+        memcpy(out, rs->scene.bvh.nodes, sizeof(BVHNode)*(size_t)(n < max_nodes ? n : max_nodes));
+    return n;
 }
 
 // Replace the sky probe by a procedural lat-long HDR (width x height) so probe

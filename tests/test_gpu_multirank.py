@@ -33,6 +33,25 @@ def test_two_ranks_on_one_device():
     g = d["group"]
     assert g.get("n_gpus") == 2 and g["one_device_validation"] is True, g
     assert g["kpass_msamples_s"] > 0 and g["api_1pass_plain_msamples_s"] > 0 and g["api_1pass_lookahead_msamples_s"] > 0, g
+    # the communicator's own rank count and every rank's share of the work are in the line
+    rk = d["ranks"]
+    assert rk["communicator_world_size"] == 2 and [x["rank"] for x in rk["per_rank"]] == [0, 1]
+    assert sum(x["samples"] for x in rk["per_rank"]) == 16*512*384 and all(x["kernel_ms"] > 0 for x in rk["per_rank"])
+
+
+def test_plain_launch_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher in the environment (the way the driver starts `--gpus 1`): bench.py re-executes itself
+    under torch.distributed.run, so the line still says n_gpus = 2 (a first 8-GPU lease must not be spent on one rank)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TINSEL_BENCH_BACKEND="gloo", TINSEL_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--width", "256", "--height", "256",
+                        "--no-group-leg"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "starting 2 ranks" in p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"]["communicator_world_size"] == 2 and d["value"] > 0
 
 
 def test_group_mode_prints_one_line():

@@ -1,0 +1,117 @@
+"""tinsel_hip_set_primitive_transform + tinsel_hip_rebuild_scene: primitives MOVE and the scene level follows on the device -- what the
+reference does by mutating Scene::primitives and re-running Scene::Build (scene.cpp:4-16; the batch re-init of main.cpp:318-327).
+
+tests/golden/moved.golden.npz (tests/golden/make_moved.py) holds, per scene, the moves, the scene BVH the reference's own builder made
+for the moved scene, and the reference's PathTrace + AddSample output on it.  A renderer created from the ORIGINAL pack is told the
+moves and rebuilds:
+  * from the reference's nodes  -> radiance and framebuffer bit-identical to the reference's moved scene;
+  * on the device (PLOC over PrimitiveBounds) -> the same, except where two hits tie exactly (the scene-level walk has no closest-t
+    cull, so another tree changes the visit ORDER only): >= 99.9 % of the paths identical."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import tinsel_amd
+from tinsel_amd import abi
+from tests import oracle_api as oa
+
+pytestmark = pytest.mark.gpu
+MOVED = np.load(os.path.join(oa.GOLDEN, "moved.golden.npz"))
+SCENES = ["many_spheres", "features", "cornell"]
+PIPES = [abi.PIPELINE_AUTO, abi.PIPELINE_WAVEFRONT_SPLIT, abi.PIPELINE_MEGAKERNEL]
+
+
+def _moved(name):
+    m = {k[len(name) + 1:]: MOVED[k] for k in MOVED.files if k.startswith(name + "_")}
+    cam = abi.Camera.from_buffer_copy(m["camera"].tobytes())
+    opt = abi.Options.from_buffer_copy(m["options"].tobytes())
+    nodes = (abi.BVHNode*(m["nodes"].size//C.sizeof(abi.BVHNode))).from_buffer_copy(m["nodes"].tobytes())
+    return m, cam, opt, nodes
+
+
+def _apply(r, m):
+    for k, i in enumerate(m["index"]):
+        s = abi.Transform.from_buffer_copy(m["start"][k].tobytes())
+        e = abi.Transform.from_buffer_copy(m["end"][k].tobytes())
+        r.set_primitive_transform(int(i), s, e)
+
+
+def _render(r, cam, opt, passes):
+    r.init(opt.width, opt.height)
+    r.set_pass_index(0)
+    out = r.render(cam, opt, passes=passes)
+    return out, r.batch_radiance(passes, opt.height, opt.width)
+
+
+@pytest.mark.parametrize("pipe", PIPES)
+@pytest.mark.parametrize("name", SCENES)
+def test_moved_primitives_on_the_references_tree_are_bit_identical(name, pipe):
+    m, cam, opt, nodes = _moved(name)
+    scene = tinsel_amd.Scene.load_pack(os.path.join(oa.GOLDEN, name + ".pack"))
+    r = tinsel_amd.create_gpu_renderer(scene)
+    r.set_pipeline(pipe)
+    _apply(r, m)
+    r.rebuild_scene(nodes)
+    out, rad = _render(r, cam, opt, int(m["passes"]))
+    r.close()
+    assert np.array_equal(rad, m["radiance"]), "%s: %d paths differ" % (name, int((rad != m["radiance"]).any(axis=-1).sum()))
+    assert np.array_equal(out, m["accum"])
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_moved_primitives_on_a_device_built_tree(name):
+    m, cam, opt, nodes = _moved(name)
+    scene = tinsel_amd.Scene.load_pack(os.path.join(oa.GOLDEN, name + ".pack"))
+    r = tinsel_amd.create_gpu_renderer(scene)
+    _apply(r, m)
+    ms = r.rebuild_scene()
+    out, rad = _render(r, cam, opt, int(m["passes"]))
+    same = float((rad == m["radiance"]).all(axis=-1).mean())
+    print("%s: %d primitives, scene BVH rebuilt on the device in %.3f ms, %.4f %% of the paths identical to the reference's tree" % (
+        name, scene.desc.num_primitives, ms, 100*same))
+    assert same >= 0.999 and oa.image_l2(out, m["accum"]) <= 1e-3
+    # ... and the reference's nodes afterwards give the reference's bits back (the device-built tree left nothing behind)
+    r.rebuild_scene(nodes)
+    out2, rad2 = _render(r, cam, opt, int(m["passes"]))
+    r.close()
+    assert np.array_equal(rad2, m["radiance"]) and np.array_equal(out2, m["accum"])
+
+
+def test_render_is_refused_between_a_move_and_the_rebuild_and_moving_back_restores_the_image():
+    name = "many_spheres"
+    m, cam, opt, nodes = _moved(name)
+    g = np.load(os.path.join(oa.GOLDEN, name + ".golden.npz"))
+    scene = tinsel_amd.Scene.load_pack(os.path.join(oa.GOLDEN, name + ".pack"))
+    r = tinsel_amd.create_gpu_renderer(scene)
+    _apply(r, m)
+    r.init(opt.width, opt.height)
+    with pytest.raises(tinsel_amd.TinselHipError, match="rebuild_scene"):
+        r.render(cam, opt, passes=1)
+    r.rebuild_scene(nodes)
+    # back to where the primitives were, on the ORIGINAL tree (the pack's own scene BVH): the original fixture, bit for bit
+    d = scene.desc
+    prims = C.cast(d.primitives, C.POINTER(abi.Primitive))
+    for i in m["index"]:
+        p = prims[int(i)]
+        r.set_primitive_transform(int(i), abi.Transform.from_buffer_copy(bytes(p.start_transform)), abi.Transform.from_buffer_copy(bytes(p.end_transform)))
+    orig = (abi.BVHNode*d.num_bvh_nodes).from_buffer_copy(C.string_at(C.cast(d.bvh_nodes, C.c_void_p), d.num_bvh_nodes*C.sizeof(abi.BVHNode)))
+    r.rebuild_scene(orig)
+    out, rad = _render(r, cam, opt, int(g["passes"]))
+    r.close()
+    assert np.array_equal(rad, g["radiance"]) and np.array_equal(out, g["accum"])
+
+
+def test_malformed_scene_trees_are_refused():
+    m, cam, opt, nodes = _moved("cornell")
+    scene = tinsel_amd.Scene.load_pack(os.path.join(oa.GOLDEN, "cornell.pack"))
+    r = tinsel_amd.create_gpu_renderer(scene)
+    bad = (abi.BVHNode*len(nodes)).from_buffer_copy(bytes(nodes))
+    bad[0].left_index = 9999
+    with pytest.raises(tinsel_amd.TinselHipError):
+        r.rebuild_scene(bad)
+    short = (abi.BVHNode*3).from_buffer_copy(bytes(nodes)[:3*C.sizeof(abi.BVHNode)])
+    with pytest.raises(tinsel_amd.TinselHipError):
+        r.rebuild_scene(short)
+    r.close()

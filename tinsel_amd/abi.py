@@ -113,6 +113,7 @@ class KernelTime(C.Structure):
 
 MODE_NORMALS, MODE_COMPLEXITY, MODE_PATHTRACE = 0, 1, 2
 BVH_REFERENCE, BVH_LBVH, BVH_PLOC = 0, 1, 2
+SCENE_BVH_NODES, SCENE_BVH_DEVICE = 0, 1
 ARITH_EXACT, ARITH_FAST = 0, 1
 PROBE_CDF, PROBE_ALIAS = 0, 1
 LOOKAHEAD_OFF, LOOKAHEAD_ON, LOOKAHEAD_PIN_OUTPUT = 0, 1, 2

@@ -262,6 +262,36 @@ void transform_bounds(const Xform& x, V3 lower, V3 upper, V3& outLower, V3& outU
     outUpper = center + ax + ay + az;
 }
 
+Moving64 make_moving(const Xform& xs, const Xform& xe)
+{
+    Moving64 mv;
+    mv.spx = xs.p.x; mv.spy = xs.p.y; mv.spz = xs.p.z; mv.ss = xs.s;
+    mv.srx = xs.r.x; mv.sry = xs.r.y; mv.srz = xs.r.z; mv.srw = xs.r.w;
+    mv.epx = xe.p.x; mv.epy = xe.p.y; mv.epz = xe.p.z; mv.es = xe.s;
+    mv.erx = xe.r.x; mv.ery = xe.r.y; mv.erz = xe.r.z; mv.erw = xe.r.w;
+    return mv;
+}
+
+Xform to_xform(const tinsel_transform& t);
+
+// the pose part of a primitive's record: static primitives carry InterpolateTransform(a, a, t), evaluated once with the same function
+void set_prim_pose(Prim64& o, const Xform& xs, const Xform& xe, bool isStatic)
+{
+    if (isStatic)
+    {
+        const Xform x = interpolate_xform(xs, xe, 0.0f);
+        o.px = x.p.x; o.py = x.p.y; o.pz = x.p.z; o.s = x.s;
+        o.rx = x.r.x; o.ry = x.r.y; o.rz = x.r.z; o.rw = x.r.w;
+        o.flags &= ~(uint32_t)kPrimMoving;
+    }
+    else
+    {
+        o.px = o.py = o.pz = o.s = 0.0f;
+        o.rx = o.ry = o.rz = o.rw = 0.0f;
+        o.flags |= kPrimMoving;
+    }
+}
+
 Xform to_xform(const tinsel_transform& t)
 {
     Xform x;
@@ -345,6 +375,14 @@ struct tinsel_hip
     std::vector<std::vector<int32_t>> meshIndices;
     std::vector<int> primMesh;
     std::vector<float> primEndScale;
+    // ... and what moving a PRIMITIVE needs (tinsel_hip_set_primitive_transform / tinsel_hip_rebuild_scene): the Prim64 records as
+    // uploaded, where they and the Moving64 slots (one per primitive) sit in the arena, every mesh's root box in mesh space and its
+    // area (PrimitiveBounds, PrimitiveArea), whether a transform changed since the scene BVH was last built
+    std::vector<Prim64> primsHost;
+    size_t arenaOffPrims = 0, arenaOffMoving = 0, arenaOffMats = 0;
+    std::vector<V3> meshRootLo, meshRootHi;
+    std::vector<float> meshArea;
+    bool sceneDirty = false;
     // ... and to follow a refitted mesh at the SCENE level (its primitives' leaf boxes and their ancestors in the scene BVH):
     // the primitives' start / end transforms, the reference's scene BVH as handed in, where its device form and the leaf boxes
     // sit in the arena
@@ -1488,6 +1526,8 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
         return fail("render: options.width/height do not match the last tinsel_hip_init");
     if (passes < 1)
         return fail("render: passes must be >= 1");
+    if (r->sceneDirty)
+        return fail("render: a primitive was moved (tinsel_hip_set_primitive_transform): call tinsel_hip_rebuild_scene first");
     HIP_TRY(hipSetDevice(r->device));
 
     // return finished timing events to the pool
@@ -1988,7 +2028,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
     const int P = desc->num_primitives;
     std::vector<Prim64> prims((size_t)P);
     std::vector<Mat128> mats((size_t)P);
-    std::vector<Moving64> moving;
+    std::vector<Moving64> moving((size_t)P);
     std::vector<DevMesh> meshes;
     std::vector<int32_t> lights;
     std::map<uint64_t, uint32_t> meshIndex;     // MeshGeometry::id (util.h:20) -> DevScene::meshes index
@@ -2042,24 +2082,11 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         const Xform xs = to_xform(p.start_transform), xe = to_xform(p.end_transform);
         r->primStart.push_back(xs);
         r->primEnd.push_back(xe);
-        if (isStatic)
-        {
-            // InterpolateTransform(a, a, t) is t-independent: evaluate it once, with the same function
-            const Xform x = interpolate_xform(xs, xe, 0.0f);
-            o.px = x.p.x; o.py = x.p.y; o.pz = x.p.z; o.s = x.s;
-            o.rx = x.r.x; o.ry = x.r.y; o.rz = x.r.z; o.rw = x.r.w;
-        }
-        else
-        {
-            o.flags |= kPrimMoving;
-            o.moving = (uint32_t)moving.size();
-            Moving64 mv;
-            mv.spx = xs.p.x; mv.spy = xs.p.y; mv.spz = xs.p.z; mv.ss = xs.s;
-            mv.srx = xs.r.x; mv.sry = xs.r.y; mv.srz = xs.r.z; mv.srw = xs.r.w;
-            mv.epx = xe.p.x; mv.epy = xe.p.y; mv.epz = xe.p.z; mv.es = xe.s;
-            mv.erx = xe.r.x; mv.ery = xe.r.y; mv.erz = xe.r.z; mv.erw = xe.r.w;
-            moving.push_back(mv);
-        }
+        // InterpolateTransform(a, a, t) is t-independent: static primitives get it evaluated once, with the same function
+        set_prim_pose(o, xs, xe, isStatic);
+        // (a Moving64 slot for EVERY primitive, its own index: a static one may start to move, tinsel_hip_set_primitive_transform)
+        o.moving = (uint32_t)i;
+        moving[(size_t)i] = make_moving(xs, xe);
 
         if (p.type == TINSEL_GEOM_SPHERE)
         {
@@ -2153,6 +2180,9 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                     maxMeshNeed = dm.stackNeed;
                 r->meshNumVertices.push_back(g.num_vertices);
                 r->meshIndices.emplace_back(g.indices, g.indices + (size_t)numTris*3);
+                r->meshRootLo.push_back(V3(g.nodes[0].lower.x, g.nodes[0].lower.y, g.nodes[0].lower.z));      // PrimitiveBounds reads nodes[0].bounds (intersection.h:928)
+                r->meshRootHi.push_back(V3(g.nodes[0].upper.x, g.nodes[0].upper.y, g.nodes[0].upper.z));
+                r->meshArea.push_back(g.area);
                 o.mesh = (uint32_t)meshes.size();
                 meshIndex[g.id] = o.mesh;
                 meshes.push_back(dm);
@@ -2286,6 +2316,10 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             r->sceneBvhHost.assign(desc->bvh_nodes, desc->bvh_nodes + desc->num_bvh_nodes);
             r->arenaOffNodes = offNodes;
             r->arenaOffBoxes = offBoxes;
+            r->arenaOffPrims = offPrims;
+            r->arenaOffMoving = offMoving;
+            r->arenaOffMats = offMats;
+            r->primsHost = prims;
             sc.hasMedia = 0;
             for (const Mat128& mm : mats)
                 if (mm.absorption[0] != 0.0f || mm.absorption[1] != 0.0f || mm.absorption[2] != 0.0f)
@@ -2778,6 +2812,9 @@ int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_x
         lo = V3(minT(lo.x, v[0]), minT(lo.y, v[1]), minT(lo.z, v[2]));
         hi = V3(maxT(hi.x, v[0]), maxT(hi.y, v[1]), maxT(hi.z, v[2]));
     }
+    r->meshRootLo[(size_t)mi] = lo;
+    r->meshRootHi[(size_t)mi] = hi;
+    r->meshArea[(size_t)mi] = totalArea;
     std::vector<tinsel_bvh_node>& sb = r->sceneBvhHost;
     std::vector<int> leafOf((size_t)r->scene.numPrims, -1);
     for (size_t k = 0; k < sb.size(); ++k)
@@ -2831,6 +2868,200 @@ int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_x
         HIP_TRY(hipMemcpy(arenaDev + r->arenaOffNodes, sceneBvh.nodes.data(), sizeof(Node64)*sceneBvh.nodes.size(), hipMemcpyHostToDevice));
     for (size_t k = 0; k < newBoxes.size(); ++k)
         HIP_TRY(hipMemcpy(arenaDev + r->arenaOffBoxes + sizeof(PrimBox)*(size_t)newBoxPrim[k], &newBoxes[k], sizeof(PrimBox), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// A primitive moves (the reference mutates Scene::primitives[i].startTransform / endTransform and re-runs Scene::Build).
+int tinsel_hip_set_primitive_transform(tinsel_hip* r, int index, const tinsel_transform* start, const tinsel_transform* end)
+{
+    lookahead_cancel(r);
+    if (!r || !start || !end || index < 0 || index >= r->scene.numPrims)
+        return fail("set_primitive_transform: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const Xform xs = to_xform(*start), xe = to_xform(*end);
+    const bool isStatic = memcmp(start, end, sizeof(tinsel_transform)) == 0;
+    r->primStart[(size_t)index] = xs;
+    r->primEnd[(size_t)index] = xe;
+    r->primEndScale[(size_t)index] = xe.s;
+    Prim64& o = r->primsHost[(size_t)index];
+    set_prim_pose(o, xs, xe, isStatic);
+    const Moving64 mv = make_moving(xs, xe);
+    unsigned char* arenaDev = const_cast<unsigned char*>(r->scene.arena);
+    HIP_TRY(hipMemcpy(arenaDev + r->arenaOffPrims + sizeof(Prim64)*(size_t)index, &o, sizeof(Prim64), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(arenaDev + r->arenaOffMoving + sizeof(Moving64)*(size_t)index, &mv, sizeof(Moving64), hipMemcpyHostToDevice));
+    if (o.type == kPrimMesh)
+    {
+        // PrimitiveArea of a mesh: area*endTransform.s (intersection.h:843-847)
+        const float area = r->meshArea[(size_t)r->primMesh[(size_t)index]]*xe.s;
+        HIP_TRY(hipMemcpy(arenaDev + r->arenaOffMats + sizeof(Mat128)*(size_t)index + offsetof(Mat128, area), &area, sizeof(float), hipMemcpyHostToDevice));
+    }
+    r->sceneDirty = true;
+    return 0;
+}
+
+namespace {
+
+// PrimitiveBounds (intersection.h:906-939) of primitive i as it is now: the local box (sphere: +-radius; plane: +-1e8; mesh: its root's)
+// under the start and the end transform, TransformBounds (maths.h:1004-1021), united
+void primitive_bounds(const tinsel_hip* r, int i, V3& lower, V3& upper)
+{
+    const Prim64& p = r->primsHost[(size_t)i];
+    V3 lo, hi;
+    if (p.type == kPrimSphere)      { lo = V3(-p.g0); hi = V3(p.g0); }
+    else if (p.type == kPrimPlane)  { lo = V3(-1.e+8f); hi = V3(1.e+8f); }
+    else                            { lo = r->meshRootLo[(size_t)r->primMesh[(size_t)i]]; hi = r->meshRootHi[(size_t)r->primMesh[(size_t)i]]; }
+    V3 sl, su, el, eu;
+    transform_bounds(r->primStart[(size_t)i], lo, hi, sl, su);
+    transform_bounds(r->primEnd[(size_t)i], lo, hi, el, eu);
+    lower = V3(minT(sl.x, el.x), minT(sl.y, el.y), minT(sl.z, el.z));      // Union, maths.h:1023-1026
+    upper = V3(maxT(su.x, eu.x), maxT(su.y, eu.y), maxT(su.z, eu.z));
+}
+
+// a Node64 tree (as the device builders emit it) back into the reference's node array: what tinsel_hip_refit_mesh walks to refit
+// the scene level, and what a later TINSEL_SCENE_BVH_NODES caller would hand in
+void node64_to_reference(const std::vector<Node64>& nodes, uint32_t ref, float lminx, float lminy, float lminz, float lmaxx, float lmaxy, float lmaxz,
+                         std::vector<tinsel_bvh_node>& out, uint32_t at)
+{
+    tinsel_bvh_node& me = out[at];
+    me.lower.x = lminx; me.lower.y = lminy; me.lower.z = lminz;
+    me.upper.x = lmaxx; me.upper.y = lmaxy; me.upper.z = lmaxz;
+    if (ref & kLeafBit)
+    {
+        me.left_index = ref & ~kLeafBit;
+        me.right_index_leaf = 0x80000000u;
+        return;
+    }
+    const Node64 n = nodes[ref];
+    const uint32_t l = (uint32_t)out.size();
+    out.push_back(tinsel_bvh_node());
+    out.push_back(tinsel_bvh_node());
+    out[at].left_index = l;
+    out[at].right_index_leaf = l + 1u;
+    node64_to_reference(nodes, n.left, n.lminx, n.lminy, n.lminz, n.lmaxx, n.lmaxy, n.lmaxz, out, l);
+    node64_to_reference(nodes, n.right, n.rminx, n.rminy, n.rminz, n.rmaxx, n.rmaxy, n.rmaxz, out, l + 1u);
+}
+
+} // namespace
+
+int tinsel_hip_rebuild_scene(tinsel_hip* r, int mode, const tinsel_bvh_node* nodes, int num_nodes, double* build_ms)
+{
+    lookahead_cancel(r);
+    if (!r || (mode != TINSEL_SCENE_BVH_NODES && mode != TINSEL_SCENE_BVH_DEVICE) || (mode == TINSEL_SCENE_BVH_NODES && (!nodes || num_nodes <= 0)))
+        return fail("rebuild_scene: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (build_ms)
+        *build_ms = 0.0;
+    const int P = r->scene.numPrims;
+
+    std::vector<tinsel_bvh_node> ref;       // the new tree in the reference's format
+    if (mode == TINSEL_SCENE_BVH_NODES)
+        ref.assign(nodes, nodes + num_nodes);
+    else
+    {
+        // leaf boxes: PrimitiveBounds of every primitive as it is now
+        std::vector<V3> lo((size_t)P), hi((size_t)P);
+        for (int i = 0; i < P; ++i)
+            primitive_bounds(r, i, lo[(size_t)i], hi[(size_t)i]);
+        if (P == 1)
+        {
+            ref.resize(1);
+            ref[0].lower.x = lo[0].x; ref[0].lower.y = lo[0].y; ref[0].lower.z = lo[0].z;
+            ref[0].upper.x = hi[0].x; ref[0].upper.y = hi[0].y; ref[0].upper.z = hi[0].z;
+            ref[0].left_index = 0;
+            ref[0].right_index_leaf = 0x80000000u;
+        }
+        else
+        {
+            // The mesh builders' kernels over the primitives' boxes: a box travels as a degenerate triangle record (a = c = lower, b = upper),
+            // whose min / max IS the box; Morton order of the centroids, agglomerative clustering by surface area (tn_lbvh.h)
+            std::vector<Tri48> items((size_t)P);
+            for (int i = 0; i < P; ++i)
+            {
+                Tri48& T = items[(size_t)i];
+                T.ax = lo[(size_t)i].x; T.ay = lo[(size_t)i].y; T.az = lo[(size_t)i].z; T.i0 = i;
+                T.bx = hi[(size_t)i].x; T.by = hi[(size_t)i].y; T.bz = hi[(size_t)i].z; T.i1 = i;
+                T.cx = lo[(size_t)i].x; T.cy = lo[(size_t)i].y; T.cz = lo[(size_t)i].z; T.i2 = i;
+            }
+            Tri48* itemsDev = nullptr;
+            HIP_TRY(hipMalloc((void**)&itemsDev, sizeof(Tri48)*(size_t)P));
+            int rc = 0;
+            std::vector<Node64> built((size_t)P - 1);
+            DevMesh fake, out;
+            memset(&fake, 0, sizeof(fake));
+            fake.tris = itemsDev;
+            fake.numTris = P;
+            fake.inArena = 1;           // (no bottom-level records for this one)
+            const size_t allocsBefore = r->lbvhAllocs.size();
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (hipMemcpy(itemsDev, items.data(), sizeof(Tri48)*(size_t)P, hipMemcpyHostToDevice) != hipSuccess ||
+                hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+                rc = fail("rebuild_scene: upload failed");
+            if (!rc)
+            {
+                (void)hipEventRecord(e0, nullptr);
+                rc = build_device_bvh(r, fake, out, TINSEL_BVH_PLOC);
+                (void)hipEventRecord(e1, nullptr);
+                (void)hipEventSynchronize(e1);
+                float ms = 0.0f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (build_ms)
+                    *build_ms = ms;
+            }
+            if (!rc && hipMemcpy(built.data(), out.nodes, sizeof(Node64)*((size_t)P - 1), hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail("rebuild_scene: read-back failed");
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            // the builder's own allocation for this tree: the arena takes a copy
+            for (size_t k = allocsBefore; k < r->lbvhAllocs.size(); ++k)
+                (void)hipFree(r->lbvhAllocs[k]);
+            r->lbvhAllocs.resize(allocsBefore);
+            (void)hipFree(itemsDev);
+            if (rc)
+                return rc;
+            // root box: the union of its children's
+            const Node64& rt = built[0];
+            ref.reserve((size_t)2*P - 1);
+            ref.push_back(tinsel_bvh_node());
+            node64_to_reference(built, 0u, minT(rt.lminx, rt.rminx), minT(rt.lminy, rt.rminy), minT(rt.lminz, rt.rminz),
+                                maxT(rt.lmaxx, rt.rmaxx), maxT(rt.lmaxy, rt.rmaxy), maxT(rt.lmaxz, rt.rmaxz), ref, 0u);
+        }
+    }
+
+    // from here on as at create: validate, convert, leaf boxes by primitive, stack depth
+    ConvertedBvh sceneBvh;
+    if (!convert_bvh(ref.data(), (int)ref.size(), P, 0, sceneBvh))
+        return fail("rebuild_scene: malformed scene BVH");
+    if ((int)sceneBvh.nodes.size() != (P > 1 ? P - 1 : 0))
+        return fail("rebuild_scene: the scene BVH must have one leaf per primitive");
+    std::vector<PrimBox> boxes((size_t)P);
+    std::vector<char> seen((size_t)P, 0);
+    for (const tinsel_bvh_node& nd : ref)
+        if (ref_is_leaf(nd) && nd.left_index < (uint32_t)P)
+        {
+            boxes[nd.left_index] = make_prim_box(nd);
+            seen[nd.left_index] = 1;
+        }
+    for (int k = 0; k < P; ++k)
+        if (!seen[(size_t)k])
+            return fail("rebuild_scene: a primitive has no leaf in the scene BVH");
+    int maxMeshNeed = 0;
+    for (const DevMesh& dm : r->meshesNow)
+        maxMeshNeed = std::max(maxMeshNeed, dm.stackNeed);
+    const int stack = pick_stack(sceneBvh.maxLeafDepth + 1 + maxMeshNeed);
+    if (stack < 0 || ((size_t)stack*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes > (size_t)r->sharedMemLimit)
+        return fail("rebuild_scene: tree too deep for the LDS traversal stack (previous tree kept)");
+
+    unsigned char* arenaDev = const_cast<unsigned char*>(r->scene.arena);
+    if (!sceneBvh.nodes.empty())
+        HIP_TRY(hipMemcpy(arenaDev + r->arenaOffNodes, sceneBvh.nodes.data(), sizeof(Node64)*sceneBvh.nodes.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(arenaDev + r->arenaOffBoxes, boxes.data(), sizeof(PrimBox)*(size_t)P, hipMemcpyHostToDevice));
+    r->scene.root = sceneBvh.root;
+    r->sceneStackNeed = sceneBvh.maxLeafDepth + 1;
+    r->stackNeed = stack;
+    r->sceneBvhHost = ref;
+    r->sceneDirty = false;
     return 0;
 }
 

@@ -82,32 +82,6 @@ struct WalkJob
 #define TN_WP_FLUSH
 #endif
 
-// IntersectRayAABBFast (intersection.h:373-397) with hardware min/max.  Only for rays whose 1/d is finite in
-// all three components: then every product below is finite or +-inf, never NaN, and v_min/v_max return what the
-// reference's ternaries return up to the sign of a zero, which no comparison below or in the caller can see.
-TN_D bool ray_aabb_minmax(V3 pos, V3 rcp, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t)
-{
-    float l1 = (minx - pos.x)*rcp.x;
-    float l2 = (maxx - pos.x)*rcp.x;
-    float lmin = fminf(l1, l2);
-    float lmax = fmaxf(l1, l2);
-
-    l1 = (miny - pos.y)*rcp.y;
-    l2 = (maxy - pos.y)*rcp.y;
-    lmin = fmaxf(fminf(l1, l2), lmin);
-    lmax = fminf(fmaxf(l1, l2), lmax);
-
-    l1 = (minz - pos.z)*rcp.z;
-    l2 = (maxz - pos.z)*rcp.z;
-    lmin = fmaxf(fminf(l1, l2), lmin);
-    lmax = fminf(fmaxf(l1, l2), lmax);
-
-    t = lmin;
-    return (lmax >= 0.f) & (lmax >= lmin);
-}
-
-TN_D bool finite_bits(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
-
 // The walked meshes live in HBM by definition: say so to the compiler (a pointer read out of the mesh table is a
 // generic one to it, and generic loads are flat_load + a wait on both counters).
 typedef float WalkF4 __attribute__((ext_vector_type(4)));

@@ -91,6 +91,9 @@ def load_library():
         L.tinsel_hip_queue_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
     L.tinsel_hip_set_lookahead.argtypes = [vp, ci]
     L.tinsel_hip_refit_mesh.argtypes = [vp, ci, vp, ci, vp]
+    if hasattr(L, "tinsel_hip_rebuild_scene"):         # absent from older builds loaded through TINSEL_HIP_LIB for an A/B
+        L.tinsel_hip_set_primitive_transform.argtypes = [vp, ci, C.POINTER(abi.Transform), C.POINTER(abi.Transform)]
+        L.tinsel_hip_rebuild_scene.argtypes = [vp, ci, vp, ci, C.POINTER(C.c_double)]
     L.tinsel_hip_set_probe_sampling.argtypes = [vp, ci]
     L.tinsel_hip_set_arithmetic.argtypes = [vp, ci]
     L.tinsel_hip_get_arithmetic.argtypes = [vp]
@@ -123,6 +126,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
     "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_russian_roulette", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
     "tinsel_hip_walked_prims", "tinsel_hip_queue_counts", "tinsel_hip_set_lookahead", "tinsel_hip_set_arithmetic", "tinsel_hip_get_arithmetic", "tinsel_hip_refit_mesh", "tinsel_hip_set_probe_sampling",
+    "tinsel_hip_set_primitive_transform", "tinsel_hip_rebuild_scene",
     "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
     "tinsel_hip_group_size", "tinsel_hip_group_member", "tinsel_hip_group_set_lookahead", "tinsel_hip_ubench",
     "tinsel_hip_selftest_arith", "tinsel_hip_plan_regions",
@@ -257,6 +261,22 @@ class HipRenderer:
             nptr = normals.ctypes.data_as(C.c_void_p)
         _check(self._L.tinsel_hip_refit_mesh(self._h, int(primitive), positions.ctypes.data_as(C.c_void_p), int(positions.shape[0]), nptr),
                "tinsel_hip_refit_mesh")
+
+    def set_primitive_transform(self, index, start, end=None):
+        """Primitive `index` moves: new start / end transforms (abi.Transform; end defaults to start).  Follow with rebuild_scene()."""
+        end = start if end is None else end
+        _check(self._L.tinsel_hip_set_primitive_transform(self._h, int(index), C.byref(start), C.byref(end)), "tinsel_hip_set_primitive_transform")
+
+    def rebuild_scene(self, nodes=None):
+        """The scene-level BVH from the primitives as they are now: from `nodes` (a ctypes array of abi.BVHNode, e.g. the reference's own
+        Scene::Build -- bit-identical to a fresh renderer) or, without, built on the device.  Returns the device build time in ms."""
+        ms = C.c_double(0.0)
+        if nodes is None:
+            rc = self._L.tinsel_hip_rebuild_scene(self._h, abi.SCENE_BVH_DEVICE, None, 0, C.byref(ms))
+        else:
+            rc = self._L.tinsel_hip_rebuild_scene(self._h, abi.SCENE_BVH_NODES, C.cast(nodes, C.c_void_p), len(nodes), C.byref(ms))
+        _check(rc, "tinsel_hip_rebuild_scene")
+        return ms.value
 
     def set_probe_sampling(self, mode):
         """abi.PROBE_CDF (the reference's binary searches: sample-identical) or abi.PROBE_ALIAS (O(1) alias table: same distribution)."""
