@@ -37,6 +37,9 @@ SCENES = {
     "furnace": ("data/furnace.tin", 32, 32, 2, 32),
     "emitter": ("data/emitter.tin", 48, 48, 2, None),
     "gloss": ("data/gloss.tin", 64, 64, 3, None),
+    # the reference's own motion-blur scene: the octopus mesh (10,214 triangles, in HBM: walked by k_walk) turns half a revolution about y
+    # while the shutter is open (motionblur.tin:16-17, 68), a sphere light with 10 samples
+    "motionblur": ("data/motionblur.tin", 64, 64, 3, None),
     "features": (os.path.join(HERE, "scenes", "features.tin"), 96, 64, 4, None),
     # 203 primitives: scene-level BVH walk instead of the flat scan, arena too large for LDS (HBM-resident scene)
     "many_spheres": (os.path.join(HERE, "scenes", "many_spheres.tin"), 128, 96, 3, None),

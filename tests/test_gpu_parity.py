@@ -22,7 +22,7 @@ from tests.oracle_api import GOLDEN, image_l2
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell", "veach", "glass", "simple", "conservation", "furnace", "emitter", "gloss", "features",
-          "features_probe", "cornell_probe", "ajax_standin_96", "many_spheres", "one_sphere"]
+          "features_probe", "cornell_probe", "ajax_standin_96", "many_spheres", "one_sphere", "motionblur"]
 
 
 def _load(name):

@@ -18,7 +18,7 @@ SETTINGS = [
     {"TINSEL_HIP_BOUNCE_LAUNCHES": "per"}, {"TINSEL_HIP_BOUNCE_LAUNCHES": "per", "TINSEL_HIP_NO_REGION_ORDER": "1"},
     {"TINSEL_HIP_BOUNCE_GROUP_STEP": "0"}, {"TINSEL_HIP_BOUNCE_SHARE": "0"}, {"TINSEL_HIP_BOUNCE_SHARE": "1"}, {"TINSEL_HIP_BOUNCE_SHARE_LEN": "0"},
     {"TINSEL_HIP_REPACK": "0"}, {"TINSEL_HIP_REPACK": "1"}, {"TINSEL_HIP_REPACK": "1", "TINSEL_HIP_BOUNCE_SHARE": "1"},
-    {"TINSEL_HIP_SHADE_SORTED": "1"}, {"TINSEL_HIP_LIGHTS_IN_EXTEND": "0"},
+    {"TINSEL_HIP_SHADE_SORTED": "1"}, {"TINSEL_HIP_SHADE_SORTED": "0"}, {"TINSEL_HIP_LIGHTS_IN_EXTEND": "0"},
     {"TINSEL_HIP_NO_SCENE_WALK": "1"}, {"TINSEL_HIP_SWALK_NO_LDS": "1"}, {"TINSEL_HIP_SWALK_REFILL": "8", "TINSEL_HIP_SWALK_LEAFMIN": "1"},
     {"TINSEL_HIP_SWALK_GRID_MULT": "4", "TINSEL_HIP_SWALK_LIST_STEP": "1"},
     {"TINSEL_HIP_NO_LDS_SCENE": "1"}, {"TINSEL_HIP_NO_LDS_TEMPLATE": "1"}, {"TINSEL_HIP_ARENA_LDS_LIMIT": "1024"},

@@ -537,7 +537,7 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
     memset(&ss, 0, sizeof(ss));
     for (int b = 0; b < 2; ++b)
         if (batch_alloc(r, &ss.rayO[b], cap) || batch_alloc(r, &ss.rayD[b], cap) || batch_alloc(r, &ss.thr[b], cap) ||
-            batch_alloc(r, &ss.rad[b], cap) || batch_alloc(r, &ss.absorb[b], r->scene.hasMedia ? cap : 1) || batch_alloc(r, &ss.rngId[b], cap))
+            batch_alloc(r, &ss.rad[b], cap) || batch_alloc(r, &ss.rngId[b], cap))
             return -1;
     if (batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)) ||
         batch_alloc(r, &r->regionOrder, maxRegions/(kBlock/kWave)) || batch_alloc(r, &r->regionOrderNee, maxRegions/(kBlock/kWave)))
@@ -1498,8 +1498,14 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             }
             {
                 ScopedTimer t(r, KN_SHADE, st);
-                // TINSEL_HIP_SHADE_SORTED=1 (A/B): k_shade_sorted takes a region's paths class by class (tn_kernels.h)
-                static const bool shadeSorted = getenv("TINSEL_HIP_SHADE_SORTED") && atoi(getenv("TINSEL_HIP_SHADE_SORTED")) != 0;
+                // k_shade_sorted takes a region's paths class by class (tn_kernels.h): chosen PER SCENE.  It pays where a good share of a
+                // bounce's paths are rays that LEFT the scene (a cheap class that otherwise idles through its wave-mates' shading) and the
+                // path state is not already ordered by k_walk's front / back split: many_spheres 2087 -> 2122 Msamples/s, and in the split
+                // pipeline veach 1902 -> 2003, features 1047 -> 1093; it loses in an enclosed scene (glass: no ray leaves, 17.5 -> 19.3 ms) and
+                // where k_walk runs (the 524k-triangle config 6.47 -> 6.86 ms) (profiles/r03_g_ab_shade_sorted.txt, r04_e_rates.md).
+                // TINSEL_HIP_SHADE_SORTED=0 / 1 forces either arm (A/B, tests).
+                static const char* sortedEnv = getenv("TINSEL_HIP_SHADE_SORTED");
+                const bool shadeSorted = sortedEnv ? atoi(sortedEnv) != 0 : (!r->sceneEnclosed && !walk);
                 a.grid = gridPersist;
                 a.shadeSorted = shadeSorted ? 1 : 0;
                 a.ldsBytes = ldsShade + (shadeSorted ? (uint32_t)(kShadeListWords*sizeof(uint32_t)) : 0u);

@@ -32,6 +32,10 @@ struct PathRegs
     V3 absorption;      // rayAbsorption
     float bsdfPdf;
     int rayType;        // BSDFType of the last bounce
+    // Where rayAbsorption came from: it is never anything but 0 (outside) or the absorption of the material the path entered last
+    // (render.cpp:259-269, 346-351) -- the primitive's index, or -1.  The wavefront pipelines keep THIS in their path state (4 B in a
+    // record's spare word) instead of the 16-B vector, and read the vector back out of the material table.
+    int medium;
 };
 
 // render.cpp:233-248
@@ -45,6 +49,7 @@ TN_D void path_begin(PathRegs& p, V3 o, V3 d, float time, Rng rng)
     p.absorption = V3(0.0f);
     p.bsdfPdf = 1.0f;
     p.rayType = kReflected;
+    p.medium = -1;
 }
 
 struct HitCtx
@@ -54,20 +59,23 @@ struct HitCtx
     V3 wo;              // -rayDir
     float etaI, etaO;   // rayEta, outEta
     V3 outAbsorption;
+    int outMedium;      // the primitive outAbsorption belongs to (entering: the hit one), or -1 (leaving: 0)
 };
 
 // render.cpp:255-310.  `bounce` is the loop index i.
-TN_D void on_hit_begin(PathRegs& p, const Mat& mat, float t, V3 n, int bounce, HitCtx& h)
+TN_D void on_hit_begin(PathRegs& p, const Mat& mat, float t, V3 n, int bounce, HitCtx& h, int prim = -1)
 {
     if (p.eta == 1.0f)
     {
         h.etaO = mat.ior;
         h.outAbsorption = mat.absorption;
+        h.outMedium = prim;
     }
     else
     {
         h.etaO = 1.0f;
         h.outAbsorption = V3(0.0f);
+        h.outMedium = -1;
     }
     h.etaI = p.eta;
 
@@ -312,6 +320,7 @@ TN_D int bsdf_step(PathRegs& p, const Mat& mat, const HitCtx& h)
     {
         p.eta = h.etaO;
         p.absorption = h.outAbsorption;
+        p.medium = h.outMedium;
     }
 
     // pathThroughput *= f * Abs(Dot(n, bsdfDir))/bsdfPdf   (Vec3/Real == a*(1.0/s), maths.h:242)

@@ -154,6 +154,32 @@ TN_D bool ray_plane(V3 p, V3 dir, float px, float py, float pz, float pw, float&
     return t > 0.0f;
 }
 
+// IntersectRayPlane for a closest-hit scan that already holds a hit at `bound`: the same answer wherever the answer can matter, without
+// the IEEE division (a dozen instructions; a flat scan of cornell's five planes made ten per round) where it cannot --
+//   * t = -num/d > 0 needs num and d of opposite signs: a quotient's sign is exact, and +-0 is not > 0;
+//   * a plane farther than `bound` by more than the scan's tie window (trace_flat: 1e-5 relative) neither becomes the closest hit nor
+//     raises the tie flag: |num| * v_rcp(|d|) is within 2^-21 of |num/d|, the margin is 4e-5.
+// bound == FLT_MAX (every caller but the flat scan): IntersectRayPlane as it is.
+#ifndef TN_PLANE_PRUNE
+#define TN_PLANE_PRUNE 1
+#endif
+TN_D bool ray_plane_bounded(V3 p, V3 dir, float px, float py, float pz, float pw, float bound, float& t)
+{
+    float d = px*dir.x + py*dir.y + pz*dir.z + pw*0.0f;
+    if (d == 0.0f)
+        return false;
+    const float num = px*p.x + py*p.y + pz*p.z + pw*1.0f;
+    if (TN_PLANE_PRUNE && bound < kFltMax)
+    {
+        if (((num > 0.0f) == (d > 0.0f)) || num == 0.0f)
+            return false;
+        if (fabsf(num)*__builtin_amdgcn_rcpf(fabsf(d)) > bound*1.00004f)
+            return false;
+    }
+    t = -num/d;
+    return t > 0.0f;
+}
+
 // IntersectRayTriTwoSided (intersection.h:117-145)
 TN_D bool ray_tri(V3 p, V3 dir, V3 a, V3 b, V3 c, float& t, float& u, float& v, float& w, float& sign, V3& n)
 {
@@ -351,8 +377,11 @@ TN_D Prim64 load_prim_uniform(ConstF4 prims, int idx)
 
 // PrimitiveIntersect (intersection.h:951-1020)
 // UNIFORM: `index` is the same in every lane (the flat scan's loop counter)
+// `bound`: the closest hit a scene-level SCAN already holds (trace_flat) -- lets a plane skip its division where it cannot matter
+// (ray_plane_bounded); every other caller leaves it at FLT_MAX.
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false, bool UNIFORM = false>
-TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f)
+TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f,
+                         float bound = kFltMax)
 {
     const Prim64 p = UNIFORM ? load_prim_uniform(sc.kPrims, index) : load_prim(sc.prims, index);
     if (COUNT) ctr.prims++;
@@ -360,7 +389,7 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
     if (p.type == kPrimPlane)
     {
         // the reference interpolates the pose here too but the plane test never reads it
-        bool hit = ray_plane(o, d, p.g0, p.g1, p.g2, p.g3, outT);
+        bool hit = ray_plane_bounded(o, d, p.g0, p.g1, p.g2, p.g3, bound, outT);
         if (hit)
             outN = V3(p.g0, p.g1, p.g2);
         return hit;
@@ -486,7 +515,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
         }
         float t;
         V3 n;
-        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop);
+        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, minT);
 #ifdef TN_PROFILE_TRACE
         { const uint32_t ty = __builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float4*>(sc.prims + i)[3].x)); TN_TTICK(ctr, ty == kPrimPlane ? 1 : ty == kPrimSphere ? 2 : 3) }
 #endif

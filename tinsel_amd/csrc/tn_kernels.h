@@ -294,8 +294,7 @@ struct SplitState
     float4* rayD[2];    // dir.xyz, bsdfPdf
     float4* thr[2];     // throughput.xyz, rayEta
     float4* rad[2];     // radiance.xyz, rayType (int bits)
-    float4* absorb[2];  // rayAbsorption.xyz, -          (scenes with absorbing media only)
-    float4* rngId[2];   // rng.s1, rng.s2, path slot (bits), -
+    float4* rngId[2];   // rng.s1, rng.s2, path slot (bits), the medium the ray travels in (PathRegs::medium: a primitive index as bits, -1 = none)
     float4* hit;        // [position] this bounce's closest hit: t, n.xyz
     int32_t* hitPrim;
     uint32_t* pathNee;  // [position] NEE position q of the path's shadow rays of this bounce
@@ -352,29 +351,37 @@ struct RegionAppend
 
 constexpr uint32_t kRegionsPerBlock = kBlock/kWave;
 
-TN_D void load_state(const SplitState& ss, int buf, uint32_t pos, PathRegs& p, uint32_t& slot, bool hasMedia)
+// rayAbsorption of a path whose state says which medium it is in: the material's own vector (what on_hit_begin copied when the path
+// entered, render.cpp:262-263), or 0.  Scenes without an absorbing material never look.
+TN_D V3 medium_absorption(const DevScene& sc, int medium, bool hasMedia)
+{
+    if (!hasMedia || medium < 0)
+        return V3(0.0f);
+    const float4 c = reinterpret_cast<const float4*>(sc.mats + medium)[2];
+    return V3(c.x, c.y, c.z);
+}
+
+TN_D void load_state(const DevScene& sc, const SplitState& ss, int buf, uint32_t pos, PathRegs& p, uint32_t& slot, bool hasMedia)
 {
     const float4 ro = ss.rayO[buf][pos], rd = ss.rayD[buf][pos], th = ss.thr[buf][pos], ra = ss.rad[buf][pos];
-    const float4 ab = hasMedia ? ss.absorb[buf][pos] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const float4 rr = ss.rngId[buf][pos];
     p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
     p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
     p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
     p.rad = V3(ra.x, ra.y, ra.z); p.rayType = __float_as_int(ra.w);
-    p.absorption = V3(ab.x, ab.y, ab.z);
     p.rng.s1 = __float_as_uint(rr.x); p.rng.s2 = __float_as_uint(rr.y);
     slot = __float_as_uint(rr.z);
+    p.medium = __float_as_int(rr.w);
+    p.absorption = medium_absorption(sc, p.medium, hasMedia);
 }
 
-TN_D void store_state(const SplitState& ss, int buf, uint32_t pos, const PathRegs& p, uint32_t slot, bool hasMedia)
+TN_D void store_state(const SplitState& ss, int buf, uint32_t pos, const PathRegs& p, uint32_t slot)
 {
     ss.rayO[buf][pos] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
     ss.rayD[buf][pos] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
     ss.thr[buf][pos] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
     ss.rad[buf][pos] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
-    if (hasMedia)
-        ss.absorb[buf][pos] = make_float4(p.absorption.x, p.absorption.y, p.absorption.z, 0.0f);
-    ss.rngId[buf][pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), 0.0f);
+    ss.rngId[buf][pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), __int_as_float(p.medium));
 }
 
 // ---------------------------------------------------------------------------
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(kOrderBlock) void k_region_order(const uint32_t* __
 // is skipped this round.  A region thus runs ceil(hits/64) shading rounds instead of one per trace round, no barrier, no
 // atomic; a path's arithmetic does not know which lane runs it, so no result changes.  Layout: pool[field][entry], one
 // dword per field, consecutive lanes on consecutive entries.
-constexpr int kPoolFields = 27;
+constexpr int kPoolFields = 28;
 constexpr int kPoolWordsPerWave = kPoolFields*kWave;
 constexpr int kPoolWords = kPoolWordsPerWave*(kBlock/kWave);     // per workgroup: 27 KB
 
@@ -448,6 +455,7 @@ TN_D void pool_store(uint32_t* pool, uint32_t e, const PathRegs& p, uint32_t slo
     q[22*kWave] = (uint32_t)prim;
     q[23*kWave] = __float_as_uint(t);
     q[24*kWave] = __float_as_uint(n.x); q[25*kWave] = __float_as_uint(n.y); q[26*kWave] = __float_as_uint(n.z);
+    q[27*kWave] = (uint32_t)p.medium;
 }
 
 TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slot, int& prim, float& t, V3& n)
@@ -467,6 +475,7 @@ TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slo
     prim = (int)q[22*kWave];
     t = __uint_as_float(q[23*kWave]);
     n = V3(__uint_as_float(q[24*kWave]), __uint_as_float(q[25*kWave]), __uint_as_float(q[26*kWave]));
+    p.medium = (int)q[27*kWave];
 }
 
 // ---------------------------------------------------------------------------
@@ -622,7 +631,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                     }
                     else
                         pos = region_pos(base, rLen, nFront, j);
-                    load_state(ss, cur, pos, p, slot, hasMedia);
+                    load_state(sc, ss, cur, pos, p, slot, hasMedia);
                     have = true;
                 }
             }
@@ -674,7 +683,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                     const V3 n = n3;
                     const Mat mat = load_mat(sc.mats, prim);
                     HitCtx h;
-                    on_hit_begin(p, mat, t, n, bounce, h);
+                    on_hit_begin(p, mat, t, n, bounce, h, prim);
 
                     if (sc.totalLightSamples > 0)
                     {
@@ -731,7 +740,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
             }
             const uint32_t np = out.push(alive, front);
             if (alive)
-                store_state(ss, nxt, np, p, slot, hasMedia);
+                store_state(ss, nxt, np, p, slot);
             if (flush)
                 break;
         }
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(SplitState ss, QueueCtl 
                 // ray and RNG only: the rest of a fresh path's state is constant and k_shade knows it (ShadeFetch::issue)
                 ss.rayO[0][pos] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
                 ss.rayD[0][pos] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
-                ss.rngId[0][pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), 0.0f);
+                ss.rngId[0][pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), __int_as_float(-1));
             }
         }
         if (lane == 0)
@@ -1123,7 +1132,7 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
 #endif
 struct ShadeFetch
 {
-    float4 ro, rd, th, ra, ab, rr, hh;
+    float4 ro, rd, th, ra, rr, hh;
     int prim;
     uint32_t qn;
 
@@ -1138,12 +1147,10 @@ struct ShadeFetch
         {
             th = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             ra = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(kReflected));
-            ab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         else
         {
             th = ss.thr[buf][pos]; ra = ss.rad[buf][pos];
-            ab = hasMedia ? ss.absorb[buf][pos] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         rr = ss.rngId[buf][pos];
         hh = ss.hit[pos];
@@ -1151,15 +1158,17 @@ struct ShadeFetch
         qn = hasNee ? ss.pathNee[pos] : 0u;
     }
 
+    // (the medium's absorption is the caller's to look up: medium_absorption)
     TN_D void unpack(PathRegs& p, uint32_t& slot) const
     {
         p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
         p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
         p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
         p.rad = V3(ra.x, ra.y, ra.z); p.rayType = __float_as_int(ra.w);
-        p.absorption = V3(ab.x, ab.y, ab.z);
+        p.absorption = V3(0.0f);
         p.rng.s1 = __float_as_uint(rr.x); p.rng.s2 = __float_as_uint(rr.y);
         slot = __float_as_uint(rr.z);
+        p.medium = __float_as_int(rr.w);
     }
 };
 
@@ -1172,6 +1181,7 @@ TN_D bool shade_path(const SC& sc, const SplitState& ss, const ShadeFetch& f, in
     const int K = ss.neePerPath;
     bool alive = false;
     f.unpack(p, slot);
+    p.absorption = medium_absorption(sc, p.medium, sc.hasMedia != 0);
     const int prim = f.prim;
     if (prim < 0)
     {
@@ -1183,7 +1193,7 @@ TN_D bool shade_path(const SC& sc, const SplitState& ss, const ShadeFetch& f, in
         const Mat mat = load_mat(sc.mats, prim);
 
         HitCtx h;
-        on_hit_begin(p, mat, hh.x, V3(hh.y, hh.z, hh.w), bounce, h);
+        on_hit_begin(p, mat, hh.x, V3(hh.y, hh.z, hh.w), bounce, h, prim);
 
         // SampleLights, after the traces (render.cpp:118-139, 171-224): k_shadow left, per shadow ray, the primitive
         // whose emission arrives; the BSDF terms are evaluated for those rays only
@@ -1273,7 +1283,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
                 alive = shade_path(sc, ss, f, bounce, maxDepth, rrStart, bp, p, slot, front);
             const uint32_t np = out.push(alive, front);
             if (alive)
-                store_state(ss, nxt, np, p, slot, hasMedia);
+                store_state(ss, nxt, np, p, slot);
         }
         if (lane == 0)
         {
@@ -1400,7 +1410,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade_sorted(DevScen
                 alive = shade_path(sc, ss, f, bounce, maxDepth, rrStart, bp, p, slot, front);
             const uint32_t np = out.push(alive, front);
             if (alive)
-                store_state(ss, nxt, np, p, slot, hasMedia);
+                store_state(ss, nxt, np, p, slot);
         }
         if (lane == 0)
         {
@@ -1546,7 +1556,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_FUSED) void k_mega(DevScene scIn, 
 
                 const Mat mat = load_mat(sc.mats, prim);
                 HitCtx h;
-                on_hit_begin(p, mat, t, n, bounce, h);
+                on_hit_begin(p, mat, t, n, bounce, h, prim);
 
                 // SampleLights (render.cpp:103-227): draw, trace, and the BSDF terms for the samples that arrive
                 {
