@@ -182,6 +182,17 @@ bool convert_bvh(const tinsel_bvh_node* ref, int numNodes, int numItems, int top
 // ---------------------------------------------------------------------------
 // material digestion: every material-only sub-expression, in the reference's own precision
 
+// the MIS constants of a (light) primitive, divided here once with the reference's fp32 expressions (tn_scene.h Mat128); again whenever
+// PrimitiveArea changes (refit, a moved mesh light)
+void set_light_constants(Mat128& m)
+{
+    m.rcpArea = 1.0f/m.area;                                                // (1.0f/lightArea), render.cpp:182, 292
+    m.rcpLightSamples = 1.0f/(float)m.lightSamples;                         // (1.0f/numSamples), :223
+    const int N = (int)((float)m.lightSamples + 1.0f);                      // lightSamples + kBsdfSamples, :209, :296
+    m.cbsdf = 1.0f/(float)N;                                                // kBsdfSamples/N
+    m.clight = (float)m.lightSamples/(float)N;
+}
+
 void make_material(const tinsel_primitive& p, Mat128& m)
 {
     const tinsel_material& a = p.material;
@@ -235,6 +246,7 @@ void make_material(const tinsel_primitive& p, Mat128& m)
         m.area = 0.0f;
 
     m.lightSamples = p.light_samples;
+    set_light_constants(m);
 }
 
 // the leaf box of a primitive as the flat scan reads it
@@ -2803,7 +2815,9 @@ int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_x
         if (r->primMesh[(size_t)p] == mi)
         {
             const float area = totalArea*r->primEndScale[(size_t)p];          // intersection.h:843-847
+            const float rcpArea = 1.0f/area;
             HIP_TRY(hipMemcpy((void*)&r->scene.mats[p].area, &area, sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy((void*)&r->scene.mats[p].rcpArea, &rcpArea, sizeof(float), hipMemcpyHostToDevice));
         }
 
     // The scene level follows: Scene::Build (scene.cpp:4-16) gives the scene BVH builder PrimitiveBounds(p) (intersection.h:906-939)
@@ -2900,7 +2914,9 @@ int tinsel_hip_set_primitive_transform(tinsel_hip* r, int index, const tinsel_tr
     {
         // PrimitiveArea of a mesh: area*endTransform.s (intersection.h:843-847)
         const float area = r->meshArea[(size_t)r->primMesh[(size_t)index]]*xe.s;
+        const float rcpArea = 1.0f/area;
         HIP_TRY(hipMemcpy(arenaDev + r->arenaOffMats + sizeof(Mat128)*(size_t)index + offsetof(Mat128, area), &area, sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(arenaDev + r->arenaOffMats + sizeof(Mat128)*(size_t)index + offsetof(Mat128, rcpArea), &rcpArea, sizeof(float), hipMemcpyHostToDevice));
     }
     r->sceneDirty = true;
     return 0;

@@ -15,12 +15,13 @@ struct Mat
     V3 emission, color, absorption, cspec0, sqrtColor;
     float ior, metallic, subsurface, roughness, transmission, clearcoat, clearcoatAlpha, clearcoatA2, clearcoatLogA2, area;
     int lightSamples;
+    float rcpArea, rcpLightSamples, cbsdf, clight;      // Mat128: the MIS constants divided on the host
 };
 
 TN_D Mat load_mat(const Mat128* mats, int idx)
 {
     const float4* p = reinterpret_cast<const float4*>(mats + idx);
-    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6];
+    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7];
     Mat m;
     m.emission = V3(a.x, a.y, a.z); m.ior = a.w;
     m.color = V3(b.x, b.y, b.z); m.metallic = b.w;
@@ -29,6 +30,7 @@ TN_D Mat load_mat(const Mat128* mats, int idx)
     m.sqrtColor = V3(e.x, e.y, e.z); m.transmission = e.w;
     m.clearcoat = f.x; m.clearcoatAlpha = f.y; m.area = f.z; m.lightSamples = __float_as_int(f.w);
     m.clearcoatA2 = g.x; m.clearcoatLogA2 = g.y;
+    m.rcpArea = g.z; m.rcpLightSamples = g.w; m.cbsdf = h.x; m.clight = h.y;
     return m;
 }
 

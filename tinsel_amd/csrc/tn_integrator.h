@@ -100,11 +100,11 @@ TN_D void on_hit_begin(PathRegs& p, const Mat& mat, float t, V3 n, int bounce, H
         float lightArea = mat.area;
         if (lightArea > 0.0f)
         {
-            float lightPdf = (rcpf_cr(lightArea)*t*t)/clampT(dot(-p.d, n), 1.e-3f, 1.0f);
+            // (1.0f/lightArea, kBsdfSamples/N and float(lightSamples)/N with N = lightSamples + kBsdfSamples: the host's, Mat128)
+            float lightPdf = (mat.rcpArea*t*t)/clampT(dot(-p.d, n), 1.e-3f, 1.0f);
 
-            int N = int(float(mat.lightSamples) + kBsdfSamples);
-            float cbsdf = kBsdfSamples/N;
-            float clight = float(mat.lightSamples)/N;
+            float cbsdf = mat.cbsdf;
+            float clight = mat.clight;
             float weight = cbsdf*p.bsdfPdf/(cbsdf*p.bsdfPdf + clight*lightPdf);
 
             if (p.rayType == kSpecular)
@@ -207,17 +207,14 @@ TN_D V3 nee_contrib_light(const DevScene& sc, const Mat& surf, const HitCtx& h, 
 {
     V3 L(0.0f);
     const Mat128* lm = sc.mats + light;
-    const float lightArea = lm->area;
-    const int lightSamples = lm->lightSamples;
     float tSq = t*t;
-    float lightPdf = (rcpf_cr(lightArea)*tSq)/nl;
+    float lightPdf = (lm->rcpArea*tSq)/nl;          // ((1.0f/lightArea)*t*t)/nl, the reciprocal divided on the host (Mat128)
 
     const float bsdfPdf = bsdf_pdf(surf, h.etaI, h.etaO, h.n, h.wo, wi);
     if (bsdfPdf > 0.0f)
     {
-        int N = int(float(lightSamples) + kBsdfSamples);
-        float cbsdf = kBsdfSamples/N;
-        float clight = float(lightSamples)/N;
+        float cbsdf = lm->cbsdf;                    // kBsdfSamples/N, float(lightSamples)/N: the host's (Mat128)
+        float clight = lm->clight;
         float weight = clight*lightPdf/(cbsdf*bsdfPdf + clight*lightPdf);
 
         const V3 f = bsdf_eval(surf, h.etaI, h.etaO, h.n, h.wo, wi);
@@ -289,7 +286,7 @@ TN_D V3 nee_sum(const DevScene& sc, Contrib contrib)
         V3 L(0.0f);
         for (int s = 0; s < numSamples; ++s)
             L = L + contrib(k++);
-        sum = sum + L*rcpf_cr(numSamples);                    // render.cpp:223
+        sum = sum + L*sc.mats[sc.lights[li]].rcpLightSamples;     // L*(1.0f/numSamples), render.cpp:223: divided on the host (Mat128)
     }
     return sum;
 }

@@ -155,13 +155,16 @@ TN_D bool ray_plane(V3 p, V3 dir, float px, float py, float pz, float pw, float&
 }
 
 // IntersectRayPlane for a closest-hit scan that already holds a hit at `bound`: the same answer wherever the answer can matter, without
-// the IEEE division (a dozen instructions; a flat scan of cornell's five planes made ten per round) where it cannot --
+// the IEEE division (a dozen instructions; a flat scan of cornell's five planes makes ten per round) where it cannot --
 //   * t = -num/d > 0 needs num and d of opposite signs: a quotient's sign is exact, and +-0 is not > 0;
 //   * a plane farther than `bound` by more than the scan's tie window (trace_flat: 1e-5 relative) neither becomes the closest hit nor
 //     raises the tie flag: |num| * v_rcp(|d|) is within 2^-21 of |num/d|, the margin is 4e-5.
 // bound == FLT_MAX (every caller but the flat scan): IntersectRayPlane as it is.
+// OFF (-DTN_PLANE_PRUNE=1 builds it in): bit-identical (the whole GPU suite ran with it), and it LOSES -- cornell 4177 -> 4014 Msamples/s,
+// cfg1 2745 -> 2648, veach 4K 2845 -> 2819 (profiles/r04_g_ab_plane_prune.md): the flat scan is wave-uniform, a lane-dependent early-out
+// saves the division only when all 64 lanes take it, and pays its exec-mask branches always.
 #ifndef TN_PLANE_PRUNE
-#define TN_PLANE_PRUNE 1
+#define TN_PLANE_PRUNE 0
 #endif
 TN_D bool ray_plane_bounded(V3 p, V3 dir, float px, float py, float pz, float pw, float bound, float& t)
 {

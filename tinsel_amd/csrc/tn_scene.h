@@ -114,7 +114,12 @@ struct alignas(128) Mat128
     int32_t lightSamples;
     float clearcoatA2;                      // a*a and logf(a*a) of GTR1 (disney.h:59-61), a = clearcoatAlpha
     float clearcoatLogA2;
-    float pad[6];
+    // per-light constants of the MIS weights, divided once on the host with the reference's own fp32 expressions instead of once per
+    // light sample and bounce on the device (an IEEE division is a dozen instructions): 1.0f/PrimitiveArea (render.cpp:182, 292),
+    // 1.0f/numSamples (:223), and with N = lightSamples + kBsdfSamples: kBsdfSamples/N, float(lightSamples)/N (:209-211, 296-298)
+    float rcpArea, rcpLightSamples;
+    float cbsdf, clight;
+    float pad[2];
 };
 static_assert(sizeof(Mat128) == 128, "Mat128");
 
