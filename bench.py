@@ -607,7 +607,9 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     if copy_gbs:
         common["stream_copy_GBs"] = copy_gbs
         common["frac_of_stream_copy"] = drow.get("frac_of_stream_copy")
-    wrow = next((r for r in kernels if r["kernel"] == "k_walk"), None)
+    # (only where k_walk is the dominant kernel: there it does ALL the mesh visits the device counters I, T count -- config 3; in a scene
+    # that also walks small meshes inline, glass, the per-ray constants are not k_walk's alone)
+    wrow = next((r for r in kernels if r["kernel"] == "k_walk"), None) if dom_name == "k_walk" else None
     if wrow and wrow["ms"] > 0:
         # what the walk is made of: Node64 visits (and triangle tests) per second, next to the record-chase rates this GPU
         # sustains on a table of the tree's size and on one that fits an XCD's L2 (tinsel_hip_ubench, this run)
