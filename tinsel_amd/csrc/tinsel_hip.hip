@@ -365,178 +365,6 @@ const char* kKernelNames[] = { "k_generate", "k_extend", "k_shade", "k_shadow", 
                                "k_present", "k_nlm_means", "k_nlm", "k_walk", "k_lights", "k_seg" };
 enum { KN_GENERATE = 0, KN_EXTEND, KN_SHADE, KN_SHADOW, KN_ACCUMULATE, KN_MEGA, KN_NORMALS, KN_BOUNCE, KN_PRESENT, KN_NLM_MEANS, KN_NLM, KN_WALK, KN_LIGHTS, KN_SEG, KN_COUNT };
 
-// ---------------------------------------------------------------------------
-// Full-frame read-back into a PAGEABLE host array (what the reference's caller hands Render: `new Color[w*h]`, main.cpp:73-87).
-// The runtime's own pageable copy stages through a pinned buffer on the calling thread, DMA and CPU copy taking turns: 16.8 MB in
-// 0.36 ms where a page-locked destination takes 0.305 (55 GB/s: this box's PCIe).  Here the DMA runs in chunks into a pinned staging
-// buffer the library owns, and a few host threads (the caller's among them) copy each chunk out to the caller's array as soon as its
-// event fires -- the CPU copy rides under the DMA, one chunk behind.  TINSEL_HIP_COPY_THREADS (default 8; 0 / 1: the runtime's copy),
-// TINSEL_HIP_COPY_CHUNK_KB (default 1024).  A destination that already is page-locked goes by one DMA as before.
-struct StagedCopy
-{
-    unsigned char* staging = nullptr;
-    size_t cap = 0;
-    std::vector<hipEvent_t> events;
-    std::vector<std::thread> workers;
-    std::mutex mu;
-    std::condition_variable cvWork, cvDone;
-    unsigned long long epoch = 0;
-    int pending = 0;
-    bool quit = false;
-    int device = 0;
-    // the job
-    unsigned char* dst = nullptr;
-    size_t bytes = 0, chunk = 0;
-    int chunks = 0, parts = 1;
-
-    void copy_part(int w)
-    {
-        for (int c = 0; c < chunks; ++c)
-        {
-            (void)hipEventSynchronize(events[(size_t)c]);
-            const size_t off = (size_t)c*chunk, len = std::min(chunk, bytes - off);
-            const size_t a = len*(size_t)w/(size_t)parts, b = len*(size_t)(w + 1)/(size_t)parts;
-            memcpy(dst + off + a, staging + off + a, b - a);
-        }
-    }
-
-    void worker(int w)
-    {
-        (void)hipSetDevice(device);
-        unsigned long long seen = 0;
-        for (;;)
-        {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cvWork.wait(lk, [&] { return quit || epoch != seen; });
-                if (quit)
-                    return;
-                seen = epoch;
-            }
-            copy_part(w);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                --pending;
-            }
-            cvDone.notify_one();
-        }
-    }
-
-    // false: not available (allocation refused, one thread asked for): the caller uses the runtime's copy
-    bool prepare(int dev, size_t nbytes)
-    {
-        static const int threads = getenv("TINSEL_HIP_COPY_THREADS") ? atoi(getenv("TINSEL_HIP_COPY_THREADS")) : 8;
-        static const size_t chunkBytes = (size_t)(getenv("TINSEL_HIP_COPY_CHUNK_KB") ? std::max(64, atoi(getenv("TINSEL_HIP_COPY_CHUNK_KB"))) : 1024) << 10;
-        if (threads < 2 || nbytes < (4u << 20))
-            return false;
-        device = dev;
-        if (cap < nbytes)
-        {
-            if (staging)
-                (void)hipHostFree(staging);
-            staging = nullptr;
-            cap = 0;
-            if (hipHostMalloc((void**)&staging, nbytes, hipHostMallocDefault) != hipSuccess)
-            {
-                (void)hipGetLastError();
-                return false;
-            }
-            cap = nbytes;
-        }
-        chunk = chunkBytes;
-        chunks = (int)((nbytes + chunk - 1)/chunk);
-        while (events.size() < (size_t)chunks)
-        {
-            hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
-                return false;
-            events.push_back(e);
-        }
-        parts = std::min(threads, 32);
-        while ((int)workers.size() < parts - 1)
-        {
-            const int w = (int)workers.size() + 1;          // part 0 is the calling thread's
-            workers.emplace_back([this, w] { worker(w); });
-        }
-        return true;
-    }
-
-    // device -> staging: the chunks' DMAs and their events, enqueued on `stream` (returns at once)
-    int begin(hipStream_t stream, const void* devSrc, size_t nbytes)
-    {
-        bytes = nbytes;
-        for (int c = 0; c < chunks; ++c)
-        {
-            const size_t off = (size_t)c*chunk, len = std::min(chunk, nbytes - off);
-            HIP_TRY(hipMemcpyAsync(staging + off, (const unsigned char*)devSrc + off, len, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipEventRecord(events[(size_t)c], stream));
-        }
-        return 0;
-    }
-
-    // staging -> the caller's array, chunk by chunk as the events fire, all threads; returns when `hostDst` is complete
-    void finish(void* hostDst)
-    {
-        dst = (unsigned char*)hostDst;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            pending = parts - 1;
-            ++epoch;
-        }
-        cvWork.notify_all();
-        copy_part(0);
-        std::unique_lock<std::mutex> lk(mu);
-        cvDone.wait(lk, [&] { return pending == 0; });
-    }
-
-    void shutdown()
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            quit = true;
-        }
-        cvWork.notify_all();
-        for (std::thread& t : workers)
-            t.join();
-        workers.clear();
-        for (hipEvent_t e : events)
-            (void)hipEventDestroy(e);
-        events.clear();
-        if (staging)
-            (void)hipHostFree(staging);
-        staging = nullptr;
-        cap = 0;
-    }
-};
-
-// is `p` page-locked host memory the runtime can DMA into directly?
-bool host_pointer_is_pinned(const void* p)
-{
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, p) != hipSuccess)
-    {
-        (void)hipGetLastError();        // an ordinary malloc'ed pointer: "invalid value"
-        return false;
-    }
-    return attr.type == hipMemoryTypeHost;
-}
-
-// one full-frame D2H, blocking: staged through `sc` when the destination is pageable and the copier is available, else the runtime's
-int frame_to_host(StagedCopy* sc, int device, hipStream_t stream, const void* devSrc, void* hostDst, size_t bytes)
-{
-    if (sc && !host_pointer_is_pinned(hostDst) && sc->prepare(device, bytes))
-    {
-        if (sc->begin(stream, devSrc, bytes))
-            return -1;
-        sc->finish(hostDst);
-        HIP_TRY(hipStreamSynchronize(stream));
-        return 0;
-    }
-    HIP_TRY(hipMemcpyAsync(hostDst, devSrc, bytes, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    return 0;
-}
-
 struct TimedSpan { int kernel; hipEvent_t start, stop; };
 
 } // namespace
@@ -659,8 +487,6 @@ struct tinsel_hip
     hipStream_t workStream = nullptr, copyStream = nullptr;
     void* pinnedPtr = nullptr;          // caller's output buffer, page-locked in place (hipHostRegister) for the D2H DMA
     size_t pinnedBytes = 0;
-
-    StagedCopy* hostCopy = nullptr;     // full-frame read-backs into pageable arrays (created on first use)
 
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -1984,22 +1810,8 @@ int lookahead_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_op
             (void)hipGetLastError();        // pageable copy below: still correct
     }
     const bool asyncCopy = r->pinnedPtr != nullptr;
-    // a pageable destination: the DMA into the library's pinned staging starts now (chunks + events on the copy stream); the host threads
-    // copy it out to the caller's array AFTER the next batch has been launched (StagedCopy, above)
-    StagedCopy* staged = nullptr;
     if (asyncCopy)
         HIP_TRY(hipMemcpyAsync(out_rgba, r->accum, bytes, hipMemcpyDeviceToHost, r->copyStream));
-    else if (!host_pointer_is_pinned(out_rgba))
-    {
-        if (!r->hostCopy)
-            r->hostCopy = new StagedCopy();
-        if (r->hostCopy->prepare(r->device, bytes))
-        {
-            staged = r->hostCopy;
-            if (staged->begin(r->copyStream, r->accum, bytes))
-                return -1;
-        }
-    }
 
     if (options->mode == TINSEL_MODE_PATHTRACE && options->max_depth >= 1)
     {
@@ -2014,9 +1826,7 @@ int lookahead_render(tinsel_hip* r, const tinsel_camera* camera, const tinsel_op
         }
     }
 
-    if (staged)
-        staged->finish(out_rgba);
-    else if (!asyncCopy)
+    if (!asyncCopy)
         HIP_TRY(hipMemcpyAsync(out_rgba, r->accum, bytes, hipMemcpyDeviceToHost, r->copyStream));
     HIP_TRY(hipStreamSynchronize(r->copyStream));
     return 0;
@@ -2643,12 +2453,6 @@ void tinsel_hip_destroy(tinsel_hip* r)
     (void)hipDeviceSynchronize();
     if (r->workStream) (void)hipStreamDestroy(r->workStream);
     if (r->copyStream) (void)hipStreamDestroy(r->copyStream);
-    if (r->hostCopy)
-    {
-        r->hostCopy->shutdown();
-        delete r->hostCopy;
-        r->hostCopy = nullptr;
-    }
     if (r->probeAlias) (void)hipFree(r->probeAlias);
     if (r->walkOverflow) (void)hipFree(r->walkOverflow);
     if (r->walkProf)
@@ -2773,9 +2577,8 @@ int tinsel_hip_read_accum(tinsel_hip* r, float* out_rgba)
         return fail("read_accum: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipDeviceSynchronize());
-    if (!r->hostCopy)
-        r->hostCopy = new StagedCopy();
-    return frame_to_host(r->hostCopy, r->device, nullptr, r->accum, out_rgba, sizeof(float4)*(size_t)r->width*r->height);
+    HIP_TRY(hipMemcpy(out_rgba, r->accum, sizeof(float4)*(size_t)r->width*r->height, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 // The display stage of the reference's frame loop (main.cpp:258-282) on the device accumulator.
@@ -2837,12 +2640,7 @@ int tinsel_hip_present(tinsel_hip* r, const tinsel_options* options, int nlm_wid
         return -1;
     HIP_TRY(hipStreamSynchronize(nullptr));
     if (out_rgba)
-    {
-        if (!r->hostCopy)
-            r->hostCopy = new StagedCopy();
-        if (frame_to_host(r->hostCopy, r->device, nullptr, r->presented, out_rgba, sizeof(float4)*(size_t)r->width*r->height))
-            return -1;
-    }
+        HIP_TRY(hipMemcpy(out_rgba, r->presented, sizeof(float4)*(size_t)r->width*r->height, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -4370,11 +4168,11 @@ int tinsel_hip_group_render(tinsel_hip_group* g, const tinsel_camera* camera, co
             return -1;
     }
     HIP_TRY(hipSetDevice(g->members[0].device));
-    tinsel_hip* r0 = g->members[0].r;
-    if (!r0->hostCopy)
-        r0->hostCopy = new StagedCopy();
     if (!wanted)
-        return frame_to_host(r0->hostCopy, g->members[0].device, nullptr, g->total, out_rgba, bytes);
+    {
+        HIP_TRY(hipMemcpy(out_rgba, g->total, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
 
     // 2. the sum starts towards the host and the members go on with the next call meanwhile: its passes traced (a batch of
     //    `depth` calls at a time), its snapshots reduced into totalNext -- per call the caller waits for one reduce (already
@@ -4404,7 +4202,8 @@ int tinsel_hip_group_render(tinsel_hip_group* g, const tinsel_camera* camera, co
     // is on the host; into a page-locked array it is one DMA, into a pageable one it is staged by the runtime)
     post_ahead();
     HIP_TRY(hipSetDevice(g->members[0].device));
-    return frame_to_host(r0->hostCopy, g->members[0].device, nullptr, g->total, out_rgba, bytes);
+    HIP_TRY(hipMemcpy(out_rgba, g->total, bytes, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int tinsel_hip_group_present(tinsel_hip_group* g, const tinsel_options* options, int nlm_width, float nlm_falloff, float* out_rgba)
