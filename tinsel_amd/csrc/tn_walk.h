@@ -103,25 +103,20 @@ TN_D Node64 load_node_from(Ptr nodes, uint32_t idx)
     return n;
 }
 
-// Walk modes (template parameter MODE of k_walk; launch_walk picks one, TINSEL_HIP_WALK_PAIRS / TINSEL_HIP_WALK_DRAIN):
-//   kWalkPairs   THE BOTTOM LEVEL IN ONE RECORD.  A node over two one-triangle leaves is not visited as a node: its parent hands the
-//                lane a pair ref (kPairBit | node index, from Node64::pairKids), the lane waits for the triangle phase like a lane at
-//                a leaf, and there ONE 128-B Pair128 record -- one request, eight dwordx4 -- gives it the two leaf boxes and both
-//                triangles: box tests (`tChild < tmax` against the closest hit so far, intersection.h:696-705), both triangle tests,
-//                and the outcome of the sequence the reference's stack produces for that node (push far, push near, pop near, pop
-//                far: :706-722 -- the far leaf is NOT culled again after the near one's hit, and a strict `t < closestT` keeps the
-//                first of two equal hits).  One fetch, one phase and one pop where there were a node phase, two triangle phases with
-//                their waits and three stack operations.
-//                (Tried first, 15.3 ms against 11.1 on the 524k-triangle config: box fetch, near-triangle fetch, far-triangle fetch as three
-//                dependent round trips inside the phase.  And "drain" -- a lane that pops another leaf after a leaf tests it in the same
-//                phase: 11.1 -> 11.8 ms, the same lesson: a phase must hold ONE round trip.  profiles/r04_a_ab_walk_pairs.md)
+// Walk modes (template parameter MODE of k_walk; launch_walk picks one, TINSEL_HIP_WALK_PAIRS / TINSEL_HIP_WALK_SINGLE):
+//   kWalkPairs   THE BOTTOM LEVEL IN ONE RECORD (opt-in: measured neutral, profiles/r04_c_ab_walk_pairs3.md).  A node over two one-triangle
+//                leaves is not visited as a node: its parent hands the lane a pair ref (kPairBit | node index, from Node64::pairKids), the
+//                lane waits for the triangle phase like a lane at a leaf, and there ONE request -- the five 16-B words of a Pair128 --
+//                gives it both triangles; the two leaf boxes are the min / max of their vertices (tn_scene.h).  Box tests (`tChild <
+//                tmax` against the closest hit so far, intersection.h:696-705), both triangle tests, and the outcome of the sequence
+//                the reference's stack produces for that node (push far, push near, pop near, pop far: :706-722 -- the far leaf is NOT
+//                culled again after the near one's hit, and a strict `t < closestT` keeps the first of two equal hits).
+//                (Its first version fetched boxes, then the near triangle, then the far one inside the phase: 15.3 ms against 11.1 on the
+//                524k-triangle config; "draining" a second leaf in the same phase: 11.1 -> 11.8.  A phase must hold ONE memory round trip.)
 //   kWalkSingle  ONE walked primitive (the host knows): tree, triangles, pair records and the staged top are the same for every lane --
 //                kernel-argument scalars instead of five per-lane registers (what lets kWalkPairs run at 64 VGPRs).
 constexpr int kWalkPairs = 1;
 constexpr int kWalkSingle = 2;
-
-typedef float WalkF2 __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(1))) WalkF2* GlobalF2;
 
 // The closest hit's normal for its record: n*sign with n = Cross(b - a, c - a) as IntersectRayTriTwoSided forms it (intersection.h:122-124),
 // computed again from the triangle where the record is written -- the lane's next refill, whose chain of dependent loads hides the
