@@ -387,7 +387,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     # per-rank view of the run (load balance of the pixel tiles): every rank's samples, rays, kernel time and median block
     per_rank = None
     if world > 1:
-        mine = {"rank": rank, "samples": int(st["samples"]), "rays": int(st["rays"]), "kernel_ms": round(sum(v[1] for v in ktimes.values()), 3),
+        mine = {"rank": rank, "samples": int(st["samples"]), "rays": int(st["rays"]), "kernel_ms": round(sum(v[2] for v in ktimes.values()), 3),
                 "median_block_ms": round(statistics.median(blocks)*1e3, 3), "device": int(local)}
         gathered = [None]*world
         dist.all_gather_object(gathered, mine)
@@ -492,10 +492,14 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
             fast = {"msamples_s": None, "error": str(e)}
 
     # ---- roofline: every kernel of the block, the dominant one (by time, over ALL kernels) in the headline fields ------------
-    gpu_ms = sum(v[1] for v in ktimes.values())
-    dom = max(ktimes.items(), key=lambda kv: kv[1][1], default=(None, (0, 0.0)))
-    dom_name, (dom_launches, dom_ms) = dom
+    # a kernel's time: (launches, sum of the launches' durations, union of their intervals).  Where a call's two chunks run on two streams
+    # (tinsel_hip.hip render_impl) launches of one kernel overlap: RATES divide by the union ("busy"); the average launch duration is the
+    # sum over the launches, which is what rocprofv3 --stats reports, and `concurrent_launches` = sum / union says how many ran at once
+    gpu_ms = sum(v[2] for v in ktimes.values())
+    dom = max(ktimes.items(), key=lambda kv: kv[1][2], default=(None, (0, 0.0, 0.0)))
+    dom_name, (dom_launches, dom_ms, dom_busy) = dom
     avg_launch_s = dom_ms*1e-3/max(1, dom_launches)
+    dom_concurrency = (dom_ms/dom_busy) if dom_busy > 0 else 1.0
     rays = st["rays"]
     # algorithmic bytes by kernel (SURVEY.md 8d's B_ray split over the kernels that do the work): the mesh walk (Node64 visits + triangle
     # tests) belongs to k_walk when it runs, the primitive tests and ray/hit records to the scan kernels; path-state streaming (k_shade,
@@ -536,8 +540,8 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
 
     def kernel_row(name):
         """one row of roofline.kernels[]: time from the library's HIP events (this block), counters from this run's rocprofv3 passes"""
-        launches, ms = ktimes[name]
-        row = {"kernel": name, "launches": launches, "ms": round(ms, 4), "share_of_gpu_time": (ms/gpu_ms) if gpu_ms > 0 else None,
+        launches, sum_ms, ms = ktimes[name]           # (every rate below is over `ms`, the kernel's busy time)
+        row = {"kernel": name, "launches": launches, "ms": round(ms, 4), "sum_of_launch_ms": round(sum_ms, 4), "share_of_gpu_time": (ms/gpu_ms) if gpu_ms > 0 else None,
                "frac_model": None, "frac": None, "counter_GB": None, "counter_GBs": None, "frac_hbm_counter": None, "frac_of_stream_copy": None,
                "algorithmic_GBs": None, "valu_frac_of_issue_peak": None, "valu_lanes_active": None, "wave_cycles_waiting": None, "waves_per_simd": None, "l2_hit_rate": None}
         t = kernel_traffic(name)
@@ -584,7 +588,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     counter_job = sum(r["counter_GB"] for r in kernels if r["counter_GB"]) if any(r["counter_GB"] for r in kernels) else None
 
     common = {
-        "kernel": dom_name, "launches": dom_launches, "avg_launch_ms": avg_launch_s*1e3, "traffic": traffic,
+        "kernel": dom_name, "launches": dom_launches, "avg_launch_ms": avg_launch_s*1e3, "concurrent_launches": dom_concurrency, "traffic": traffic,
         "frac_model": drow.get("frac_model"),
         "algorithmic_GBs": drow.get("algorithmic_GBs"), "frac_hbm_algorithmic": (alg_gbs/HBM_PEAK_GBS) if alg_gbs else None,
         "counter_GBs": drow.get("counter_GBs"), "frac_hbm_counter": drow.get("frac_hbm_counter"),
@@ -597,7 +601,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         "job_counter_GB": counter_job, "job_compulsory_GB": job_compulsory/1e9,
         "job_counter_over_compulsory": (counter_job*1e9/job_compulsory) if (counter_job and job_compulsory > 0) else None,
         "kernels": kernels,
-        "kernel_ms": {k: round(v[1], 3) for k, v in ktimes.items()},
+        "kernel_ms": {k: round(v[2], 3) for k, v in ktimes.items()},
         "kernel_traffic_GB": {r["kernel"]: (round(r["counter_GB"], 3) if r["counter_GB"] else None) for r in kernels} if any(pmc.values()) else None,
         "counter_calibration": dict(cal, source=("k_ub_copy / k_ub_gather<0> in the same rocprofv3 passes" if any(cal.values()) else
                                                  "none measured: FETCH_SIZE x2 on streaming kernels (the guide), x1 elsewhere"),
@@ -627,7 +631,8 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         common["k_walk"] = walk     # ... and under the kernel's name, whichever kernel is the dominant one
     if drow.get("frac_model") == "valu_issue":
         # the scene never leaves the CU: the HBM model counts bytes that are LDS reads.  What binds is instruction issue.
-        ach = (valu_per_launch/avg_launch_s/1e9) if (valu_per_launch and avg_launch_s > 0) else None
+        # (per-launch instructions / average launch duration x the launches that ran at once = all of them / the kernel's busy time)
+        ach = (valu_per_launch*dom_concurrency/avg_launch_s/1e9) if (valu_per_launch and avg_launch_s > 0) else None
         roofline = dict({"bound": "valu", "achieved": ach, "peak": VALU_PEAK/1e9, "unit": "G wave-instructions/s",
                          "frac": (ach/(VALU_PEAK/1e9)) if ach else None}, **common)
     else:

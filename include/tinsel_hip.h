@@ -340,7 +340,8 @@ void tinsel_hip_reset_stats(tinsel_hip* r);
 typedef struct tinsel_kernel_time {
     char name[32];
     uint32_t launches;
-    float total_ms;
+    float total_ms;     /* sum of the launches' durations */
+    float busy_ms;      /* union of their intervals: less than total_ms where a call's chunks overlap on two streams */
 } tinsel_kernel_time;
 int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entries);
 int tinsel_hip_enable_kernel_timing(tinsel_hip* r, int enable);

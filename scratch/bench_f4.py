@@ -36,7 +36,7 @@ def timed(r, cam, opt, passes):
         r.render(cam, opt, passes=passes, readback=False)
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
-            best = (dt, r.stats(), {k: round(v[1], 3) for k, v in r.kernel_times().items()}, r.queue_counts())
+            best = (dt, r.stats(), {k: round(v[2], 3) for k, v in r.kernel_times().items()}, r.queue_counts())
     r.enable_kernel_timing(False)
     return best
 

@@ -25,5 +25,5 @@ for world in (1, 2, 4, 8):
     st = r.stats()
     print("N=%d  rank %d: %.2f ms for %d passes -> %.1f Msamples/s per rank (x%d = %.0f aggregate), kernels %s" % (
         world, world//2, dt*1e3, steps*world, steps*1024*1024/dt/1e6, world, world*steps*1024*1024/dt/1e6,
-        {k: round(v[1], 2) for k, v in r.kernel_times().items()}))
+        {k: round(v[2], 2) for k, v in r.kernel_times().items()}))
     r.close()

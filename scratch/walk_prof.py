@@ -18,5 +18,5 @@ r.enable_kernel_timing(True)
 t0 = time.perf_counter()
 r.render(cam, opt, passes=passes, readback=False)
 dt = time.perf_counter() - t0
-print(pack, "%.1f Msamples/s" % (passes*W*H/dt/1e6), {k: round(v[1], 2) for k, v in r.kernel_times().items()}, flush=True)
+print(pack, "%.1f Msamples/s" % (passes*W*H/dt/1e6), {k: round(v[2], 2) for k, v in r.kernel_times().items()}, flush=True)
 r.close()

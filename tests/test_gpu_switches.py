@@ -34,6 +34,9 @@ SETTINGS = [
     {"TINSEL_HIP_WALK_PAIRS": "1", "TINSEL_HIP_WALK_LDS_STACK": "2", "TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_WALK_LEAFMIN": "1"}, {"TINSEL_HIP_WALK_BLOCK": "256", "TINSEL_HIP_WALK_PAIRS": "1"},
     {"TINSEL_HIP_TAIL_SPLIT": "0"}, {"TINSEL_HIP_TAIL_SPLIT_SPLIT": "1"}, {"TINSEL_HIP_TAIL_SPLIT_SPLIT": "1", "TINSEL_HIP_TAIL_SPLIT": "0.3,2"}, {"TINSEL_HIP_TAIL_SPLIT": "0.4,8"}, {"TINSEL_HIP_TAIL_SPLIT": "0.05,2"}, {"TINSEL_HIP_TAIL_SPLIT": "0.125,4"},
     {"TINSEL_HIP_ACC_NO_SPAN": "1"}, {"TINSEL_HIP_ACC_WIDE": "0"}, {"TINSEL_HIP_ACC_WIDE": "1"},
+    # a batch's passes as two overlapped chunks on two streams (render_impl): every fixture, both pipelines; with several batches per call; off
+    {"TINSEL_HIP_OVERLAP": "1"}, {"TINSEL_HIP_OVERLAP": "1", "TINSEL_HIP_BATCH_PATHS": "65536"}, {"TINSEL_HIP_OVERLAP": "0"},
+    {"TINSEL_HIP_OVERLAP": "1", "TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_SMALL_MESH_BYTES": "0"}, {"TINSEL_HIP_OVERLAP": "1", "TINSEL_HIP_BOUNCE_LAUNCHES": "per"},
 ]
 
 

@@ -108,7 +108,7 @@ class PackHeader(C.Structure):
 
 
 class KernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_float)]
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_float), ("busy_ms", C.c_float)]
 
 
 MODE_NORMALS, MODE_COMPLEXITY, MODE_PATHTRACE = 0, 1, 2

@@ -442,6 +442,23 @@ struct tinsel_hip
     BinPrims walkPrims = { 0, { 0, 0, 0, 0, 0, 0, 0 } };   // the subset of binPrims whose closest hits k_walk computes (large trees)
     int walkPrimMesh[7] = { 0, 0, 0, 0, 0, 0, 0 };         // DevScene::meshes index of each walked primitive
     float4* walkRec = nullptr;                          // k_walk's closest-hit records (tn_walk.h); batch-sized
+    // A SECOND set of the dense state (render_impl's overlapped chunks: two halves of a batch on two streams, each chunk's accumulate
+    // behind the other chunk's kernels).  The fields above are the set in use; lane_swap exchanges them with this one between ENQUEUES
+    // (a launch has copied its pointers by the time it returns).
+    struct DenseLane
+    {
+        SplitState ss;
+        size_t splitCap = 0;
+        uint32_t splitMaxRegions = 0;
+        uint32_t *regionOrder = nullptr, *regionOrderNee = nullptr, *walkList = nullptr, *segPrefix = nullptr;
+        float4* walkRec = nullptr;
+        uint32_t* walkOverflow = nullptr;       // (allocated by launch_walk on first use; freed with the renderer, not with the batch)
+        size_t walkOverflowCap = 0;
+    } laneB;
+    int batchLanes = 1;                 // dense-state sets allocated (1 or 2)
+    size_t batchStateSlots = 0;         // path slots each set holds (batchSlots: what ps.rad holds)
+    hipStream_t laneStream = nullptr;   // the second chunk's stream
+    hipEvent_t laneFork = nullptr, laneJoin = nullptr, accDone[2] = { nullptr, nullptr };
     uint32_t* walkOverflow = nullptr;                   // k_walk's stack entries beyond the LDS ones (TINSEL_HIP_WALK_LDS_STACK)
     size_t walkOverflowCap = 0;
     bool walkEnabled = true;                            // TINSEL_HIP_NO_WALK: walk meshes inline in k_extend / k_shadow (A/B)
@@ -502,8 +519,16 @@ void free_batch(tinsel_hip* r)
         (void)hipFree(p);
     r->batchAllocs.clear();
     r->walkRec = nullptr;
+    {
+        tinsel_hip::DenseLane fresh;
+        fresh.walkOverflow = r->laneB.walkOverflow;
+        fresh.walkOverflowCap = r->laneB.walkOverflowCap;
+        r->laneB = fresh;
+    }
     r->batchPipeline = -1;
     r->batchSlots = 0;
+    r->batchStateSlots = 0;
+    r->batchLanes = 1;
     r->batchNee = -1;
     r->batchDepth = -1;
 }
@@ -582,11 +607,31 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
     return 0;
 }
 
-int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
+void lane_swap(tinsel_hip* r)
+{
+    tinsel_hip::DenseLane& b = r->laneB;
+    std::swap(r->ss, b.ss);
+    std::swap(r->splitCap, b.splitCap);
+    std::swap(r->splitMaxRegions, b.splitMaxRegions);
+    std::swap(r->regionOrder, b.regionOrder);
+    std::swap(r->regionOrderNee, b.regionOrderNee);
+    std::swap(r->walkList, b.walkList);
+    std::swap(r->segPrefix, b.segPrefix);
+    std::swap(r->walkRec, b.walkRec);
+    std::swap(r->walkOverflow, b.walkOverflow);
+    std::swap(r->walkOverflowCap, b.walkOverflowCap);
+}
+
+// slots: paths whose radiance ps.rad holds (a whole batch); stateSlots: paths each set of dense state holds (a chunk of the batch
+// where chunks overlap, render_impl; 0: the whole batch); lanes: how many sets
+int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth, size_t stateSlots = 0, int lanes = 1)
 {
     const int K = r->neePerPath;
     const int pipeline = resolve_pipeline(r);
-    if (r->batchSlots >= slots && r->batchNee == K && r->batchDepth >= maxDepth && r->batchPipeline == pipeline)
+    if (stateSlots == 0 || stateSlots > slots)
+        stateSlots = slots;
+    if (r->batchSlots >= slots && r->batchStateSlots >= stateSlots && r->batchLanes >= lanes && r->batchNee == K && r->batchDepth >= maxDepth &&
+        r->batchPipeline == pipeline)
         return 0;
     free_batch(r);
 
@@ -595,8 +640,14 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
     memset(&ps, 0, sizeof(ps));
     if (batch_alloc(r, &ps.rad, slots))
         return -1;
-    if (pipeline != TINSEL_PIPELINE_MEGAKERNEL && alloc_dense(r, slots, maxDepth, pipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT))
-        return -1;
+    if (pipeline != TINSEL_PIPELINE_MEGAKERNEL)
+        for (int lane = lanes; lane-- > 0; )
+        {
+            if (alloc_dense(r, stateSlots, maxDepth, pipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT))
+                return -1;
+            if (lane > 0)
+                lane_swap(r);           // the set just made becomes laneB
+        }
 
     // slots of other shards are never written (gen_slot): keep their radiance at zero for the test hook
     HIP_TRY(hipMemset(ps.rad, 0, sizeof(float4)*slots));
@@ -607,6 +658,8 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth)
 
     r->ctl.stats = r->statsDev;
     r->batchSlots = slots;
+    r->batchStateSlots = stateSlots;
+    r->batchLanes = pipeline != TINSEL_PIPELINE_MEGAKERNEL ? lanes : 1;
     r->batchNee = K;
     r->batchDepth = maxDepth;
     r->batchPipeline = pipeline;
@@ -1635,17 +1688,97 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
     int perBatch = (int)std::max<size_t>(1, batch_slots(r)/perPass);
     if (perBatch > passes)
         perBatch = passes;
-    if (ensure_batch(r, perPass*(size_t)perBatch, fp.maxDepth))
+
+    // Overlapped chunks.  A batch of several passes can be traced as TWO chunks of passes on two streams, each with its own dense state
+    // (ensure_batch's lanes), both writing their slots of the one radiance array; a chunk's accumulate kernel follows its own trace
+    // on its own stream and the previous chunk's accumulate by an event -- the framebuffer adds keep the reference's pass order, so no
+    // bit changes (tests/test_gpu_switches.py) -- and the two chunks' kernels fill each other's tails.  Measured built in
+    // (profiles/r04_k_ab_overlap.md, Msamples/s off -> on): it pays where a bounce is MANY SHORT launches that leave the chip half empty
+    // at their ends -- the scene-level walk of scenes beyond the flat scan (k_seg_* + k_swalk twice a bounce: many_spheres 2118 -> 2304)
+    // -- and nowhere else: the fused kernel is one launch that already ends in short regions (cornell 1024^2 x 20 passes 4173 -> 4145,
+    // x 256 4338 -> 4268, veach 4K 2838 -> 2846, gloss 10972 -> 10588, a 1 M-path batch 2748 -> 2406: two launches, two tails);
+    // k_walk's workgroups take a CU's whole LDS and gain nothing from a neighbour (the 524k-triangle config 2223 -> 2114, glass 1426 ->
+    // 1418).  (Two RENDERERS on two streams had looked like +4 % on cornell, profiles/r04_j_two_streams.txt: that was the host's
+    // share of a call overlapping, not the device's.)  Default: scenes whose scene level is walked by k_swalk, batches of 8 Mi paths
+    // or more.  TINSEL_HIP_OVERLAP=0 / 1: never / wherever a batch has two passes (A/B, tests); TINSEL_HIP_OVERLAP_MIN_PATHS: the floor.
+    int chunkPasses = perBatch;
+    int lanes = 1;
+    {
+        const char* overlapEnv = getenv("TINSEL_HIP_OVERLAP");         // (read per call: tests switch it)
+        static const size_t minPaths = getenv("TINSEL_HIP_OVERLAP_MIN_PATHS") ? (size_t)atoll(getenv("TINSEL_HIP_OVERLAP_MIN_PATHS")) : ((size_t)8u << 20);
+        const int pipeline = resolve_pipeline(r);
+        const bool can = !traceOnly && perBatch >= 2 && pipeline != TINSEL_PIPELINE_MEGAKERNEL;
+        static const bool noSceneWalk = getenv("TINSEL_HIP_NO_SCENE_WALK") != nullptr;
+        const bool sceneWalked = pipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT && !r->scene.flatScan && !noSceneWalk && !r->countDetail &&
+                                 !(r->walkPrims.count > 0 && r->walkEnabled);
+        const bool want = overlapEnv ? atoi(overlapEnv) != 0 : (sceneWalked && perPass*(size_t)perBatch >= minPaths);
+        if (can && want)
+        {
+            chunkPasses = (perBatch + 1)/2;
+            lanes = 2;
+        }
+    }
+    if (ensure_batch(r, perPass*(size_t)perBatch, fp.maxDepth, perPass*(size_t)chunkPasses, lanes))
         return -1;
 
     if (traceOnly && perBatch < passes)
         return fail("render: look-ahead batch does not fit");
+    if (lanes == 2 && !r->laneStream)
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&r->laneStream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&r->laneFork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r->laneJoin, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k)
+            HIP_TRY(hipEventCreateWithFlags(&r->accDone[k], hipEventDisableTiming));
+    }
     for (int done = 0; done < passes; done += perBatch)
     {
-        fp.passBase = done;
-        fp.numPasses = std::min(perBatch, passes - done);
-        if (render_batch(r, st, cam, fp, !traceOnly))
+        const int n = std::min(perBatch, passes - done);
+        if (lanes == 1 || n < 2)
+        {
+            fp.passBase = done;
+            fp.numPasses = n;
+            if (render_batch(r, st, cam, fp, !traceOnly))
+                return -1;
+            continue;
+        }
+        float4* const radBase = r->ps.rad;
+        const int first = std::min(chunkPasses, (n + 1)/2);
+        HIP_TRY(hipEventRecord(r->laneFork, st));                       // whatever the caller's stream holds comes first
+        HIP_TRY(hipStreamWaitEvent(r->laneStream, r->laneFork, 0));
+        int rc = 0;
+        for (int c = 0; c < 2 && !rc; ++c)
+        {
+            hipStream_t s = c ? r->laneStream : st;
+            if (c)
+                lane_swap(r);
+            fp.passBase = done + (c ? first : 0);
+            fp.numPasses = c ? n - first : first;
+            r->ps.rad = radBase + (size_t)(c ? first : 0)*perPass;
+            r->ss.radOut = r->ps.rad;
+            rc = render_batch(r, s, cam, fp, false);
+            if (!rc && c)
+                rc = hipStreamWaitEvent(s, r->accDone[0], 0) == hipSuccess ? 0 : fail("render: hipStreamWaitEvent");
+            if (!rc)
+                rc = launch_accumulate(r, s, r->lastFp, r->accum);
+            if (!rc)
+                rc = hipEventRecord(c ? r->laneJoin : r->accDone[0], s) == hipSuccess ? 0 : fail("render: hipEventRecord");
+            r->ps.rad = radBase;
+            r->ss.radOut = radBase;
+            if (c)
+                lane_swap(r);
+        }
+        if (!rc)
+            rc = hipStreamWaitEvent(st, r->laneJoin, 0) == hipSuccess ? 0 : fail("render: hipStreamWaitEvent");
+        if (rc)
             return -1;
+        // the test hooks read a whole batch (tinsel_hip_read_batch_radiance; queue_counts reports the second chunk's regions)
+        r->lastBatchSlots = perPass*(size_t)n;
+        r->lastFp.passBase = done;
+        r->lastFp.numPasses = n;
+        r->lastFp.genCount = (uint32_t)(perPass*(size_t)n);
+        r->lastFp.accBegin = 0;
+        r->lastFp.accEnd = n;
     }
     r->passIndex += (uint32_t)passes;
     return 0;
@@ -2451,10 +2584,16 @@ void tinsel_hip_destroy(tinsel_hip* r)
     (void)hipSetDevice(r->device);
     lookahead_release(r);
     (void)hipDeviceSynchronize();
+    if (r->laneStream) (void)hipStreamDestroy(r->laneStream);
+    if (r->laneFork) (void)hipEventDestroy(r->laneFork);
+    if (r->laneJoin) (void)hipEventDestroy(r->laneJoin);
+    for (int k = 0; k < 2; ++k)
+        if (r->accDone[k]) (void)hipEventDestroy(r->accDone[k]);
     if (r->workStream) (void)hipStreamDestroy(r->workStream);
     if (r->copyStream) (void)hipStreamDestroy(r->copyStream);
     if (r->probeAlias) (void)hipFree(r->probeAlias);
     if (r->walkOverflow) (void)hipFree(r->walkOverflow);
+    if (r->laneB.walkOverflow) (void)hipFree(r->laneB.walkOverflow);
     if (r->walkProf)
     {
         unsigned long long wp[16] = { 0 };
@@ -3294,14 +3433,33 @@ int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entr
     HIP_TRY(hipDeviceSynchronize());
     float total[KN_COUNT] = { 0 };
     uint32_t launches[KN_COUNT] = { 0 };
+    // busy time: the union of a kernel's launch intervals -- launches of one kernel on two streams overlap (render_impl's chunks), and
+    // the sum of their durations counts the shared stretch twice
+    std::vector<std::pair<float, float>> intervals[KN_COUNT];
     for (const TimedSpan& s : r->spans)
     {
-        float ms = 0.0f;
+        float ms = 0.0f, at = 0.0f;
         if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess)
         {
             total[s.kernel] += ms;
             launches[s.kernel]++;
+            if (hipEventElapsedTime(&at, r->spans.front().start, s.start) == hipSuccess)
+                intervals[s.kernel].push_back(std::make_pair(at, at + ms));
         }
+    }
+    float busy[KN_COUNT] = { 0 };
+    for (int k = 0; k < KN_COUNT; ++k)
+    {
+        std::sort(intervals[k].begin(), intervals[k].end());
+        float end = -1e30f;
+        for (const auto& iv : intervals[k])
+        {
+            if (iv.second > end)
+                busy[k] += iv.second - std::max(iv.first, end);
+            end = std::max(end, iv.second);
+        }
+        if (intervals[k].size() != launches[k])
+            busy[k] = total[k];
     }
     int n = 0;
     double sum = 0.0;
@@ -3313,6 +3471,7 @@ int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entr
         strncpy(out[n].name, kKernelNames[k], sizeof(out[n].name) - 1);
         out[n].launches = launches[k];
         out[n].total_ms = total[k];
+        out[n].busy_ms = busy[k];
         sum += total[k];
         ++n;
     }

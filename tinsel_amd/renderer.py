@@ -316,7 +316,8 @@ class HipRenderer:
         n = self._L.tinsel_hip_kernel_times(self._h, arr, 16)
         if n < 0:
             _check(n, "tinsel_hip_kernel_times")
-        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n)}
+        # (launches, sum of their durations, union of their intervals: smaller where a call's chunks overlap on two streams)
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms, arr[i].busy_ms) for i in range(n)}
 
     def stats(self):
         names = ["rays", "samples", "internal_visits", "tri_tests", "prim_tests", "shadow_rays", "_6", "_7"]
