@@ -37,6 +37,10 @@ SETTINGS = [
     # a batch's passes as two overlapped chunks on two streams (render_impl): every fixture, both pipelines; with several batches per call; off
     {"TINSEL_HIP_OVERLAP": "1"}, {"TINSEL_HIP_OVERLAP": "1", "TINSEL_HIP_BATCH_PATHS": "65536"}, {"TINSEL_HIP_OVERLAP": "0"},
     {"TINSEL_HIP_OVERLAP": "1", "TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_SMALL_MESH_BYTES": "0"}, {"TINSEL_HIP_OVERLAP": "1", "TINSEL_HIP_BOUNCE_LAUNCHES": "per"},
+    # k_shade traces the shadow rays itself (no k_shadow launch): scenes as they are, and with every mesh walked by k_walk (the lean variant)
+    {"TINSEL_HIP_SHADOW_IN_SHADE": "1"}, {"TINSEL_HIP_SHADOW_IN_SHADE": "0"},
+    {"TINSEL_HIP_SHADOW_IN_SHADE": "1", "TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_SMALL_MESH_BYTES": "0"},
+    {"TINSEL_HIP_SHADOW_IN_SHADE": "1", "TINSEL_HIP_WALK_LDS_STACK": "2", "TINSEL_HIP_WALK_MIN_TRIS": "1"}, {"TINSEL_HIP_SHADOW_IN_SHADE": "1", "TINSEL_HIP_OVERLAP": "1"},
 ]
 
 

@@ -1464,6 +1464,11 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         const bool lightsInMixed = lightsInExtendEnv && !walkedOnly && !r->countDetail && mixedArena && !(!noSceneWalkEarly && !r->scene.flatScan);
         a.lightsInExtend = lightsInMixed ? 1 : 0;
         const bool lightsInExtend = (walkedOnly && !r->countDetail) || lightsInMixed;
+        // k_shade's variant that traces the shadow rays itself, after k_walk has done their mesh parts (no k_shadow launch, no pass over
+        // the shadow-ray records of its own): staged arena + meshes in HBM, flat scan.  TINSEL_HIP_SHADOW_IN_SHADE=1 (A/B)
+        const char* shadowInShadeEnv = getenv("TINSEL_HIP_SHADOW_IN_SHADE");        // (read per call: tests switch it)
+        const bool shadowInShade = shadowInShadeEnv && atoi(shadowInShadeEnv) != 0 && mixedArena && r->scene.flatScan && !r->countDetail &&
+                                   r->neePerPath > 0 && arenaLdsShade == arenaLdsTrace;
         // No short regions at the end by default here (TINSEL_HIP_TAIL_SPLIT_SPLIT=1: A/B): the launches are many and short, k_walk cuts its
         // own list into static ranges, and more regions cost k_seg_prefix / k_walk more than the other kernels' tails gain -- the 524k-triangle
         // config 2319 -> 2254 Msamples/s, many_spheres 2108 -> 2082, glass +-0 (profiles/r03_z5_ab_tail_split.md).  (k_seg_prefix stages
@@ -1546,7 +1551,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                     if (launch_swalk(r, st, a, r->ss.neeFront + (size_t)bounce*W, r->ss.neeBack + (size_t)bounce*W, true))
                         return -1;
                 }
-                else
+                else if (!shadowInShade)
                 {
                     if (ordered && bounce > 0)
                     {
@@ -1572,8 +1577,10 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 static const char* sortedEnv = getenv("TINSEL_HIP_SHADE_SORTED");
                 const bool shadeSorted = sortedEnv ? atoi(sortedEnv) != 0 : (!r->sceneEnclosed && !walk);
                 a.grid = gridPersist;
-                a.shadeSorted = shadeSorted ? 1 : 0;
-                a.ldsBytes = ldsShade + (shadeSorted ? (uint32_t)(kShadeListWords*sizeof(uint32_t)) : 0u);
+                a.shadeSorted = (shadeSorted && !shadowInShade) ? 1 : 0;
+                a.shadowInShade = shadowInShade ? 1 : 0;
+                a.ldsBytes = shadowInShade ? ldsTrace : ldsShade + (shadeSorted ? (uint32_t)(kShadeListWords*sizeof(uint32_t)) : 0u);
+                a.stackEntries = stackScan;
                 a.scene.arenaLdsBytes = arenaLdsShade;
                 launch_path(r, PK_SHADE, a, st);
                 a.scene.arenaLdsBytes = arenaLdsTrace;

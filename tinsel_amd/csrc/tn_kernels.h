@@ -1174,9 +1174,12 @@ struct ShadeFetch
 
 // the shading half of one path (shared by the two k_shade kernels): on_hit_begin / on_miss, the BSDF terms of the arriving light
 // samples, the BSDF step; true when the path goes on (its state in `p`, `front`: its next ray enters a mesh in HBM)
-template <class SC>
-TN_D bool shade_path(const SC& sc, const SplitState& ss, const ShadeFetch& f, int bounce, int maxDepth, int rrStart, const BinPrims& bp,
-                     PathRegs& p, uint32_t& slot, bool& front)
+// SHADOW: the shadow rays are traced HERE, between on_hit_begin and the BSDF terms (k_shade's variant that replaces k_shadow: the rays'
+// mesh parts already lie in k_walk's records) -- the same trace<> call on the same ray as k_shadow's, the same acceptance tests
+struct NoStack {};
+template <class SC, bool SHADOW = false, class Stack = NoStack>
+TN_D bool shade_path(SC& sc, const SplitState& ss, const ShadeFetch& f, int bounce, int maxDepth, int rrStart, const BinPrims& bp,
+                     PathRegs& p, uint32_t& slot, bool& front, Stack* st = nullptr, uint32_t walkPrims = 0u, uint32_t* shadowRays = nullptr)
 {
     const int K = ss.neePerPath;
     bool alive = false;
@@ -1204,7 +1207,29 @@ TN_D bool shade_path(const SC& sc, const SplitState& ss, const ShadeFetch& f, in
             const float2* res = ss.neeRes + qn;
             const float4* wis = ss.neeRay + (size_t)ss.capacity + qn;       // {wi, nl} of ray k at wis[k*2*capacity]
             V3 sum = nee_sum(sc, [&](int k) -> V3 {
-                const float2 rk = res[(size_t)k*ss.capacity];
+                float2 rk;
+                if constexpr (SHADOW)
+                {
+                    const float4* src = ss.neeRay + (size_t)(k*2)*ss.capacity + qn;
+                    const float4 a = src[0], b = src[ss.capacity];
+                    NeeGeo ray;
+                    ray.o = V3(a.x, a.y, a.z); ray.dist = a.w;
+                    ray.wi = V3(b.x, b.y, b.z); ray.nl = b.w;
+                    float t;
+                    V3 n3;
+                    TraceCounters ctr = { 0, 0, 0 };
+                    sc.walkItem = (qn*(uint32_t)K + (uint32_t)k)*walkPrims;
+                    const int hit = trace<SC, Stack, false, true>(sc, *st, ray.o, ray.wi, p.time, t, n3, ctr, shadow_stop(ray.dist));
+                    (*shadowRays)++;
+                    int arrives;
+                    if (ray.dist < 0.0f)
+                        arrives = (hit < 0) ? 0 : -1;
+                    else
+                        arrives = nee_light_reached(ray, hit, t) ? hit : -1;
+                    rk = make_float2(__int_as_float(arrives), t);
+                }
+                else
+                    rk = res[(size_t)k*ss.capacity];
                 const int hp = __float_as_int(rk.x);
                 if (sc.probe.valid && k == 0)
                 {
@@ -1235,12 +1260,18 @@ TN_D bool shade_path(const SC& sc, const SplitState& ss, const ShadeFetch& f, in
     return alive;
 }
 
-template <bool LDS, bool MIXED = false>
-__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp, const uint32_t* __restrict__ order)
+// SHADOW (with WONLY as in k_shadow): the variant that traces the shadow rays itself (shade_path) -- LDS laid out like k_shadow's (stacks,
+// kScanWords, arena), k_walk's records and the ray counters as arguments
+template <bool LDS, bool MIXED = false, bool SHADOW = false, bool WONLY = false>
+__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp, const uint32_t* __restrict__ order,
+                                                                 QueueCtl q = QueueCtl{ nullptr }, int stackEntries = 0, const float4* __restrict__ walkRec = nullptr, uint32_t walkPrims = 0u)
 {
     extern __shared__ uint32_t s_arena[];
-    SceneT<LDS, false, 2, MIXED> sc;
-    stage_scene_lds(sc, scIn, s_arena);
+    SceneT<LDS, WONLY, 2, MIXED> sc;
+    LdsStack<kBlock> st = { s_arena + threadIdx.x };
+    stage_scene_lds(sc, scIn, SHADOW ? s_arena + stackEntries*kBlock + kScanWords : s_arena);
+    sc.walkRec = walkRec;
+    uint32_t shadowRays = 0;
     const uint32_t lane = __lane_id();
     const int cur = bounce & 1, nxt = cur ^ 1;
     const int K = ss.neePerPath;
@@ -1280,7 +1311,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
             PathRegs p;
             uint32_t slot = 0;
             if (j < n)
-                alive = shade_path(sc, ss, f, bounce, maxDepth, rrStart, bp, p, slot, front);
+                alive = shade_path<SceneT<LDS, WONLY, 2, MIXED>, SHADOW, LdsStack<kBlock>>(sc, ss, f, bounce, maxDepth, rrStart, bp, p, slot, front, &st, walkPrims, &shadowRays);
             const uint32_t np = out.push(alive, front);
             if (alive)
                 store_state(ss, nxt, np, p, slot);
@@ -1290,6 +1321,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
             ss.segFront[(size_t)(bounce + 1)*ss.numRegions + r] = out.nFront;
             ss.segBack[(size_t)(bounce + 1)*ss.numRegions + r] = out.nBack;
         }
+    }
+    if (SHADOW)
+    {
+        wave_add_stat(q.stats, 0, shadowRays);
+        wave_add_stat(q.stats, 5, shadowRays);
     }
 }
 

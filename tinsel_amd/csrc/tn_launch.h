@@ -39,6 +39,7 @@ struct LaunchArgs
     int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
     int walkMode;                   // PK_WALK: kWalkPairs | kWalkSingle (tn_walk.h)
     int shadeSorted;                // PK_SHADE: k_shade_sorted (paths taken class by class) instead of k_shade
+    int shadowInShade;              // PK_SHADE: the variant that traces the shadow rays itself (no PK_SHADOW launch; staged arena + meshes in HBM)
     int lightsInExtend;             // PK_EXTEND, arena staged + meshes in HBM: the variant that draws the light samples too (A/B)
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
     int bounce;
@@ -106,7 +107,11 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             else if (lds) hipLaunchKernelGGL((KERNEL<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order); \
             else hipLaunchKernelGGL((KERNEL<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order); \
         } while (0)
-        if (a.shadeSorted) TN_LAUNCH_SHADE(k_shade_sorted); else TN_LAUNCH_SHADE(k_shade);
+        if (a.shadowInShade && mixed && a.walkedOnly)
+            hipLaunchKernelGGL((k_shade<true, true, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order, a.ctl, a.stackEntries, a.walkRec, a.walkPrims);
+        else if (a.shadowInShade && mixed)
+            hipLaunchKernelGGL((k_shade<true, true, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order, a.ctl, a.stackEntries, a.walkRec, a.walkPrims);
+        else if (a.shadeSorted) TN_LAUNCH_SHADE(k_shade_sorted); else TN_LAUNCH_SHADE(k_shade);
 #undef TN_LAUNCH_SHADE
         break;
     case PK_BOUNCE:
@@ -168,6 +173,8 @@ inline int prepare_path_kernels(int sharedMemLimit)
                            (void)hipFuncSetAttribute((const void*)k_walk<256, 5, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
     TN_PREP_WALK(0); TN_PREP_WALK(1); TN_PREP_WALK(2); TN_PREP_WALK(3);
 #undef TN_PREP_WALK
+    (void)hipFuncSetAttribute((const void*)k_shade<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
+    (void)hipFuncSetAttribute((const void*)k_shade<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_shade_sorted<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_shade_sorted<true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
     (void)hipFuncSetAttribute((const void*)k_shade_sorted<false>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
