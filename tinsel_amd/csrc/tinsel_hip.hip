@@ -304,6 +304,23 @@ void set_prim_pose(Prim64& o, const Xform& xs, const Xform& xe, bool isStatic)
     }
 }
 
+// what the device derives from a STATIC pose once instead of per ray (call when o.type and the pose are both set): the reciprocal of a
+// mesh's scale -- InverseTransformPoint / InverseTransformVector divide 1.0f by it per call (maths.h:611-619), the same IEEE division
+// here -- and whether the rotation is the identity quaternion bit for bit (pose_rotate_*, tn_isect.h)
+void set_prim_derived(Prim64& o)
+{
+    o.flags &= ~(uint32_t)kPrimNoRot;
+    if (o.flags & kPrimMoving)
+        return;
+    uint32_t rb[4];
+    const float rr[4] = { o.rx, o.ry, o.rz, o.rw };
+    memcpy(rb, rr, sizeof(rb));
+    if (rb[0] == 0u && rb[1] == 0u && rb[2] == 0u && o.rw == 1.0f)
+        o.flags |= kPrimNoRot;
+    if (o.type == kPrimMesh)
+        o.g3 = 1.0f/o.s;
+}
+
 Xform to_xform(const tinsel_transform& t)
 {
     Xform x;
@@ -2355,8 +2372,11 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
 
     r->primMesh.assign((size_t)P, -1);
     for (int i = 0; i < P && ok; ++i)
+    {
+        set_prim_derived(prims[(size_t)i]);
         if (prims[(size_t)i].type == kPrimMesh)
             r->primMesh[(size_t)i] = (int)prims[(size_t)i].mesh;
+    }
 
     ConvertedBvh sceneBvh;
     if (ok && !convert_bvh(desc->bvh_nodes, desc->num_bvh_nodes, P, 0, sceneBvh))
@@ -3052,6 +3072,7 @@ int tinsel_hip_set_primitive_transform(tinsel_hip* r, int index, const tinsel_tr
     r->primEndScale[(size_t)index] = xe.s;
     Prim64& o = r->primsHost[(size_t)index];
     set_prim_pose(o, xs, xe, isStatic);
+    set_prim_derived(o);
     const Moving64 mv = make_moving(xs, xe);
     unsigned char* arenaDev = const_cast<unsigned char*>(r->scene.arena);
     HIP_TRY(hipMemcpy(arenaDev + r->arenaOffPrims + sizeof(Prim64)*(size_t)index, &o, sizeof(Prim64), hipMemcpyHostToDevice));

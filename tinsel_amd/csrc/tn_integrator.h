@@ -138,7 +138,7 @@ TN_D void primitive_sample(const SC& sc, int index, float time, V3& pos, V3& nor
     {
         float u1 = rng.randf();
         float u2 = rng.randf();
-        pos = xform_point(x, uniform_sample_sphere(u1, u2)*p.g0);
+        pos = pose_xform_point(p, x, uniform_sample_sphere(u1, u2)*p.g0);
         normal = normalize(pos - x.p);
     }
     else if (p.type == kPrimMesh)
@@ -171,8 +171,8 @@ TN_D void primitive_sample(const SC& sc, int index, float time, V3& pos, V3& nor
         V3 n2(nr[i1*3 + 0], nr[i1*3 + 1], nr[i1*3 + 2]);
         V3 n3(nr[i2*3 + 0], nr[i2*3 + 1], nr[i2*3 + 2]);
 
-        pos = xform_point(x, u*a + v*b + (1.0f - u - v)*c);
-        normal = safe_normalize(xform_vector(x, u*n1 + v*n2 + (1.0f - u - v)*n3), V3(0.0f));
+        pos = pose_xform_point(p, x, u*a + v*b + (1.0f - u - v)*c);
+        normal = safe_normalize(pose_xform_vector(p, x, u*n1 + v*n2 + (1.0f - u - v)*n3), V3(0.0f));
     }
     // planes are never lights (PrimitiveSample asserts, intersection.h:871-875)
 }

@@ -351,6 +351,49 @@ TN_D Xform prim_pose(const DevScene& sc, const Prim64& p, float time)
     return x;
 }
 
+// Rotate() by the identity quaternion, written down.  Most primitives of most scenes are not rotated: their pose carries the quaternion
+// (+0, +0, +0, 1), and the reference still runs two quaternion products per Rotate() on it (maths.h:558-563: 56 multiplies and adds; a mesh
+// primitive's ray costs two of them per Trace(), a light sample two more).  With that q every product term but one is a signed zero:
+//   * forward, Rotate(q, v) (TransformVector / TransformPoint): a non-zero component passes through exactly and a zero one comes out
+//     as +0 whatever its sign and its neighbours' (each partial sum starts at +0 and only ever adds signed zeros): v + 0.0f per
+//     component -- for finite v (0 * inf would be NaN);
+//   * inverse, Rotate(Conjugate(q), v) = Rotate((-0, -0, -0, 1), v) (InverseTransform*): non-zero components pass through exactly; the sign
+//     of a zero one depends on its neighbours' signs, so a vector with a zero component takes the reference's formula.
+// The flag is set on the host from the bits of the stored quaternion (kPrimNoRot, set_prim_derived); a wave takes the short form only when
+// all its active lanes can (the flat scan's waves are at one primitive at a time).  tests: every fixture has such primitives; axis-aligned
+// rays (one-pixel frames) and axis-aligned light normals take the zero-component branches.
+TN_D bool finite_bits3(V3 v) { return finite_bits(v.x) && finite_bits(v.y) && finite_bits(v.z); }
+TN_D bool finite_nonzero(float x) { return ((__float_as_uint(x) & 0x7fffffffu) - 1u) < 0x7f7fffffu; }
+TN_D bool finite_nonzero3(V3 v) { return finite_nonzero(v.x) && finite_nonzero(v.y) && finite_nonzero(v.z); }
+
+TN_D V3 pose_rotate(const Prim64& p, const Xform& x, V3 v)              // Rotate(x.r, v)
+{
+    if (__all((p.flags & kPrimNoRot) != 0u && finite_bits3(v)))
+        return V3(v.x + 0.0f, v.y + 0.0f, v.z + 0.0f);
+    return qrotate(x.r, v);
+}
+TN_D V3 pose_xform_vector(const Prim64& p, const Xform& x, V3 v) { return pose_rotate(p, x, x.s*v); }              // TransformVector (maths.h:601-604)
+TN_D V3 pose_xform_point(const Prim64& p, const Xform& x, V3 v) { return x.p + pose_rotate(p, x, x.s*v); }         // TransformPoint (maths.h:606-609)
+
+// InverseTransformPoint(o), InverseTransformVector(d) (maths.h:611-619): a mesh primitive's ray into mesh space
+TN_D void pose_inv_ray(const Prim64& p, const Xform& x, V3 o, V3 d, V3& lo, V3& ld)
+{
+    // 1.0f/s: a static mesh has it in its record
+    const float rs = (p.flags & kPrimMoving) ? rcpf_cr(x.s) : p.g3;
+    const V3 op = o - x.p;
+    if (__all((p.flags & kPrimNoRot) != 0u && finite_nonzero3(op) && finite_nonzero3(d)))
+    {
+        lo = rs*op;
+        ld = rs*d;
+    }
+    else
+    {
+        const Q4 c = qconj(x.r);
+        lo = rs*qrotate(c, op);
+        ld = rs*qrotate(c, d);
+    }
+}
+
 TN_D Prim64 load_prim(const Prim64* prims, int idx)
 {
     const float4* pp = reinterpret_cast<const float4*>(prims + idx);
@@ -406,8 +449,8 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
     }
 
     // mesh: ray into mesh space
-    V3 lo = inv_xform_point(x, o);
-    V3 ld = inv_xform_vector(x, d);
+    V3 lo, ld;
+    pose_inv_ray(p, x, o, d, lo, ld);
 
     const DevMesh m = sc.meshes[p.mesh];
     const Tri48* mtris = mesh_tris(sc, m);
@@ -448,7 +491,7 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
         smooth = smooth*(-1.0f);
 
     outT = h.t;
-    outN = safe_normalize(xform_vector(x, smooth), h.n);
+    outN = safe_normalize(pose_xform_vector(p, x, smooth), h.n);
     return true;
 }
 

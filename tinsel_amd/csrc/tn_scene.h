@@ -78,6 +78,7 @@ enum : uint32_t
 {
     kPrimMoving = 1u,           // startTransform != endTransform: interpolate per ray
     kPrimWalked = 2u,           // mesh in HBM whose closest hit k_walk (tn_walk.h) computes ahead of the scan kernels
+    kPrimNoRot = 4u,            // static pose whose rotation is exactly the quaternion (+0, +0, +0, 1): Rotate() written down (tn_isect.h)
     kPrimWalkLaneShift = 8,     // bits 8..10: which of the (up to 7) walked primitives this is = its record lane
 };
 
@@ -86,7 +87,7 @@ struct alignas(64) Prim64
     // pose at ray time for static primitives == InterpolateTransform(start, end, t) for any t
     float px, py, pz, s;
     float rx, ry, rz, rw;
-    float g0, g1, g2, g3;       // sphere: radius,-,-,- ; plane: the four coefficients
+    float g0, g1, g2, g3;       // sphere: radius,-,-,- ; plane: the four coefficients ; static mesh: -,-,-,1.0f/s (divided on the host)
     uint32_t type;
     uint32_t flags;
     uint32_t mesh;              // index into DevScene::meshes (kPrimMesh)

@@ -332,8 +332,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         if (!single)
                             p = load_prim(sc.prims, index);
                         const Xform x = prim_pose(sc, p, time);
-                        o = inv_xform_point(x, wo);
-                        d = inv_xform_vector(x, wd);
+                        pose_inv_ray(p, x, wo, wd, o, d);
                         rcp = rcp3_cr(d);
                         if (SINGLE)
                             ref = mesh0root;
