@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 4, call N: the world ray's reciprocal direction reused in mesh space where they are the same bits; zero-component rays; A/B
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r4n; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_leaf.py tests/test_gpu_parity.py tests/test_gpu_reference_scenes.py tests/test_gpu_walk.py tests/test_gpu_swalk.py tests/test_fuzz.py -m gpu -q -x -s 2>&1 | grep -aE "passed|failed|rays,|Error|error" | tail -12 ) > $O/pytest.log 2>&1; tail -8 $O/pytest.log
+run() { timeout 120 python bench.py "$@" --no-cpu-baseline --no-pmc --no-second-config --no-api --no-fast --no-ubench 2>/tmp/err.txt > /tmp/b.json || tail -3 /tmp/err.txt
+python - <<PY
+import json
+d=json.load(open('/tmp/b.json'))
+print('| $TAG | %s | %.1f | %s |' % (d['config']['workload'].split(',')[0], d['value'], d['roofline']['kernel_ms']), flush=True)
+PY
+}
+ab() { local S="$1"; shift; ( [ "$S" != "-" ] && export $S; TAG="$S" run "$@" ); }
+OLD="TINSEL_HIP_LIB=$GRAFT_REPO_ROOT/scratch/ab/libtinsel_hip_norcp.so"
+( echo "| environment | config | Msamples/s | kernel busy ms of one timed block |"; echo "|---|---|---|---|"
+for S in "$OLD" "-" "$OLD" "-"; do ab "$S" --scene cornell --steps 20 --warmup 5; done
+for S in "$OLD" "-"; do ab "$S" --scene cornell --steps 256 --warmup 8; done
+for S in "$OLD" "-"; do ab "$S" --scene cornell --width 256 --height 256 --steps 16 --warmup 4; done
+for S in "$OLD" "-"; do ab "$S" --scene veach --width 3840 --height 2160 --steps 8 --warmup 1; done
+for S in "$OLD" "-"; do ab "$S" --scene glass --width 1920 --height 1080 --maxdepth 12 --steps 20 --warmup 2; done
+for S in "$OLD" "-"; do ab "$S" --scene large/transmission --width 1920 --height 1080 --steps 8 --warmup 1; done
+for S in "$OLD" "-"; do ab "$S" --scene large/meshlight --width 1920 --height 1080 --steps 8 --warmup 1; done
+) 2>&1 | sed "s#$GRAFT_REPO_ROOT/##" | tee $O/ab_rcp_reuse.md

@@ -118,7 +118,49 @@ def test_primitive_intersect(scene_name, prims):
     r.close(); R.free(h)
 
 
-@pytest.mark.parametrize("scene_name,prims", [("features", [2, 3]), ("cornell", [5]), ("veach", [5, 8])])
+@pytest.mark.parametrize("scene_name,prim", [("cornell", 5), ("glass", 6), ("glass", 7), ("veach", 2), ("veach", 3)])
+def test_primitive_intersect_rays_with_zero_components(scene_name, prim):
+    """Unrotated mesh primitives take Rotate() by the identity quaternion as written down (pose_inv_ray / pose_rotate, tn_isect.h): exact
+    for vectors without zero components; a vector WITH one (an axis-aligned ray, an origin level with the primitive's position) takes the
+    reference's two quaternion products, because the sign of the zero that comes out depends on its neighbours' signs.  Every combination
+    of -x, -0, +0, +x in the components of o - p and d, aimed at the primitive: hit flag, t and normal bit for bit (zero signs included)."""
+    import ctypes as C
+    scene, r, R, h = _setup(scene_name)
+    prims = C.cast(scene.desc.primitives, C.POINTER(abi.Primitive))
+    assert prims[prim].type == abi.GEOM_MESH
+    tp = prims[prim].start_transform.p
+    centre = np.array([tp.x, tp.y, tp.z], np.float32)           # (veach 3 is rotated: the reference's formula on every ray, as a control)
+    vals = np.array([-0.07, -0.0, 0.0, 0.07], np.float32)
+    rows = []
+    for dist, axis in ((1.5, 1), (-1.5, 1), (1.5, 0), (-1.5, 2)):
+        for a in vals:
+            for b in vals:
+                for da in vals:
+                    for db in vals:
+                        off = np.zeros(3, np.float32); dd = np.zeros(3, np.float32)
+                        others = [k for k in range(3) if k != axis]
+                        off[others[0]], off[others[1]], off[axis] = a, b, -dist
+                        dd[others[0]], dd[others[1]], dd[axis] = da, db, np.sign(dist)
+                        for sgn in (1.0, -1.0):             # (a signed zero along the axis too)
+                            o = (centre + off).astype(np.float32)
+                            if sgn < 0:
+                                o[others[0]] = centre[others[0]]        # o - p exactly +0 there
+                            d = (dd/np.float32(np.sqrt(np.float32((dd*dd).sum())))).astype(np.float32)
+                            rows.append(np.concatenate([o, d, [0.0]]).astype(np.float32))
+    rows = np.stack(rows).astype(np.float32)
+    out = r.leaf(4, prim, len(rows), 5, rows=rows)
+    hit, tt, nrm = R.primitive_intersect(h, prim, rows)
+    r.close(); R.free(h)
+    got = out[:, 0] > 0.5
+    print("%s prim %d: %d rays, %d hits" % (scene_name, prim, len(rows), int((hit > 0).sum())))
+    assert (hit > 0).sum() > len(rows)//8
+    assert np.array_equal(got, hit > 0)
+    m = hit > 0
+    assert np.array_equal(out[m, 1].view(np.uint32), tt[m].astype(np.float32).view(np.uint32))
+    assert np.array_equal(np.ascontiguousarray(out[m, 2:5]).view(np.uint32), np.ascontiguousarray(nrm[m].astype(np.float32)).view(np.uint32))
+
+
+@pytest.mark.parametrize("scene_name,prims", [("features", [2, 3]), ("cornell", [5]), ("veach", [5, 8]), ("glass", [6])])
 def test_primitive_sample(scene_name, prims):
     scene, r, R, h = _setup(scene_name)
     rng = np.random.default_rng(5)

@@ -225,9 +225,9 @@ struct MeshHit
 // near child first exactly as the stack would pop it, both leaves tested when their boxes are hit (the `tChild < tmax` cull is
 // evaluated before any triangle is: tmax is still FLT_MAX), strict `<` between the two hits.  No stack, no loop.
 template <bool COUNT>
-TN_D bool ray_mesh_two_leaves(const Node64* mnodes, const Tri48* mtris, uint32_t mroot, V3 o, V3 d, MeshHit& hit, TraceCounters& ctr)
+TN_D bool ray_mesh_two_leaves(const Node64* mnodes, const Tri48* mtris, uint32_t mroot, V3 o, V3 d, V3 rcp, MeshHit& hit, TraceCounters& ctr)
 {
-    const V3 rcp = rcp3_cr(d);
+    // rcp = rcp3_cr(d): MeshQuery's rcpDir (intersection.h:669), the caller's (pose_inv_ray)
     const Node64 nd = load_node(mnodes, mroot);
     if (COUNT) ctr.internal++;
 
@@ -270,11 +270,11 @@ TN_D bool ray_mesh_two_leaves(const Node64* mnodes, const Tri48* mtris, uint32_t
 
 // ANYHIT / tStop (shadow rays, shadow_stop below): the walk may stop at the first accepted hit with t < tStop.
 template <class Stack, bool COUNT, bool ANYHIT = false>
-TN_D bool ray_mesh(const Node64* mnodes, const Tri48* mtris, uint32_t mroot, Stack& st, int sp, V3 o, V3 d, MeshHit& hit, TraceCounters& ctr, float tStop = 0.0f)
+TN_D bool ray_mesh(const Node64* mnodes, const Tri48* mtris, uint32_t mroot, Stack& st, int sp, V3 o, V3 d, V3 rcp, MeshHit& hit, TraceCounters& ctr, float tStop = 0.0f)
 {
     float closestT = kFltMax;
     float tmax = kFltMax;
-    V3 rcp = rcp3_cr(d);
+    // rcp = rcp3_cr(d), the caller's (pose_inv_ray)
 
     const int base = sp;
     st.set(sp++, mroot);
@@ -375,8 +375,10 @@ TN_D V3 pose_rotate(const Prim64& p, const Xform& x, V3 v)              // Rotat
 TN_D V3 pose_xform_vector(const Prim64& p, const Xform& x, V3 v) { return pose_rotate(p, x, x.s*v); }              // TransformVector (maths.h:601-604)
 TN_D V3 pose_xform_point(const Prim64& p, const Xform& x, V3 v) { return x.p + pose_rotate(p, x, x.s*v); }         // TransformPoint (maths.h:606-609)
 
-// InverseTransformPoint(o), InverseTransformVector(d) (maths.h:611-619): a mesh primitive's ray into mesh space
-TN_D void pose_inv_ray(const Prim64& p, const Xform& x, V3 o, V3 d, V3& lo, V3& ld)
+// InverseTransformPoint(o), InverseTransformVector(d) (maths.h:611-619): a mesh primitive's ray into mesh space, and the reciprocal of its
+// direction (MeshQuery, intersection.h:669) -- which IS the world ray's, `rcpWorld` = rcp3_cr(d) (Trace computes it for the scene-level
+// boxes), where the mesh-space direction is d bit for bit: no rotation and 1.0f/s == 1 (1.0f*x is x)
+TN_D void pose_inv_ray(const Prim64& p, const Xform& x, V3 o, V3 d, V3& lo, V3& ld, V3& lrcp, const V3* rcpWorld = nullptr)
 {
     // 1.0f/s: a static mesh has it in its record
     const float rs = (p.flags & kPrimMoving) ? rcpf_cr(x.s) : p.g3;
@@ -385,6 +387,11 @@ TN_D void pose_inv_ray(const Prim64& p, const Xform& x, V3 o, V3 d, V3& lo, V3& 
     {
         lo = rs*op;
         ld = rs*d;
+        if (rcpWorld != nullptr && __all(rs == 1.0f))
+        {
+            lrcp = *rcpWorld;
+            return;
+        }
     }
     else
     {
@@ -392,6 +399,7 @@ TN_D void pose_inv_ray(const Prim64& p, const Xform& x, V3 o, V3 d, V3& lo, V3& 
         lo = rs*qrotate(c, op);
         ld = rs*qrotate(c, d);
     }
+    lrcp = rcp3_cr(ld);
 }
 
 TN_D Prim64 load_prim(const Prim64* prims, int idx)
@@ -427,7 +435,7 @@ TN_D Prim64 load_prim_uniform(ConstF4 prims, int idx)
 // (ray_plane_bounded); every other caller leaves it at FLT_MAX.
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false, bool UNIFORM = false>
 TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f,
-                         float bound = kFltMax)
+                         float bound = kFltMax, const V3* rcpWorld = nullptr)
 {
     const Prim64 p = UNIFORM ? load_prim_uniform(sc.kPrims, index) : load_prim(sc.prims, index);
     if (COUNT) ctr.prims++;
@@ -449,8 +457,8 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
     }
 
     // mesh: ray into mesh space
-    V3 lo, ld;
-    pose_inv_ray(p, x, o, d, lo, ld);
+    V3 lo, ld, lrcp;
+    pose_inv_ray(p, x, o, d, lo, ld, lrcp, rcpWorld);
 
     const DevMesh m = sc.meshes[p.mesh];
     const Tri48* mtris = mesh_tris(sc, m);
@@ -472,10 +480,10 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
         return false;
     else if (m.twoLeaves)
     {
-        if (!ray_mesh_two_leaves<COUNT>(mesh_nodes(sc, m), mtris, m.root, lo, ld, h, ctr))
+        if (!ray_mesh_two_leaves<COUNT>(mesh_nodes(sc, m), mtris, m.root, lo, ld, lrcp, h, ctr))
             return false;
     }
-    else if (!ray_mesh<Stack, COUNT, ANYHIT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, h, ctr, tStop))
+    else if (!ray_mesh<Stack, COUNT, ANYHIT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, lrcp, h, ctr, tStop))
         return false;
 
     // interpolate vertex normals (intersection.h:996-1012)
@@ -561,7 +569,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
         }
         float t;
         V3 n;
-        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, minT);
+        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, minT, &rcp);
 #ifdef TN_PROFILE_TRACE
         { const uint32_t ty = __builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float4*>(sc.prims + i)[3].x)); TN_TTICK(ctr, ty == kPrimPlane ? 1 : ty == kPrimSphere ? 2 : 3) }
 #endif
@@ -581,7 +589,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
             meshes &= meshes - 1ull;
             float t;
             V3 n;
-            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, i, st, 0, o, d, time, t, n, ctr, tStop))
+            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, kFltMax, &rcp))
                 accept(i, t, n);
             if (ANYHIT && minT < tStop)
                 break;
@@ -668,7 +676,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
             float t;
             V3 n;
             const int index = (int)(ref & ~kLeafBit);
-            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, index, st, sp, o, d, time, t, n, ctr, tStop))
+            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, index, st, sp, o, d, time, t, n, ctr, tStop, kFltMax, &rcp))
             {
                 if (t < minT && t > 0.0f)
                 {

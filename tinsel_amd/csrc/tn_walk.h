@@ -332,8 +332,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         if (!single)
                             p = load_prim(sc.prims, index);
                         const Xform x = prim_pose(sc, p, time);
-                        pose_inv_ray(p, x, wo, wd, o, d);
-                        rcp = rcp3_cr(d);
+                        pose_inv_ray(p, x, wo, wd, o, d, rcp, &wrcp);
                         if (SINGLE)
                             ref = mesh0root;
                         else if (single)
