@@ -23,7 +23,7 @@ SETTINGS = [
     {"TINSEL_HIP_SWALK_GRID_MULT": "4", "TINSEL_HIP_SWALK_LIST_STEP": "1"},
     {"TINSEL_HIP_NO_LDS_SCENE": "1"}, {"TINSEL_HIP_NO_LDS_TEMPLATE": "1"}, {"TINSEL_HIP_ARENA_LDS_LIMIT": "1024"},
     {"TINSEL_HIP_SMALL_MESH_BYTES": "0"}, {"TINSEL_HIP_INLINE_MAX_TRIS": "100000"}, {"TINSEL_HIP_NO_FLAT_SCAN": "1"},
-    {"TINSEL_HIP_NO_BIN": "1"}, {"TINSEL_HIP_NO_SORT_QUEUES": "1"}, {"TINSEL_HIP_NO_DEFER_MESHES": "1"}, {"TINSEL_HIP_NO_TWO_LEAVES": "1"},
+    {"TINSEL_HIP_NO_PLANE_TABLE": "1"}, {"TINSEL_HIP_NO_BIN": "1"}, {"TINSEL_HIP_NO_SORT_QUEUES": "1"}, {"TINSEL_HIP_NO_DEFER_MESHES": "1"}, {"TINSEL_HIP_NO_TWO_LEAVES": "1"},
     {"TINSEL_HIP_NO_SHADE_ARENA": "1"}, {"TINSEL_HIP_NO_LEAN_SCAN": "1"},
     {"TINSEL_HIP_NO_WALK": "1"}, {"TINSEL_HIP_WALK_MIN_TRIS": "1"}, {"TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_SMALL_MESH_BYTES": "0"},
     {"TINSEL_HIP_WALK_LDS_STACK": "0"}, {"TINSEL_HIP_WALK_LDS_STACK": "2"}, {"TINSEL_HIP_WALK_GRID_MULT": "3"},

@@ -418,6 +418,7 @@ struct tinsel_hip
     std::vector<Xform> primStart, primEnd;
     std::vector<tinsel_bvh_node> sceneBvhHost;
     size_t arenaOffNodes = 0, arenaOffBoxes = 0;
+    std::vector<int32_t> planeTablePrims;       // the planes DevScene::planeEq holds (their PrimBox says 2: re-marked when the boxes are rewritten)
     int sceneStackNeed = 1;
     bool sceneEnclosed = false;         // two planes face each other: (practically) no ray leaves the scene (k_bounce's shading pools stay off)
     int bvhMode = TINSEL_BVH_REFERENCE;
@@ -2448,7 +2449,29 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         const size_t offLights = arena.add(lights.data(), lights.size());
         const size_t offMeshes = arena.add(meshes.data(), meshes.size());
 
+        // the always-hit planes once more, four by four, for the flat scan (trace_flat; TINSEL_HIP_NO_PLANE_TABLE: A/B)
+        std::vector<float> planeEq;
+        std::vector<int32_t> planeIdx;
+        if (flatScan && !getenv("TINSEL_HIP_NO_PLANE_TABLE"))
+        {
+            for (int k = 0; k < P; ++k)
+                if (prims[(size_t)k].type == kPrimPlane && boxes[(size_t)k].alwaysHit)
+                {
+                    const Prim64& pp = prims[(size_t)k];
+                    planeEq.insert(planeEq.end(), { pp.g0, pp.g1, pp.g2, pp.g3 });
+                    planeIdx.push_back(k);
+                    boxes[(size_t)k].alwaysHit = 2u;
+                }
+            r->planeTablePrims = planeIdx;
+            while (planeIdx.size() % 4)
+            {
+                planeEq.insert(planeEq.end(), { 0.0f, 0.0f, 0.0f, 0.0f });      // d == 0: IntersectRayPlane's own "no hit"
+                planeIdx.push_back(0);
+            }
+        }
         const size_t offBoxes = arena.add(boxes.data(), boxes.size());
+        const size_t offPlaneEq = arena.add(planeEq.data(), planeEq.size());
+        const size_t offPlaneIdx = arena.add(planeIdx.data(), planeIdx.size());
         arena.bytes.resize((arena.bytes.size() + 127) & ~size_t(127), 0);
 
         unsigned char* arenaDev = r->sceneMem.upload(arena.bytes.data(), arena.bytes.size());
@@ -2491,6 +2514,9 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             sc.numMeshes = (int)meshes.size();
             r->sceneStackNeed = sceneBvh.maxLeafDepth + 1;
             sc.primBoxes = reinterpret_cast<const PrimBox*>(arenaDev + offBoxes);
+            sc.planeEq = reinterpret_cast<const float4*>(arenaDev + offPlaneEq);
+            sc.planeIdx = reinterpret_cast<const int32_t*>(arenaDev + offPlaneIdx);
+            sc.numPlanes = (int32_t)r->planeTablePrims.size();
             r->sceneBvhHost.assign(desc->bvh_nodes, desc->bvh_nodes + desc->num_bvh_nodes);
             r->arenaOffNodes = offNodes;
             r->arenaOffBoxes = offBoxes;
@@ -3245,6 +3271,9 @@ int tinsel_hip_rebuild_scene(tinsel_hip* r, int mode, const tinsel_bvh_node* nod
     unsigned char* arenaDev = const_cast<unsigned char*>(r->scene.arena);
     if (!sceneBvh.nodes.empty())
         HIP_TRY(hipMemcpy(arenaDev + r->arenaOffNodes, sceneBvh.nodes.data(), sizeof(Node64)*sceneBvh.nodes.size(), hipMemcpyHostToDevice));
+    for (int32_t k : r->planeTablePrims)
+        if (boxes[(size_t)k].alwaysHit)
+            boxes[(size_t)k].alwaysHit = 2u;
     HIP_TRY(hipMemcpy(arenaDev + r->arenaOffBoxes, boxes.data(), sizeof(PrimBox)*(size_t)P, hipMemcpyHostToDevice));
     r->scene.root = sceneBvh.root;
     r->sceneStackNeed = sceneBvh.maxLeafDepth + 1;

@@ -551,10 +551,54 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
     const bool finiteAll = TN_FLAT_MINMAX && __all(finite_bits(rcp.x) && finite_bits(rcp.y) && finite_bits(rcp.z) &&
                                                   finite_bits(o.x) && finite_bits(o.y) && finite_bits(o.z));
     TN_TTICK0(ctr)
+    // The scene's always-hit planes FOUR AT A TIME, ahead of the loop (DevScene::planeEq: the same equations, padded with planes no ray
+    // meets; their boxes say 2 and the loop below passes them by).  Every lane is at the same primitive in this scan, so one
+    // IntersectRayPlane after the other is one IEEE division's dependent chain after the other; four in one block are four independent
+    // chains the scheduler interleaves (then two, then one: what is left).  The order of the accept() calls does not matter (above).
+    const int numPlanes = SC::kPlaneTable ? sc.numPlanes : 0;
+    int pk = 0;
+    for (; pk + 4 <= numPlanes; pk += 4)
+    {
+        const ConstF4V e0 = sc.kPlaneEq[pk], e1 = sc.kPlaneEq[pk + 1], e2 = sc.kPlaneEq[pk + 2], e3 = sc.kPlaneEq[pk + 3];
+        const ConstF4V id = sc.kPlaneIdx[pk >> 2];
+        float t0, t1, t2, t3;
+        const bool h0 = ray_plane(o, d, e0.x, e0.y, e0.z, e0.w, t0);
+        const bool h1 = ray_plane(o, d, e1.x, e1.y, e1.z, e1.w, t1);
+        const bool h2 = ray_plane(o, d, e2.x, e2.y, e2.z, e2.w, t2);
+        const bool h3 = ray_plane(o, d, e3.x, e3.y, e3.z, e3.w, t3);
+        if (h0) accept(__float_as_int(id.x), t0, V3(e0.x, e0.y, e0.z));
+        if (h1) accept(__float_as_int(id.y), t1, V3(e1.x, e1.y, e1.z));
+        if (h2) accept(__float_as_int(id.z), t2, V3(e2.x, e2.y, e2.z));
+        if (h3) accept(__float_as_int(id.w), t3, V3(e3.x, e3.y, e3.z));
+    }
+    if (pk < numPlanes)
+    {
+        // the one, two or three that are left (the table is padded to a multiple of four: the loads are in bounds)
+        const ConstF4V id = sc.kPlaneIdx[pk >> 2];
+        const int left = numPlanes - pk;
+        if (left >= 2)
+        {
+            const ConstF4V e0 = sc.kPlaneEq[pk], e1 = sc.kPlaneEq[pk + 1];
+            float t0, t1;
+            const bool h0 = ray_plane(o, d, e0.x, e0.y, e0.z, e0.w, t0);
+            const bool h1 = ray_plane(o, d, e1.x, e1.y, e1.z, e1.w, t1);
+            if (h0) accept(__float_as_int(id.x), t0, V3(e0.x, e0.y, e0.z));
+            if (h1) accept(__float_as_int(id.y), t1, V3(e1.x, e1.y, e1.z));
+        }
+        if (left & 1)
+        {
+            const ConstF4V e0 = sc.kPlaneEq[pk + (left & 2)];
+            float t0;
+            if (ray_plane(o, d, e0.x, e0.y, e0.z, e0.w, t0))
+                accept(__float_as_int(left == 1 ? id.x : id.z), t0, V3(e0.x, e0.y, e0.z));
+        }
+    }
     for (int i = 0; i < sc.numPrims; ++i)
     {
         TN_TTICK(ctr, 4)
         const ConstF4V b0 = sc.kBoxes[i*2], b1 = sc.kBoxes[i*2 + 1];
+        if (SC::kPlaneTable && __float_as_uint(b1.z) == 2u)
+            continue;
         if (__float_as_uint(b1.z) == 0u)
         {
             float tb;

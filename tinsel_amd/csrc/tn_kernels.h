@@ -137,6 +137,8 @@ TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER, MIXED>& sc, const DevScene& 
     sc.walkItem = 0u;
     sc.kPrims = (ConstF4)(uintptr_t)in.prims;
     sc.kBoxes = (ConstF4)(uintptr_t)in.primBoxes;
+    sc.kPlaneEq = (ConstF4)(uintptr_t)in.planeEq;
+    sc.kPlaneIdx = (ConstF4)(uintptr_t)in.planeIdx;
     if (!LDS && in.arenaLdsBytes == 0)
         return;
 

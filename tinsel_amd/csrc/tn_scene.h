@@ -129,7 +129,7 @@ static_assert(sizeof(Mat128) == 128, "Mat128");
 struct alignas(32) PrimBox
 {
     float minx, miny, minz, maxx, maxy, maxz;
-    uint32_t alwaysHit;         // 1: an "infinite" box (planes: +-1e8) that every sane ray hits
+    uint32_t alwaysHit;         // 1: an "infinite" box (planes: +-1e8) that every sane ray hits; 2: ... and the plane is in DevScene::planeEq (the flat scan tests those four at a time)
     uint32_t pad;
 };
 static_assert(sizeof(PrimBox) == 32, "PrimBox");
@@ -195,6 +195,11 @@ struct DevScene
     int32_t hasMedia;           // 0: no material absorbs, rayAbsorption stays 0 -> its 16-B state record is skipped
     int32_t sortQueues;         // 1: the fused kernel sorts the next bounce's queue by ray_meets_bounded_prim (open scenes)
     int32_t deferMeshes;        // 1: trace_flat walks the meshes a ray enters after the scan, all lanes together (>= 2 mesh primitives)
+    // the scene's always-hit planes once more, for the flat scan: equations four by four (padded with planes no ray meets) and
+    // their primitive indices, in the arena (trace_flat, tn_isect.h)
+    const float4* planeEq;
+    const int32_t* planeIdx;
+    int32_t numPlanes;              // (the table is padded to a multiple of four)
 };
 
 // Compile-time view of where the scene lives.  SceneT<true>: the whole scene (arena incl. every mesh)
@@ -217,10 +222,14 @@ struct SceneT : DevScene
     static constexpr bool kMixed = MIXED;
     static constexpr bool kWalkedOnly = WALKED_ONLY;
     static constexpr int kDefer = DEFER;
+    // trace_flat tests the always-hit planes four at a time from DevScene::planeEq: in the split pipeline's kernels and the one-lane-per-path
+    // ones; not in the fused kernel (k_bounce: DEFER 0 / 1), where the extra blocks cost more than the interleaved divisions give back
+    // (glass k_extend 7.2 -> 6.8 ms, k_shadow 4.05 -> 3.87; fused: veach -1.1 %, gloss -2.7 %, env_loft -2.5 %, cornell +-0: profiles/r04_o_ab_plane_table.md)
+    static constexpr bool kPlaneTable = DEFER == 2;
     const unsigned char* ldsBase;
     // The flat scan reads primitive records and leaf boxes at a wave-uniform index: through these pointers (the arena's copy
     // in HBM, constant address space) they are scalar loads into SGPRs instead of 64 lanes reading the same LDS words
-    ConstF4 kPrims, kBoxes;
+    ConstF4 kPrims, kBoxes, kPlaneEq, kPlaneIdx;
     // closest-hit records of the walked primitives for the ray being traced (tn_walk.h): record lane kb of the ray
     // lives at walkRec[(walkItem + kb)*2 .. +1]; null = walk the mesh inline (ray_mesh)
     const float4* walkRec;
