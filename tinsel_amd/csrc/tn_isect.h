@@ -429,13 +429,20 @@ TN_D Prim64 load_prim_uniform(ConstF4 prims, int idx)
     return p;
 }
 
+// The first words {t, u, v, w} of a ray's first two walk records, requested by the scan kernels BEFORE the trace for the rays at the front
+// of their region (the ones k_walk walked): they arrive behind the plane tests instead of being waited for, one after the other, where the
+// scan meets the walked primitives.  By value, all the way down: values the register allocator can keep where it likes.  n == 0: none --
+// which is what the default build passes (TN_WALK_PREFETCH, tn_kernels.h: measured, a wash), and every use below folds away.
+struct WalkPre { float4 r0, r1; uint32_t n; };
+TN_D WalkPre no_walk_pre() { WalkPre p = { make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), 0u }; return p; }
+
 // PrimitiveIntersect (intersection.h:951-1020)
 // UNIFORM: `index` is the same in every lane (the flat scan's loop counter)
 // `bound`: the closest hit a scene-level SCAN already holds (trace_flat) -- lets a plane skip its division where it cannot matter
 // (ray_plane_bounded); every other caller leaves it at FLT_MAX.
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false, bool UNIFORM = false>
 TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f,
-                         float bound = kFltMax, const V3* rcpWorld = nullptr)
+                         float bound = kFltMax, const V3* rcpWorld = nullptr, WalkPre pre = no_walk_pre())
 {
     const Prim64 p = UNIFORM ? load_prim_uniform(sc.kPrims, index) : load_prim(sc.prims, index);
     if (COUNT) ctr.prims++;
@@ -467,8 +474,17 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
     {
         // the mesh-space closest hit of this (ray, primitive) was computed by k_walk with the same ray_mesh arithmetic
         // on the same lo / ld (tn_walk.h); t == FLT_MAX marks "no hit" (ray_mesh's own `closestT < FLT_MAX`)
-        const float4* rp = sc.walkRec + (size_t)(sc.walkItem + ((p.flags >> kPrimWalkLaneShift) & 7u))*2;
-        const float4 ra = rp[0];
+        const uint32_t kb = (p.flags >> kPrimWalkLaneShift) & 7u;
+        const float4* rp = sc.walkRec + (size_t)(sc.walkItem + kb)*2;
+        float4 ra;
+        if (kb < pre.n)
+        {
+            // requested before the trace (walk_prefetch, tn_kernels.h)
+            ra.x = kb == 0u ? pre.r0.x : pre.r1.x; ra.y = kb == 0u ? pre.r0.y : pre.r1.y;
+            ra.z = kb == 0u ? pre.r0.z : pre.r1.z; ra.w = kb == 0u ? pre.r0.w : pre.r1.w;
+        }
+        else
+            ra = rp[0];
         if (!(ra.x < kFltMax))
             return false;
         const float4 rb = rp[1];
@@ -516,7 +532,8 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
 // re-traces that ray with the BVH walk, which IS the oracle's order.  Results are therefore identical
 // to the BVH walk in all cases.
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false>
-TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, float& outT, V3& outN, bool& tie, TraceCounters& ctr, float tStop = 0.0f)
+TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, float& outT, V3& outN, bool& tie, TraceCounters& ctr, float tStop = 0.0f,
+                    WalkPre pre = no_walk_pre())
 {
     float minT = kFltMax;
     int closest = -1;
@@ -613,7 +630,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
         }
         float t;
         V3 n;
-        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, minT, &rcp);
+        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, minT, &rcp, pre);
 #ifdef TN_PROFILE_TRACE
         { const uint32_t ty = __builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float4*>(sc.prims + i)[3].x)); TN_TTICK(ctr, ty == kPrimPlane ? 1 : ty == kPrimSphere ? 2 : 3) }
 #endif
@@ -633,7 +650,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
             meshes &= meshes - 1ull;
             float t;
             V3 n;
-            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, kFltMax, &rcp))
+            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, kFltMax, &rcp, pre))
                 accept(i, t, n);
             if (ANYHIT && minT < tStop)
                 break;
@@ -683,7 +700,7 @@ TN_D float shadow_stop(float dist)
 }
 
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false>
-TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f)
+TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f, WalkPre pre = no_walk_pre())
 {
     float minT = kFltMax;
     int closest = -1;
@@ -702,7 +719,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
         // (the flat scan always runs to its end: stopping it early was measured and costs more in the scan's shape than the
         // skipped tests give back -- cornell 2835 -> 2713 Msamples/s, veach 1454 -> 1366; what stops early is the walks)
         if (sane)
-            prim = trace_flat<SC, Stack, COUNT, false>(sc, st, o, d, rcp, time, outT, outN, tie, ctr);
+            prim = trace_flat<SC, Stack, COUNT, false>(sc, st, o, d, rcp, time, outT, outN, tie, ctr, 0.0f, pre);
         if (sane && !tie)
             return prim;
     }
@@ -720,7 +737,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
             float t;
             V3 n;
             const int index = (int)(ref & ~kLeafBit);
-            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, index, st, sp, o, d, time, t, n, ctr, tStop, kFltMax, &rcp))
+            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, index, st, sp, o, d, time, t, n, ctr, tStop, kFltMax, &rcp, pre))
             {
                 if (t < minT && t > 0.0f)
                 {

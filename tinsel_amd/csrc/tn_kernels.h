@@ -105,6 +105,10 @@ struct FrameParams
 
 constexpr int kStatShards = 2048;       // stats[kStatShards][8]
 constexpr int kStatWords = 8;
+#ifndef TN_WALK_PREFETCH
+#define TN_WALK_PREFETCH 0          // -DTN_WALK_PREFETCH=1: the scan kernels request a front ray's first two walk records before its trace (A/B:
+                                    // a wash on glass and the 524k-triangle config, -1 % where seven primitives are walked: profiles/r04_p_ab_walk_prefetch.md)
+#endif
 constexpr int kScanWords = 16;           // LDS words kept between the traversal stacks and the staged arena
 
 TN_D int lane_id() { return (int)__lane_id(); }
@@ -925,6 +929,25 @@ TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& b
     }
 }
 
+// the scan kernels' request for a front ray's first two walk records (WalkPre, tn_isect.h), ahead of its trace
+template <class SC>
+TN_D WalkPre walk_prefetch(const SC& sc, uint32_t walkPrims, bool front)
+{
+    WalkPre pre = { make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), 0u };
+    if (TN_WALK_PREFETCH && sc.walkRec != nullptr && front && walkPrims > 0u)
+    {
+        const float4* rp = sc.walkRec + (size_t)sc.walkItem*2;
+        pre.r0 = rp[0];
+        pre.n = 1u;
+        if (walkPrims > 1u)
+        {
+            pre.r1 = rp[2];
+            pre.n = 2u;
+        }
+    }
+    return pre;
+}
+
 // k_extend: closest hit of every live path.  The lean variant (WONLY: every mesh of the scene is walked by k_walk, the
 // kernel is the flat scan + record reads) also draws the light samples, the hit still in registers: there a kernel of its
 // own for them costs more than it saves (524k-triangle config: 2.1 + 2.9 ms apart, 3.9 together); behind the inline mesh
@@ -968,9 +991,10 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_
                 const float4 ro = ss.rayO[cur][pos];
                 const float4 rd = ss.rayD[cur][pos];
                 sc.walkItem = pos*walkPrims;        // only front rays ever reach a walked primitive
+                const WalkPre pre = walk_prefetch(sc, walkPrims, j < nFront);
 
                 float t;
-                const int prim = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, hitN, ctr);
+                const int prim = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, hitN, ctr, 0.0f, pre);
 
                 ss.hit[pos] = make_float4(t, hitN.x, hitN.y, hitN.z);
                 ss.hitPrim[pos] = prim;
@@ -1104,9 +1128,10 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
                 float t;
                 V3 n3;
                 sc.walkItem = (qn*(uint32_t)K + (uint32_t)k)*walkPrims;
+                const WalkPre pre = walk_prefetch(sc, walkPrims, j < nFront);
                 // the walks of a shadow ray stop at an occluder that decides the sample (shadow_stop, tn_isect.h: the scene BVH here,
                 // meshes in HBM in k_walk; many_spheres 1309 -> 1369 Msamples/s, config 3 1923 -> 1959)
-                const int hp = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT, !COUNT>(sc, st, ray.o, ray.wi, time, t, n3, ctr, shadow_stop(ray.dist));
+                const int hp = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT, !COUNT>(sc, st, ray.o, ray.wi, time, t, n3, ctr, shadow_stop(ray.dist), pre);
                 rays++;
                 int arrives;
                 if (ray.dist < 0.0f)
