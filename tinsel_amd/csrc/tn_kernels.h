@@ -105,6 +105,9 @@ struct FrameParams
 
 constexpr int kStatShards = 2048;       // stats[kStatShards][8]
 constexpr int kStatWords = 8;
+#ifndef TN_SCAN_PREFETCH
+#define TN_SCAN_PREFETCH 0          // -DTN_SCAN_PREFETCH=1: k_extend / k_shadow request round i + 1's rays before they trace round i's (A/B)
+#endif
 #ifndef TN_WALK_PREFETCH
 #define TN_WALK_PREFETCH 0          // -DTN_WALK_PREFETCH=1: the scan kernels request a front ray's first two walk records before its trace (A/B:
                                     // a wash on glass and the 524k-triangle config, -1 % where seven primitives are walked: profiles/r04_p_ab_walk_prefetch.md)
@@ -979,6 +982,14 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
         RegionAppend out = { rBase, rLen, 0u, 0u };
+#if TN_SCAN_PREFETCH
+        float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro;
+        if (lane < n)
+        {
+            const uint32_t p0 = region_pos(rBase, rLen, nFront, lane);
+            nro = ss.rayO[cur][p0]; nrd = ss.rayD[cur][p0];
+        }
+#endif
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
@@ -986,10 +997,20 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_
             bool has = false;
             V3 hitP, hitN;
             float time = 0.0f;
+#if TN_SCAN_PREFETCH
+            const float4 ro = nro, rd = nrd;
+            if (j + kWave < n)
+            {
+                const uint32_t pn = region_pos(rBase, rLen, nFront, j + kWave);
+                nro = ss.rayO[cur][pn]; nrd = ss.rayD[cur][pn];
+            }
+#endif
             if (j < n)
             {
+#if !TN_SCAN_PREFETCH
                 const float4 ro = ss.rayO[cur][pos];
                 const float4 rd = ss.rayD[cur][pos];
+#endif
                 sc.walkItem = pos*walkPrims;        // only front rays ever reach a walked primitive
                 const WalkPre pre = walk_prefetch(sc, walkPrims, j < nFront);
 
@@ -1110,18 +1131,45 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
         const uint32_t nFront = wave_uniform(ss.neeFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.neeBack[(size_t)bounce*ss.numRegions + r]);
         const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
+#if TN_SCAN_PREFETCH
+        float4 na = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nb = na;
+        float ntime = 0.0f;
+        if (lane < n)
+        {
+            const uint32_t q0 = region_pos(rBase, rLen, nFront, lane);
+            na = ss.neeRay[q0]; nb = ss.neeRay[(size_t)ss.capacity + q0]; ntime = ss.neeTime[q0];
+        }
+#endif
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
+#if TN_SCAN_PREFETCH
+            const float4 a0 = na, b0 = nb;
+            const float time0 = ntime;
+            if (j + kWave < n)
+            {
+                const uint32_t q1 = region_pos(rBase, rLen, nFront, j + kWave);
+                na = ss.neeRay[q1]; nb = ss.neeRay[(size_t)ss.capacity + q1]; ntime = ss.neeTime[q1];
+            }
+#endif
             if (j >= n)
                 continue;
             const uint32_t qn = region_pos(rBase, rLen, nFront, j);
+#if TN_SCAN_PREFETCH
+            const float time = time0;
+#else
             const float time = ss.neeTime[qn];
+#endif
 
             for (int k = 0; k < K; ++k)
             {
                 const float4* src = ss.neeRay + (size_t)(k*2)*ss.capacity + qn;
+#if TN_SCAN_PREFETCH
+                float4 a, b;
+                if (k == 0) { a = a0; b = b0; } else { a = src[0]; b = src[ss.capacity]; }
+#else
                 const float4 a = src[0], b = src[ss.capacity];
+#endif
                 NeeGeo ray;
                 ray.o = V3(a.x, a.y, a.z); ray.dist = a.w;
                 ray.wi = V3(b.x, b.y, b.z); ray.nl = b.w;
