@@ -370,10 +370,14 @@ TN_D V3 medium_absorption(const DevScene& sc, int medium, bool hasMedia)
     return V3(c.x, c.y, c.z);
 }
 
-TN_D void load_state(const DevScene& sc, const SplitState& ss, int buf, uint32_t pos, PathRegs& p, uint32_t& slot, bool hasMedia)
+// one of the two buffers of the path state: five arrays by position
+struct StateBuf { float4 *rayO, *rayD, *thr, *rad, *rngId; };
+TN_D StateBuf state_buf(const SplitState& ss, int buf) { StateBuf b = { ss.rayO[buf], ss.rayD[buf], ss.thr[buf], ss.rad[buf], ss.rngId[buf] }; return b; }
+
+TN_D void load_state(const DevScene& sc, const StateBuf& sb, uint32_t pos, PathRegs& p, uint32_t& slot, bool hasMedia)
 {
-    const float4 ro = ss.rayO[buf][pos], rd = ss.rayD[buf][pos], th = ss.thr[buf][pos], ra = ss.rad[buf][pos];
-    const float4 rr = ss.rngId[buf][pos];
+    const float4 ro = sb.rayO[pos], rd = sb.rayD[pos], th = sb.thr[pos], ra = sb.rad[pos];
+    const float4 rr = sb.rngId[pos];
     p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
     p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
     p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
@@ -384,13 +388,23 @@ TN_D void load_state(const DevScene& sc, const SplitState& ss, int buf, uint32_t
     p.absorption = medium_absorption(sc, p.medium, hasMedia);
 }
 
+TN_D void load_state(const DevScene& sc, const SplitState& ss, int buf, uint32_t pos, PathRegs& p, uint32_t& slot, bool hasMedia)
+{
+    load_state(sc, state_buf(ss, buf), pos, p, slot, hasMedia);
+}
+
+TN_D void store_state(const StateBuf& sb, uint32_t pos, const PathRegs& p, uint32_t slot)
+{
+    sb.rayO[pos] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
+    sb.rayD[pos] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
+    sb.thr[pos] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
+    sb.rad[pos] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
+    sb.rngId[pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), __int_as_float(p.medium));
+}
+
 TN_D void store_state(const SplitState& ss, int buf, uint32_t pos, const PathRegs& p, uint32_t slot)
 {
-    ss.rayO[buf][pos] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
-    ss.rayD[buf][pos] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
-    ss.thr[buf][pos] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
-    ss.rad[buf][pos] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
-    ss.rngId[buf][pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), __int_as_float(p.medium));
+    store_state(state_buf(ss, buf), pos, p, slot);
 }
 
 // ---------------------------------------------------------------------------
@@ -522,6 +536,24 @@ TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slo
 // through ALL the bounces of a batch -- no launch boundary and no tail between bounces (what a 1 M-path batch spends most of its
 // time in), no k_region_order launches; the dispatcher balances the workgroups over whole paths instead of over bounces.  Between
 // two bounces a workgroup-scope fence (and a barrier where waves share regions) orders the state stores before their loads.
+// k_bounce reads three groups of its by-value arguments from the kernel-argument segment WHERE THEY ARE USED, through a pointer the
+// compiler cannot see through (so it cannot hoist the scalar loads back to the top): the camera (21 words, bounce 0 only), the sky (probe
+// tables, horizon, zenith: 20 words, only for a ray that left the scene or a probe sample) and the path state's pointers (22 words, a
+// dozen instructions at each end of a round).  As plain arguments they sat in SGPRs -- or in the VGPR lanes SGPRs spill to, and the
+// VGPRs those displace in scratch -- through every bounce: 340 -> 131 v_readlane, scratch 268 -> 216 B in cornell's variant; cornell
+// 4297 -> 4404 Msamples/s at 20 passes, veach 4K 2813 -> 2902, gloss 11 062 -> 11 838, env_loft 5537 -> 5753, a 1 M-path batch 2782 -> 2881
+// (profiles/r04_r_ab_late_kernargs.md; -DTN_LATE_CAMERA=0 -DTN_LATE_SKY=0 -DTN_LATE_STATE=0: the plain arm)
+#ifndef TN_LATE_CAMERA
+#define TN_LATE_CAMERA 1
+#endif
+#ifndef TN_LATE_SKY
+#define TN_LATE_SKY 1
+#endif
+#ifndef TN_LATE_STATE
+#define TN_LATE_STATE 1
+#endif
+// k_bounce's kernel arguments as the launch lays them out (a C struct of the parameters in order): for offsetof
+struct BounceKernargs { DevScene scIn; SplitState ss; QueueCtl q; int bounceBegin, bounceEnd, stackEntries; CameraParams cam; FrameParams fp; const uint32_t* passSeeds; const uint32_t* order; };
 template <bool COUNT, bool LDS, bool DEFER>
 __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scIn, SplitState ss, QueueCtl q, int bounceBegin, int bounceEnd, int stackEntries, CameraParams cam,
                                                    FrameParams fp, const uint32_t* __restrict__ passSeeds, const uint32_t* __restrict__ order)
@@ -534,6 +566,46 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
     uint32_t* const pool = s_stack + stackEntries*kBlock + kScanWords + (threadIdx.x/kWave)*kPoolWordsPerWave;
     SceneT<LDS, false, DEFER ? 1 : 0> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords + (repack ? kPoolWords : 0));
+#if TN_LATE_STATE
+    // the path state's pointers (ten of them and the radiance array: 22 SGPRs that a round needs for a dozen instructions at its start
+    // and its end) from the kernel-argument segment where they are used: `ssIn(buf)` what load_state reads of buffer `buf`, `ssOut(buf)`
+    // what store_state writes, `radOutNow()` the radiance array of finished paths
+    typedef const __attribute__((address_space(4))) SplitState* StatePtr;
+    auto state_args = [&]() {
+        StatePtr sp = (StatePtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(BounceKernargs, ss));
+        asm volatile("" : "+s"(sp));
+        return sp;
+    };
+    auto ssBuf = [&](int buf) {
+        StatePtr sp = state_args();
+        StateBuf b = { sp->rayO[buf], sp->rayD[buf], sp->thr[buf], sp->rad[buf], sp->rngId[buf] };
+        return b;
+    };
+    auto radOutNow = [&]() { return state_args()->radOut; };
+#define TN_SS_BUF(buf) ssBuf(buf)
+#define TN_RAD_OUT radOutNow()
+#else
+#define TN_SS_BUF(buf) state_buf(ss, buf)
+#define TN_RAD_OUT ss.radOut
+#endif
+#if TN_LATE_SKY
+    // the sky (probe tables, horizon, zenith: 20 words that only a ray that LEFT the scene or a probe sample reads) from the kernel-argument
+    // segment where it is needed, like the camera below: on_miss / nee_sample_probe read nothing else of the scene
+    auto late_sky = [&]() {
+        typedef const __attribute__((address_space(4))) DevScene* ScenePtr;
+        ScenePtr sp = (ScenePtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(BounceKernargs, scIn));
+        asm volatile("" : "+s"(sp));
+        DevScene s;
+        s.probe.data = sp->probe.data; s.probe.pdfX = sp->probe.pdfX; s.probe.cdfX = sp->probe.cdfX; s.probe.pdfY = sp->probe.pdfY; s.probe.cdfY = sp->probe.cdfY;
+        s.probe.width = sp->probe.width; s.probe.height = sp->probe.height; s.probe.valid = sp->probe.valid; s.probe.alias = sp->probe.alias;
+        for (int c = 0; c < 3; ++c)
+        {
+            s.horizon[c] = sp->horizon[c];
+            s.zenith[c] = sp->zenith[c];
+        }
+        return s;
+    };
+#endif
 
     const uint32_t lane = __lane_id();
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -620,9 +692,23 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                     if (gen_slot(fp, base + j, slot))
                     {
                         float rx, ry;
+#if TN_LATE_CAMERA
+                        // the camera (21 words, read by bounce 0 only) is fetched from the kernel-argument segment HERE, by scalar loads the
+                        // compiler may not hoist: as a by-value argument it sat in SGPRs (or their spill lanes) through every bounce
+                        typedef const __attribute__((address_space(4))) CameraParams* CamPtr;
+                        CamPtr camp = (CamPtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(BounceKernargs, cam));
+                        asm volatile("" : "+s"(camp));
+                        CameraParams camNow;
+                        for (int w = 0; w < 16; ++w)
+                            camNow.r2w[w] = camp->r2w[w];
+                        camNow.ox = camp->ox; camNow.oy = camp->oy; camNow.oz = camp->oz;
+                        camNow.shutterStart = camp->shutterStart; camNow.shutterEnd = camp->shutterEnd;
+                        have = begin_path(camNow, fp, passSeeds, slot, p, rx, ry);
+#else
                         have = begin_path(cam, fp, passSeeds, slot, p, rx, ry);
+#endif
                         if (!have)
-                            ss.radOut[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            TN_RAD_OUT[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         else
                             samples++;
                     }
@@ -640,7 +726,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                     }
                     else
                         pos = region_pos(base, rLen, nFront, j);
-                    load_state(sc, ss, cur, pos, p, slot, hasMedia);
+                    load_state(sc, TN_SS_BUF(cur), pos, p, slot, hasMedia);
                     have = true;
                 }
             }
@@ -654,8 +740,12 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                 TN_TICK(1)
                 if (prim < 0)
                 {
+#if TN_LATE_SKY
+                    on_miss(late_sky(), p, bounce);
+#else
                     on_miss(sc, p, bounce);
-                    ss.radOut[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
+#endif
+                    TN_RAD_OUT[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
                     have = false;
                 }
             }
@@ -704,7 +794,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                             float skyPdf = 0.0f;
                             int light = -1;
                             if (sc.probe.valid && k == 0)
+#if TN_LATE_SKY
+                                nee_sample_probe(late_sky(), h.p, h.n, p.rng, g, skyColor, skyPdf);
+#else
                                 nee_sample_probe(sc, h.p, h.n, p.rng, g, skyColor, skyPdf);
+#endif
                             else
                             {
                                 light = lights.next(sc);
@@ -745,11 +839,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                     // the next bounce, sorted: rays that meet a bounded primitive's box in front, plane-only rays at the back
                     front = !sc.sortQueues || ray_meets_bounded_prim(sc, p.o, p.d);
                 else
-                    ss.radOut[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
+                    TN_RAD_OUT[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
             }
             const uint32_t np = out.push(alive, front);
             if (alive)
-                store_state(ss, nxt, np, p, slot);
+                store_state(TN_SS_BUF(nxt), np, p, slot);
             if (flush)
                 break;
         }
@@ -787,6 +881,9 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
 // depend on queue order; what changes is that a wave of k_extend / k_shadow is either full of rays that walk the big
 // mesh's BVH or has none (measured on the 524k-triangle config: 60 % of the rays enter the mesh, and unsorted,
 // practically every wave paid for the walk with 23 % of its lanes active).
+#undef TN_SS_BUF
+#undef TN_RAD_OUT
+
 struct BinPrims
 {
     int count;
