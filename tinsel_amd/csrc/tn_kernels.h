@@ -1310,11 +1310,11 @@ struct ShadeFetch
 
     // `fresh`: bounce 0 -- throughput, radiance, medium and ray type are path_begin's constants (render.cpp:233-248), which
     // k_generate therefore does not write
-    TN_D void issue(const SplitState& ss, int buf, uint32_t pos, bool valid, bool hasMedia, bool hasNee, bool fresh)
+    TN_D void issue(const StateBuf& sb, const float4* hit, const int32_t* hitPrim, const uint32_t* pathNee, uint32_t pos, bool valid, bool hasNee, bool fresh)
     {
         if (!valid)
             return;
-        ro = ss.rayO[buf][pos]; rd = ss.rayD[buf][pos];
+        ro = sb.rayO[pos]; rd = sb.rayD[pos];
         if (fresh)
         {
             th = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
@@ -1322,12 +1322,16 @@ struct ShadeFetch
         }
         else
         {
-            th = ss.thr[buf][pos]; ra = ss.rad[buf][pos];
+            th = sb.thr[pos]; ra = sb.rad[pos];
         }
-        rr = ss.rngId[buf][pos];
-        hh = ss.hit[pos];
-        prim = ss.hitPrim[pos];
-        qn = hasNee ? ss.pathNee[pos] : 0u;
+        rr = sb.rngId[pos];
+        hh = hit[pos];
+        prim = hitPrim[pos];
+        qn = hasNee ? pathNee[pos] : 0u;
+    }
+    TN_D void issue(const SplitState& ss, int buf, uint32_t pos, bool valid, bool hasMedia, bool hasNee, bool fresh)
+    {
+        issue(state_buf(ss, buf), ss.hit, ss.hitPrim, ss.pathNee, pos, valid, hasNee, fresh);
     }
 
     // (the medium's absorption is the caller's to look up: medium_absorption)
@@ -1349,9 +1353,11 @@ struct ShadeFetch
 // SHADOW: the shadow rays are traced HERE, between on_hit_begin and the BSDF terms (k_shade's variant that replaces k_shadow: the rays'
 // mesh parts already lie in k_walk's records) -- the same trace<> call on the same ray as k_shadow's, the same acceptance tests
 struct NoStack {};
-template <class SC, bool SHADOW = false, class Stack = NoStack>
+struct NoSky {};
+// `sky`: a callable that returns a DevScene with the probe / horizon / zenith fields set (k_shade's late loads), or NoSky: read them from sc
+template <class SC, bool SHADOW = false, class Stack = NoStack, class Sky = NoSky>
 TN_D bool shade_path(SC& sc, const SplitState& ss, const ShadeFetch& f, int bounce, int maxDepth, int rrStart, const BinPrims& bp,
-                     PathRegs& p, uint32_t& slot, bool& front, Stack* st = nullptr, uint32_t walkPrims = 0u, uint32_t* shadowRays = nullptr)
+                     PathRegs& p, uint32_t& slot, bool& front, Stack* st = nullptr, uint32_t walkPrims = 0u, uint32_t* shadowRays = nullptr, Sky sky = Sky())
 {
     const int K = ss.neePerPath;
     bool alive = false;
@@ -1360,7 +1366,10 @@ TN_D bool shade_path(SC& sc, const SplitState& ss, const ShadeFetch& f, int boun
     const int prim = f.prim;
     if (prim < 0)
     {
-        on_miss(sc, p, bounce);
+        if constexpr (std::is_same<Sky, NoSky>::value)
+            on_miss(sc, p, bounce);
+        else
+            on_miss(sky(), p, bounce);
     }
     else
     {
@@ -1432,6 +1441,11 @@ TN_D bool shade_path(SC& sc, const SplitState& ss, const ShadeFetch& f, int boun
     return alive;
 }
 
+#ifndef TN_LATE_SHADE
+#define TN_LATE_SHADE 0
+#endif
+// k_shade's kernel arguments as the launch lays them out (for offsetof)
+struct ShadeKernargs { DevScene scIn; SplitState ss; int bounce, maxDepth, rrStart; BinPrims bp; const uint32_t* order; QueueCtl q; int stackEntries; const float4* walkRec; uint32_t walkPrims; };
 // SHADOW (with WONLY as in k_shadow): the variant that traces the shadow rays itself (shade_path) -- LDS laid out like k_shadow's (stacks,
 // kScanWords, arena), k_walk's records and the ray counters as arguments
 template <bool LDS, bool MIXED = false, bool SHADOW = false, bool WONLY = false>
@@ -1448,6 +1462,30 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
     const int cur = bounce & 1, nxt = cur ^ 1;
     const int K = ss.neePerPath;
     const bool hasMedia = sc.hasMedia != 0;
+#if TN_LATE_SHADE
+    // like k_bounce (above): the path state's and the hand-over records' pointers, and the sky, from the kernel-argument segment where a
+    // round uses them, not in SGPRs (or their spill lanes) through the whole of it
+    typedef const __attribute__((address_space(4))) SplitState* StatePtr;
+    auto state_args = [&]() {
+        StatePtr sp = (StatePtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ShadeKernargs, ss));
+        asm volatile("" : "+s"(sp));
+        return sp;
+    };
+    auto late_sky = [&]() {
+        typedef const __attribute__((address_space(4))) DevScene* ScenePtr;
+        ScenePtr sp = (ScenePtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ShadeKernargs, scIn));
+        asm volatile("" : "+s"(sp));
+        DevScene s2;
+        s2.probe.data = sp->probe.data; s2.probe.pdfX = sp->probe.pdfX; s2.probe.cdfX = sp->probe.cdfX; s2.probe.pdfY = sp->probe.pdfY; s2.probe.cdfY = sp->probe.cdfY;
+        s2.probe.width = sp->probe.width; s2.probe.height = sp->probe.height; s2.probe.valid = sp->probe.valid; s2.probe.alias = sp->probe.alias;
+        for (int c = 0; c < 3; ++c)
+        {
+            s2.horizon[c] = sp->horizon[c];
+            s2.zenith[c] = sp->zenith[c];
+        }
+        return s2;
+    };
+#endif
 
     for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
@@ -1477,16 +1515,43 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
             }
 #else
             ShadeFetch f;
+#if TN_LATE_SHADE
+            {
+                StatePtr sp = state_args();
+                const StateBuf sb = { sp->rayO[cur], sp->rayD[cur], sp->thr[cur], sp->rad[cur], sp->rngId[cur] };
+                f.issue(sb, sp->hit, sp->hitPrim, sp->pathNee, region_pos(rBase, rLen, nFront, j < n ? j : 0u), j < n, K > 0, bounce == 0);
+            }
+#else
             f.issue(ss, cur, region_pos(rBase, rLen, nFront, j < n ? j : 0u), j < n, hasMedia, K > 0, bounce == 0);
+#endif
 #endif
             bool alive = false, front = true;
             PathRegs p;
             uint32_t slot = 0;
+#if TN_LATE_SHADE
+            if (j < n)
+            {
+                // what shade_path reads of the state: the shadow rays' records and results, the radiance of finished paths
+                StatePtr sp = state_args();
+                SplitState sl;
+                sl.neePerPath = ss.neePerPath; sl.capacity = ss.capacity;
+                sl.neeRes = sp->neeRes; sl.neeRay = sp->neeRay; sl.neeSky = sp->neeSky; sl.radOut = sp->radOut;
+                alive = shade_path<SceneT<LDS, WONLY, 2, MIXED>, SHADOW, LdsStack<kBlock>>(sc, sl, f, bounce, maxDepth, rrStart, bp, p, slot, front, &st, walkPrims, &shadowRays, late_sky);
+            }
+            const uint32_t np = out.push(alive, front);
+            if (alive)
+            {
+                StatePtr sp = state_args();
+                const StateBuf sb = { sp->rayO[nxt], sp->rayD[nxt], sp->thr[nxt], sp->rad[nxt], sp->rngId[nxt] };
+                store_state(sb, np, p, slot);
+            }
+#else
             if (j < n)
                 alive = shade_path<SceneT<LDS, WONLY, 2, MIXED>, SHADOW, LdsStack<kBlock>>(sc, ss, f, bounce, maxDepth, rrStart, bp, p, slot, front, &st, walkPrims, &shadowRays);
             const uint32_t np = out.push(alive, front);
             if (alive)
                 store_state(ss, nxt, np, p, slot);
+#endif
         }
         if (lane == 0)
         {
