@@ -228,4 +228,12 @@ def test_device_libm_is_glibc_bit_for_bit():
     print("sinf mismatches %d, cosf %d of %d ; expf %d of %d" % (bad_s, bad_c, ang.sum(), bad_e, len(x)))
     assert bad_s == 0 and bad_c == 0
     assert bad_e <= 2
+    # atan2f's special cases (e_atan2f.c: infinities, zeros, x == 1), which unit directions never reach: the same C loop, that column only
+    inf = np.float32(np.inf)
+    ys = np.array([inf, -inf, inf, -inf, inf, -inf, 0.5, -0.5, 0.5, -0.5, 0.0, -0.0, 0.0, -0.0, inf, -inf, inf, 0.25, 0.0, -0.0, 1e-38, -1e30], np.float32)
+    xs = np.array([inf, inf, -inf, -inf, 2.5, -7.0, inf, inf, -inf, -inf, inf, inf, -inf, -inf, 3.0, 3.0, 4.0, 4.0, 3.0, 3.0, 3.0, 3.0], np.float32)
+    out2 = r.leaf(7, 0, len(xs), 5, rows=np.stack([xs, ys], axis=1))
+    ref2 = np.zeros((len(xs), 5), np.float32)
+    L.f(len(xs), xs.ctypes.data_as(C.c_void_p), ys.ctypes.data_as(C.c_void_p), ref2.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out2[:, 4].view(np.uint32), ref2[:, 4].view(np.uint32)), (out2[:, 4], ref2[:, 4])
     r.close(); R.free(h)

@@ -473,11 +473,20 @@ TN_D float m_atan2f(float y, float x)
     const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
     if (ix > 0x7f800000 || iy > 0x7f800000)
         return x + y;
-    if (ix == 0x7f800000 || iy == 0x7f800000)
-        return (float)::atan2((double)y, (double)x);            // infinities never reach here from unit directions
-    if (hx == 0x3f800000)
+    if (hx == 0x3f800000 && iy != 0x7f800000)
         return m_atanf(y);
     const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    // infinities (e_atan2f.c's own cases; never reached from unit directions.  They used to go through the double-precision atan2: twenty
+    // coefficients that the compiler hoisted out of every loop around a call site and parked in 152 B of scratch)
+    if (ix == 0x7f800000)
+    {
+        const float pi_o_4 = __uint_as_float(0x3f490fdbu);
+        if (iy == 0x7f800000)
+            return (m == 0) ? pi_o_4 + tiny : (m == 1) ? -pi_o_4 - tiny : (m == 2) ? 3.0f*pi_o_4 + tiny : -3.0f*pi_o_4 - tiny;
+        return (m == 0) ? 0.0f : (m == 1) ? -0.0f : (m == 2) ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000)
+        return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
     if (iy == 0)
         return (m < 2) ? y : ((m == 2) ? pi + tiny : -pi - tiny);
     if (ix == 0)
