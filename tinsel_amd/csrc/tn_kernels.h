@@ -36,8 +36,11 @@ namespace tn {
 #ifndef TN_WAVES_BOUNCE
 #define TN_WAVES_BOUNCE 3
 #endif
+// k_shade: four since the end of round 4 -- with the libm coefficients out of its registers (K64, tn_math.h) the staged-arena variant needs
+// 133 VGPRs and fits 128 without a byte of scratch (glass k_shade 8.9-9.1 -> 8.7-8.9 ms, motionblur 6.3 -> 5.4, many_spheres +1.7 %:
+// profiles/r04_v_ab_k64.md; at three waves it had been 168 VGPRs + 108 B)
 #ifndef TN_WAVES_SHADE
-#define TN_WAVES_SHADE 3
+#define TN_WAVES_SHADE 4
 #endif
 #ifndef TN_WAVES_LIGHTS
 #define TN_WAVES_LIGHTS 4

@@ -263,25 +263,43 @@ TN_HD V3 face_forward(V3 n, V3 v) { return (dot(v, n) < 0.0f) ? -n : n; }
 #endif
 __device__ const unsigned long long kExp2fTab[32] = { 0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL, 0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL, 0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL, 0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL, 0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL, 0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL, 0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL, 0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL };
 #if TN_LIBM_DOUBLE
+// A double-precision constant materialised WHERE IT IS USED, in a scalar register pair (two s_mov_b32 the compiler may neither hoist nor
+// merge).  Written as plain literals, the 25 coefficients of the two routines below are loop invariants to the compiler: it hoists them out
+// of the bounce loop of every kernel that samples a BSDF and keeps them in 24 VGPRs and a dozen SGPRs from the first instruction to the
+// last -- in kernels that spill at their register limit.  -DTN_K64_LOCAL=0: plain literals (A/B)
+#ifndef TN_K64_LOCAL
+#define TN_K64_LOCAL 1
+#endif
+#if TN_K64_LOCAL
+TN_D double k64_here(double c)
+{
+    unsigned hi = (unsigned)(__builtin_bit_cast(unsigned long long, c) >> 32), lo = (unsigned)__builtin_bit_cast(unsigned long long, c);
+    asm volatile("" : "+s"(hi), "+s"(lo));
+    return __hiloint2double((int)hi, (int)lo);
+}
+#define K64(c) k64_here(c)
+#else
+#define K64(c) (c)
+#endif
 TN_D void sincos_wide(double x, float& s, float& c)
 {
-    const double kd = ::rint(x*0.63661977236758138);            // 2/pi
+    const double kd = ::rint(x*K64(0.63661977236758138));            // 2/pi
     const int k = (int)kd;
-    double r = ::fma(-kd, 1.5707963267948966, x);               // pi/2 (hi)
-    r = ::fma(-kd, 6.123233995736766e-17, r);                   // pi/2 (lo)
+    double r = ::fma(-kd, K64(1.5707963267948966), x);               // pi/2 (hi)
+    r = ::fma(-kd, K64(6.123233995736766e-17), r);                   // pi/2 (lo)
     const double z = r*r;
     // fdlibm __kernel_sin / __kernel_cos
-    double ps = ::fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = ::fma(z, ps, 2.75573137070700676789e-06);
-    ps = ::fma(z, ps, -1.98412698298579493134e-04);
-    ps = ::fma(z, ps, 8.33333333332248946124e-03);
-    ps = ::fma(z, ps, -1.66666666666666324348e-01);
+    double ps = ::fma(z, K64(1.58969099521155010221e-10), K64(-2.50507602534068634195e-08));
+    ps = ::fma(z, ps, K64(2.75573137070700676789e-06));
+    ps = ::fma(z, ps, K64(-1.98412698298579493134e-04));
+    ps = ::fma(z, ps, K64(8.33333333332248946124e-03));
+    ps = ::fma(z, ps, K64(-1.66666666666666324348e-01));
     const double sr = ::fma(z*r, ps, r);
-    double pc = ::fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = ::fma(z, pc, -2.75573143513906633035e-07);
-    pc = ::fma(z, pc, 2.48015872894767294178e-05);
-    pc = ::fma(z, pc, -1.38888888888741095749e-03);
-    pc = ::fma(z, pc, 4.16666666666666019037e-02);
+    double pc = ::fma(z, K64(-1.13596475577881948265e-11), K64(2.08757232129817482790e-09));
+    pc = ::fma(z, pc, K64(-2.75573143513906633035e-07));
+    pc = ::fma(z, pc, K64(2.48015872894767294178e-05));
+    pc = ::fma(z, pc, K64(-1.38888888888741095749e-03));
+    pc = ::fma(z, pc, K64(4.16666666666666019037e-02));
     const double cr = ::fma(z*z, pc, ::fma(z, -0.5, 1.0));
     const double sv = (k & 1) ? cr : sr;
     const double cv = (k & 1) ? sr : cr;
@@ -308,21 +326,21 @@ TN_D void m_sincosf(float y, float& s, float& c)
     double xr = x;
     if (y >= 0x1.921FB6p-1f)                                    // |y| >= pi/4: reduce_fast
     {
-        const double r = x*0x1.45F306DC9C883p+23;               // hpi_inv = 2/pi * 2^24
+        const double r = x*K64(0x1.45F306DC9C883p+23);               // hpi_inv = 2/pi * 2^24
         n = ((int)r + 0x800000) >> 24;
-        xr = ::fma(-(double)n, 0x1.921FB54442D18p0, x);
+        xr = ::fma(-(double)n, K64(0x1.921FB54442D18p0), x);
     }
     const double x2 = xr*xr;
     // sinf_poly's two branches (table entries 0/1 differ only in the sign of the cosine coefficients)
     const double x3 = xr*x2;
-    const double s1 = ::fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+    const double s1 = ::fma(x2, K64(-0x1.994eb3774cf24p-13), K64(0x1.1107605230bc4p-7));
     const double x5 = x3*x2;
-    const double sp = ::fma(x5, s1, ::fma(x3, -0x1.555545995a603p-3, xr));                 // sin(xr)
+    const double sp = ::fma(x5, s1, ::fma(x3, K64(-0x1.555545995a603p-3), xr));                 // sin(xr)
     const double x4 = x2*x2;
-    const double c2 = ::fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
-    const double c1 = ::fma(x2, -0x1.ffffffd0c621cp-2, 1.0);
+    const double c2 = ::fma(x2, K64(0x1.99343027bf8c3p-16), K64(-0x1.6c087e89a359dp-10));
+    const double c1 = ::fma(x2, K64(-0x1.ffffffd0c621cp-2), 1.0);
     const double x6 = x4*x2;
-    const double cp = ::fma(x6, c2, ::fma(x4, 0x1.55553e1068f19p-5, c1));                  // cos(xr)
+    const double cp = ::fma(x6, c2, ::fma(x4, K64(0x1.55553e1068f19p-5), c1));                  // cos(xr)
     // quadrant n: sin y = {sp, cp, -sp, -cp}[n&3], cos y = {cp, -sp, -cp, sp}[n&3]  (the sign[] / table[1]
     // bookkeeping of s_sinf.c / s_cosf.c: negating x or the polynomial is exact, so signs commute)
     const double sv = (n & 1) ? cp : sp;
@@ -337,9 +355,12 @@ TN_D float m_cosf(float x) { float s, c; m_sincosf(x, s, c); return c; }
 // glibc 2.35 expf, the __expf_fma ifunc variant an FMA-capable x86-64 host runs (e_expf.c, non-TOINT path: the
 // SHIFT trick; the compiler contracted InvLn2N*x + SHIFT and InvLn2N*x - kd into FMAs there, so they are FMAs here)
 // `tab`: kExp2fTab or a copy of it (kernels that call this in a tight loop keep one in LDS)
-template <class Tab>
+// LOCAL: the five double constants materialised where they are used (K64 above) -- the path kernels' Beer-Lambert term; the accumulate
+// kernel, which calls this six times per staged path and has registers to spare, keeps the literals
+template <class Tab, bool LOCAL = false>
 TN_D float m_expf_tab(float xf, const Tab& tab)
 {
+#define KE(c) (LOCAL ? K64(c) : (c))
     const uint32_t ix = __float_as_uint(xf);
     const uint32_t abstop = (ix >> 20) & 0x7ffu;
     if (abstop > 0x42au)                                        // |x| >= 88 or NaN
@@ -356,20 +377,21 @@ TN_D float m_expf_tab(float xf, const Tab& tab)
             return __uint_as_float(1u);                         // 0x1.4p-75f*0x1.4p-75f: the smallest subnormal
     }
     const double x = (double)xf;
-    double kd = ::fma(0x1.71547652b82fep+5, x, 0x1.8p+52);       // InvLn2N (N = 32), SHIFT
+    double kd = ::fma(KE(0x1.71547652b82fep+5), x, KE(0x1.8p+52));       // InvLn2N (N = 32), SHIFT
     const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
-    kd -= 0x1.8p+52;
-    const double r = ::fma(0x1.71547652b82fep+5, x, -kd);
+    kd -= KE(0x1.8p+52);
+    const double r = ::fma(KE(0x1.71547652b82fep+5), x, -kd);
     unsigned long long t = tab[ki & 31u];
     t += ki << (52 - 5);
     const double sc = __longlong_as_double((long long)t);
-    const double z = ::fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+    const double z = ::fma(KE(0x1.c6af84b912394p-20), r, KE(0x1.ebfce50fac4f3p-13));
     const double r2 = r*r;
-    double yv = ::fma(0x1.62e42ff0c52d6p-6, r, 1.0);
+    double yv = ::fma(KE(0x1.62e42ff0c52d6p-6), r, 1.0);
     yv = ::fma(z, r2, yv);
     return (float)(yv*sc);
+#undef KE
 }
-TN_D float m_expf(float xf) { return m_expf_tab(xf, kExp2fTab); }
+TN_D float m_expf(float xf) { return m_expf_tab<decltype(kExp2fTab), true>(xf, kExp2fTab); }
 TN_D float m_logf(float x) { return (float)::log((double)x); }
 
 // glibc 2.35 __ieee754_acosf (sysdeps/ieee754/flt-32/e_acosf.c, the fdlibm fp32 routine; plain fp32 ops, no
