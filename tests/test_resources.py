@@ -1,0 +1,57 @@
+"""Register / scratch budgets of the hot kernels, as the compiler reported them for THIS build (tinsel_amd/build.py build_verified ->
+tinsel_amd/csrc/_obj/resources.json, written by __graft_entry__.build()).  The occupancy every measured number in DESIGN.md rests on is a
+property of the build, and it has been lost silently before: until the end of round 4 the double-precision coefficients of the restated
+sinf / cosf / expf sat in 24 VGPRs for the whole of every kernel that samples a BSDF, and 152 B of k_bounce's scratch were the constants
+of a double atan2 no ray ever calls ("Where the time goes").  No GPU needed: the numbers come from hipcc."""
+import hashlib
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJ = os.path.join(ROOT, "tinsel_amd", "csrc", "_obj")
+
+
+def _resources():
+    path = os.path.join(OBJ, "resources.json")
+    obj = os.path.join(OBJ, "tinsel_hip.o")
+    if not (os.path.exists(path) and os.path.exists(obj)):
+        pytest.skip("no build record in this tree (python -c 'import __graft_entry__ as g; g.build()' writes it)")
+    rec = json.load(open(path))
+    if rec.get("object_sha256") != hashlib.sha256(open(obj, "rb").read()).hexdigest() or not rec.get("kernels"):
+        pytest.skip("resources.json does not describe the object the library was linked from")
+    return rec["kernels"]
+
+
+def test_the_fused_kernel_runs_three_waves_per_simd_without_scratch():
+    k = _resources()
+    variants = [n for n in k if n.startswith("k_bounce<0,")]            # (the <1,..> ones count detail statistics: not a timed path)
+    assert len(variants) == 4
+    for n in variants:
+        assert k[n]["waves_per_simd"] == 3 and k[n]["vgprs"] <= 168 and k[n]["scratch_bytes"] == 0, (n, k[n])
+
+
+def test_the_shading_kernel_runs_four_waves_per_simd():
+    k = _resources()
+    for n in ("k_shade<1,1,0,0>", "k_shade<1,0,0,0>"):                  # staged arena (+ meshes in HBM): glass, the 524k-triangle config
+        assert k[n]["waves_per_simd"] == 4 and k[n]["vgprs"] <= 128 and k[n]["scratch_bytes"] == 0, (n, k[n])
+    assert k["k_shade<0,0,0,0>"]["waves_per_simd"] == 4 and k["k_shade<0,0,0,0>"]["scratch_bytes"] <= 32
+    for n in (m for m in k if m.startswith("k_shade_sorted<")):
+        assert k[n]["waves_per_simd"] == 4 and k[n]["scratch_bytes"] <= 40, (n, k[n])
+
+
+def test_the_walk_kernels_keep_eight_waves_per_simd():
+    k = _resources()
+    for n in ("k_walk<1024,8,2>", "k_walk<1024,8,0>"):                  # one walked primitive / several (the defaults)
+        assert k[n]["waves_per_simd"] == 8 and k[n]["vgprs"] <= 64 and k[n]["scratch_bytes"] == 0, (n, k[n])
+    for n in (m for m in k if m.startswith("k_swalk<")):
+        assert k[n]["scratch_bytes"] == 0 and k[n]["waves_per_simd"] >= 5, (n, k[n])
+
+
+def test_the_scan_kernels_spill_nothing():
+    k = _resources()
+    for n in (m for m in k if m.startswith(("k_extend<0,", "k_shadow<0,", "k_lights<", "k_generate", "k_accumulate"))):
+        assert k[n]["scratch_bytes"] <= 20, (n, k[n])                  # (k_shadow with inline mesh walks parks 20 B of plane equations)
+    assert k["k_extend<0,1,1,1,1>"]["waves_per_simd"] >= 6              # lean scan + light sampling (the 524k-triangle config)
+    assert k["k_shadow<0,1,1,1>"]["waves_per_simd"] >= 7

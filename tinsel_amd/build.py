@@ -75,6 +75,44 @@ def _compile(obj_dir, extra=(), verbose=True):
             raise subprocess.CalledProcessError(p.returncode, cmd)
 
 
+def _resource_job(tmp):
+    """The parity translation unit's device code once more, with -Rpass-analysis=kernel-resource-usage: registers, scratch and occupancy
+    of every kernel as the compiler reports them.  (A compile of its own: the flag changes the object's bytes, and the shipped object
+    must be the one build() makes.)  Returns the process; parse its stderr with _parse_resources."""
+    cmd = [hipcc()] + HIPCC_FLAGS + ["--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", "resources_only.o"]
+    return subprocess.Popen(cmd, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+
+
+def _kernel_name(mangled):
+    """_ZN2tn8k_bounceILb0ELb1ELb0EE... -> k_bounce<0,1,0>   (template arguments of the kernels here are bools and ints)"""
+    import re
+    m = re.match(r"_ZN2tn\d+(k_[a-z_0-9]+?)(I((?:L[bij]-?n?\d+E)+)E)?(?:v|E|P|N|$)", mangled)
+    if not m:
+        return mangled
+    args = re.findall(r"L[bij](n?\d+)E", m.group(3) or "")
+    return m.group(1) + ("<" + ",".join(a.replace("n", "-") for a in args) + ">" if args else "")
+
+
+def _parse_resources(text):
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+(.*?)\s*\[-Rpass-analysis", line)
+        if not m:
+            continue
+        body = m.group(1)
+        if body.startswith("Function Name:"):
+            cur = out.setdefault(_kernel_name(body.split(":", 1)[1].strip()), {})
+        elif cur is not None and ":" in body:
+            k, v = body.split(":", 1)
+            key = {"VGPRs": "vgprs", "AGPRs": "agprs", "TotalSGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch_bytes",
+                   "Occupancy [waves/SIMD]": "waves_per_simd", "LDS Size [bytes/block]": "static_lds_bytes",
+                   "SGPRs Spill": "sgpr_spills", "VGPRs Spill": "vgpr_spills"}.get(k.strip())
+            if key:
+                cur[key] = int(v.strip())
+    return out
+
+
 def _link(obj_dir, out, verbose=True):
     link = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out, os.path.join(obj_dir, "tinsel_hip.o"), os.path.join(obj_dir, "tinsel_fast.o")]
     if verbose:
@@ -106,7 +144,10 @@ def build_verified(verbose=True):
     t0 = time.time()
     names = ("tinsel_hip.o", "tinsel_fast.o")
     with tempfile.TemporaryDirectory(prefix="tinsel_build_") as tmp:
+        res_proc = _resource_job(tmp)               # (beside the two compiles below: the box has the cores)
         _compile(tmp, (), verbose)
+        res_err = res_proc.communicate()[1]
+        resources = _parse_resources(res_err) if res_proc.returncode == 0 else {}
         fresh = {n: _sha(os.path.join(tmp, n)) for n in names}
         have = {n: (_sha(os.path.join(OBJ_DIR, n)) if os.path.exists(os.path.join(OBJ_DIR, n)) else None) for n in names}
         same = all(fresh[n] == have[n] for n in names) and os.path.exists(OUT) and \
@@ -123,6 +164,10 @@ def build_verified(verbose=True):
         "action": "verified: the in-tree library was linked from byte-identical objects" if same else "rebuilt: objects replaced, library linked again",
         "hipcc": ver[0] if ver else None,
     }
+    # per-kernel registers / scratch / occupancy of THIS build (tests/test_resources.py holds the hot kernels to their budgets)
+    with open(os.path.join(OBJ_DIR, "resources.json"), "w") as f:
+        json.dump({"object_sha256": fresh["tinsel_hip.o"], "kernels": resources}, f, indent=1, sort_keys=True)
+    record["kernels_reported"] = len(resources)
     with open(os.path.join(OBJ_DIR, "build_record.json"), "w") as f:
         json.dump(record, f, indent=1)
     print("[tinsel_amd.build] record:", json.dumps(record), flush=True)
