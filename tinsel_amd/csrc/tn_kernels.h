@@ -1056,8 +1056,10 @@ TN_D WalkPre walk_prefetch(const SC& sc, uint32_t walkPrims, bool front)
 // own for them costs more than it saves (524k-triangle config: 2.1 + 2.9 ms apart, 3.9 together); behind the inline mesh
 // walk it is the other way round (the fused kernel needs 170 VGPRs: glass 21.2 + 7.9 apart, 31.5 together at 3 waves).
 // LIGHTS: the kernel draws the light samples too (always in the lean variant; in the others an A/B: TINSEL_HIP_LIGHTS_IN_EXTEND)
+// (five waves per SIMD since the end of round 4: with the libm coefficients out of its registers the staged-arena variant needs 106 VGPRs,
+// one granule above the limit; at 96 + 36 B of scratch glass's k_extend runs 6.93 -> 6.32 ms, profiles/r04_w_ab_extend5.md)
 #ifndef TN_WAVES_EXTEND_LIGHTS
-#define TN_WAVES_EXTEND_LIGHTS 4
+#define TN_WAVES_EXTEND_LIGHTS 5
 #endif
 template <bool COUNT, bool LDS, bool WONLY = false, bool MIXED = false, bool LIGHTS = WONLY>
 __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_WAVES_EXTEND_LIGHTS : TN_WAVES_TRACE) void k_extend(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
