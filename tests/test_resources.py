@@ -52,6 +52,9 @@ def test_the_walk_kernels_keep_eight_waves_per_simd():
 def test_the_scan_kernels_spill_nothing():
     k = _resources()
     for n in (m for m in k if m.startswith(("k_extend<0,", "k_shadow<0,", "k_lights<", "k_generate", "k_accumulate"))):
-        assert k[n]["scratch_bytes"] <= 20, (n, k[n])                  # (k_shadow with inline mesh walks parks 20 B of plane equations)
+        # (k_shadow with inline mesh walks parks 20 B of plane equations; k_extend's staged-arena variant with light sampling trades 36 B
+        # for its fifth wave per SIMD: glass, profiles/r04_w_ab_extend5.md)
+        assert k[n]["scratch_bytes"] <= (40 if n == "k_extend<0,1,0,1,1>" else 20), (n, k[n])
+    assert k["k_extend<0,1,0,1,1>"]["waves_per_simd"] >= 5
     assert k["k_extend<0,1,1,1,1>"]["waves_per_simd"] >= 6              # lean scan + light sampling (the 524k-triangle config)
     assert k["k_shadow<0,1,1,1>"]["waves_per_simd"] >= 7
