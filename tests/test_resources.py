@@ -58,3 +58,23 @@ def test_the_scan_kernels_spill_nothing():
     assert k["k_extend<0,1,0,1,1>"]["waves_per_simd"] >= 5
     assert k["k_extend<0,1,1,1,1>"]["waves_per_simd"] >= 6              # lean scan + light sampling (the 524k-triangle config)
     assert k["k_shadow<0,1,1,1>"]["waves_per_simd"] >= 7
+
+
+def test_the_build_parses_the_compiler_remarks():
+    """build.py's reading of -Rpass-analysis=kernel-resource-usage (no compiler needed: canned text)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tinsel_amd import build as hb
+    assert hb._kernel_name("_ZN2tn8k_bounceILb0ELb1ELb0EEEvNS_8DevSceneENS_10SplitStateE") == "k_bounce<0,1,0>"
+    assert hb._kernel_name("_ZN2tn6k_walkILi1024ELi8ELi2EEEvNS_7WalkJobE") == "k_walk<1024,8,2>"
+    assert hb._kernel_name("_ZN2tn10k_generateENS_10SplitStateENS_8QueueCtlE") == "k_generate"
+    text = """
+a.h:33:1: remark: Function Name: _ZN2tn7k_shadeILb1ELb1ELb0ELb0EEEvNS_8DevSceneE [-Rpass-analysis=kernel-resource-usage]
+a.h:33:1: remark:     TotalSGPRs: 106 [-Rpass-analysis=kernel-resource-usage]
+a.h:33:1: remark:     VGPRs: 128 [-Rpass-analysis=kernel-resource-usage]
+a.h:33:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
+a.h:33:1: remark:     Occupancy [waves/SIMD]: 4 [-Rpass-analysis=kernel-resource-usage]
+a.h:33:1: remark:     SGPRs Spill: 52 [-Rpass-analysis=kernel-resource-usage]
+"""
+    got = hb._parse_resources(text)
+    assert got == {"k_shade<1,1,0,0>": {"sgprs": 106, "vgprs": 128, "scratch_bytes": 0, "waves_per_simd": 4, "sgpr_spills": 52}}
