@@ -555,6 +555,9 @@ TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slo
 #ifndef TN_LATE_STATE
 #define TN_LATE_STATE 1
 #endif
+#ifndef TN_LATE_FRAME
+#define TN_LATE_FRAME 0             // a lead for the next round (needs TN_LATE_CAMERA): compiles, not yet run on a GPU
+#endif
 // k_bounce's kernel arguments as the launch lays them out (a C struct of the parameters in order): for offsetof
 struct BounceKernargs { DevScene scIn; SplitState ss; QueueCtl q; int bounceBegin, bounceEnd, stackEntries; CameraParams cam; FrameParams fp; const uint32_t* passSeeds; const uint32_t* order; };
 template <bool COUNT, bool LDS, bool DEFER>
@@ -706,7 +709,16 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                             camNow.r2w[w] = camp->r2w[w];
                         camNow.ox = camp->ox; camNow.oy = camp->oy; camNow.oz = camp->oz;
                         camNow.shutterStart = camp->shutterStart; camNow.shutterEnd = camp->shutterEnd;
+#if TN_LATE_FRAME
+                        // (prepared, unmeasured: the frame parameters and the seed table that only bounce 0 reads, fetched here as well)
+                        typedef const __attribute__((address_space(4))) BounceKernargs* ArgsPtr;
+                        ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                        asm volatile("" : "+s"(ap));
+                        const FrameParams fpNow = ap->fp;
+                        have = begin_path(camNow, fpNow, ap->passSeeds, slot, p, rx, ry);
+#else
                         have = begin_path(camNow, fp, passSeeds, slot, p, rx, ry);
+#endif
 #else
                         have = begin_path(cam, fp, passSeeds, slot, p, rx, ry);
 #endif
