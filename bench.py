@@ -2,22 +2,22 @@
 """bench.py -- Msamples/s and Mrays/s of the hot path on N MI355X (one process per GPU).
 
 A "step" is one pass of the hot path over one batch of synthetic input: one sample per pixel.  The default run (N = 1)
-times the FOUR GPU configurations of BASELINE.json and prints ONE JSON line (`configs`: the headline first):
+times the FOUR GPU configurations of BASELINE.json and prints ONE SMALL JSON line (<= 6 KB: the contract's fields for the headline,
+`configs`: one compact object per other configuration); the full records -- per-kernel tables, counter calibration, yard-sticks, API
+legs, per-rank statistics -- go to bench_detail.json beside this file (and to stderr behind "bench_detail: ").
 
-  configs[0] / headline   BASELINE configs[1]: data/cornell.tin 1024x1024 maxDepth 4 (spp 256 <=> --steps 256).  The
-                          scene (2.6 KB) lives in LDS: the path is bound by VALU issue, and `roofline` says so
-                          (bound "valu": wave-instructions issued per second against SIMDs x clock / 2).
-  configs[1]              BASELINE configs[2]: data/ajax.tin with the 524,288-triangle stand-in mesh (ajax.obj is not in
-                          the reference tree) at 1920x1080 maxDepth 4 -- the configuration whose scene lives in HBM / the
-                          Infinity Cache.  Its roofline carries BOTH HBM fractions: algorithmic bytes (SURVEY.md 8d's
-                          B_ray model) and counter bytes, each divided by time and by 8 TB/s; the node-visit rate of k_walk
-                          next to the record-chase ceilings measured on this GPU in this run (tinsel_hip_ubench).
-  configs[2]              BASELINE configs[3]: data/glass.tin 1920x1080 maxDepth 12.
-  configs[3]              BASELINE configs[4]: data/veach.tin 3840x2160 (one GPU's share of it at N = 1: the whole frame).
+  headline     BASELINE configs[1]: data/cornell.tin 1024x1024 maxDepth 4 (spp 256 <=> --steps 256).  The scene (2.6 KB) lives in
+               LDS: the path is bound by VALU issue, and `roofline` says so (bound "valu": wave-instructions issued per second
+               against SIMDs x clock / 2).
+  configs[0]   BASELINE configs[2]: data/ajax.tin with the 524,288-triangle stand-in mesh (ajax.obj is not in the reference tree)
+               at 1920x1080 maxDepth 4 -- the configuration whose scene lives in HBM / the Infinity Cache (HBM fractions from
+               counter bytes; the node-visit rate of k_walk next to this GPU's record-chase ceilings in the detail file).
+  configs[1]   BASELINE configs[3]: data/glass.tin 1920x1080 maxDepth 12.
+  configs[2]   BASELINE configs[4]: data/veach.tin 3840x2160 (at N = 1 the whole frame; at N > 1 every rank's pixel tiles of it).
 
 Scenes come from scene packs written by the reference's own loader (tests/golden/*.pack); camera rays, RNG seeds and
 everything downstream are generated on the GPU, so inputs are resident in HBM when a timed region starts, and the
-accumulation buffer stays in HBM (`pcie_inclusive_*` and `api_1pass_*` report the API's per-call D2H separately).
+accumulation buffer stays in HBM (`api_msamples_s` reports the API's per-call D2H patterns separately).
 
 Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize()
 on both sides, repeated until >= 0.5 s have been timed; `ms_per_step` is the MEDIAN block / K, `value` the samples of
@@ -28,14 +28,16 @@ Counters: `roofline.traffic` (HBM bytes per launch of the dominant kernel) and t
 `rocprofv3 --pmc` (separate passes for FETCH_SIZE, WRITE_SIZE, the SQ counters and TCC hits / misses).  What one count of
 FETCH_SIZE / WRITE_SIZE stands for is CALIBRATED in the same passes on kernels with a known byte count
 (tinsel_hip_ubench: a float4 stream copy for the streaming kernels -- the guide's gfx950 x2 -- and dependent 64-B record
-chases through a 1 GiB table, beyond the Infinity Cache, for the walking kernels); the factors are in the line
+chases through a 1 GiB table, beyond the Infinity Cache, for the walking kernels); the factors are in the detail file
 (`counter_calibration`).  When rocprofv3 is not available the fields are null -- nothing is read from a stored file.
 
-N > 1 (launched by torch.distributed.run): weak scaling -- every rank traces its interleaved pixel tiles for K*N passes
-(same paths per GPU as N = 1), then ONE RCCL sum-reduce of the float4 accumulator to rank 0 inside the timed region
-(tinsel_amd.distributed.reduce_accum: out of place, the ranks' accumulators keep their own partial sums).  Before the ranks
-meet, rank 0 also times the SAME N devices through the library's own multi-GPU path (`--group`: tinsel_hip_group, what the
-reference's single-process C++ caller gets through the shim) in a child process with a time limit: `group` in the line.
+N > 1 (launched by torch.distributed.run; the ranks meet at once, under a 90 s watchdog): `value` is WEAK scaling -- every rank
+traces its interleaved pixel tiles for K*N passes (same paths per GPU as N = 1), then ONE RCCL sum-reduce of the float4 accumulator
+to rank 0 inside the timed region (tinsel_amd.distributed.reduce_accum).  `strong_msamples_s` is the FIXED-WORK leg beside it: the
+same K full-frame passes as N = 1 split over the ranks' tiles + the reduce (north_star's 8-GPU configuration, veach 4K at 4096
+spp, is a fixed job); veach 4K gets both legs too (`configs`).  AFTER the ranks' timed regions rank 0 times the SAME N devices
+through the library's own multi-GPU path (`--group`: tinsel_hip_group, what the reference's single-process C++ caller gets through
+the shim) in child processes limited to 60 s each: `group`, `group_cfg5`.
 """
 import argparse
 import csv
@@ -61,6 +63,7 @@ SIMDS = 256*4                   # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9                # max clock, same guide
 VALU_PEAK = SIMDS*CLOCK_HZ/2    # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (same guide; scratch/ubench/valu_bench.hip: 2.6)
 MIN_TIMED_S = 0.5
+GROUP_LEG_LIMIT_S = 60            # each tinsel_hip_group leg of an N-rank run (child process of rank 0, after the ranks' timed regions)
 LARGE = "large/ajax_standin"
 YARD = [None]                   # this run's yard-sticks (yard_sticks(): stream copy, record chases), N = 1 only
 
@@ -277,8 +280,9 @@ def yard_sticks():
 
 # ---------------------------------------------------------------------------------------------------------------------
 
-def run_config(args, scene_name, width, height, maxdepth, rank, world, local, dist, backend, torch, with_extras):
-    """Times one configuration per the contract; returns (dict for the JSON line, elapsed seconds of the median block)."""
+def run_config(args, scene_name, width, height, maxdepth, rank, world, local, dist, backend, torch, with_extras, cfg_spp=256):
+    """Times one configuration per the contract; returns the dict bench_detail.json keeps for it (rank 0; None elsewhere).
+    `cfg_spp`: the samples per pixel BASELINE.json quotes the configuration at (the tolerance arm's L2 is taken at that spp)."""
     import tinsel_amd
     from tinsel_amd import abi
 
@@ -312,8 +316,8 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     total_buf = torch.empty_like(accum) if world > 1 else None     # the reduce target: allocated outside the timed region
     reduced = [accum]
 
-    def run(steps):
-        r.render_async(cam, opt, passes=steps*passes_per_step, stream=stream)
+    def run(steps, per_step=None):
+        r.render_async(cam, opt, passes=steps*(passes_per_step if per_step is None else per_step), stream=stream)
         if world > 1:
             # the ONE collective of the path, out of place: `accum` keeps this rank's own partial sums (a later render + reduce
             # cannot count a sample twice); RCCL over xGMI on the render stream, or the gloo stand-in through host memory
@@ -376,6 +380,26 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     elapsed = statistics.median(blocks)
     st = stats_blocks
 
+    # ---- N > 1: the FIXED-WORK leg (north_star's 8-GPU configuration is a fixed job: veach 4K at 4096 spp).  The same K full-frame
+    # passes as N = 1, split over the ranks' pixel tiles (K passes over 1/N of the pixels each) + the one reduce; same bracketing.
+    strong = None
+    if world > 1:
+        sblocks, stotal = [], 0.0
+        while stotal < MIN_TIMED_S/2 and len(sblocks) < 1000:
+            accum.zero_()
+            sync()
+            t0 = time.perf_counter()
+            run(args.steps, per_step=1)
+            sync()
+            el = time.perf_counter() - t0
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sblocks.append(float(tt.item()))
+            stotal += sblocks[-1]
+        sel = statistics.median(sblocks)
+        strong = {"msamples_s": args.steps*opt.width*opt.height/sel/1e6, "ms_per_step": sel*1e3/args.steps, "timed_blocks": len(sblocks),
+                  "what": "fixed work: the same %d full-frame passes as N = 1, each rank its own pixel tiles, one reduce" % args.steps}
+
     if world > 1:
         small_dev = "cuda" if backend == "nccl" else "cpu"
         cc = torch.tensor([st["rays"], st["samples"], st["shadow_rays"]], dtype=torch.float64, device=small_dev)
@@ -400,16 +424,17 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     # validation mode only: the reduced image of the N-rank run must equal an unsharded render of the same passes
     if os.environ.get("TINSEL_BENCH_ONE_DEVICE") and world > 1:
         torch.cuda.synchronize()
-        last_first = r.get_pass_index() - args.steps*passes_per_step
+        last_passes = args.steps            # (the last render was the fixed-work leg's: K passes)
+        last_first = r.get_pass_index() - last_passes
         chk = tinsel_amd.create_gpu_renderer(scene, local)
         chk.init(opt.width, opt.height)
         chk.set_pass_index(last_first)
-        want = chk.render(cam, opt, passes=args.steps*passes_per_step)
+        want = chk.render(cam, opt, passes=last_passes)
         chk.close()
         got = reduced[0].cpu().numpy()
         ok = np.allclose(got, want, rtol=1e-4, atol=1e-5)
         print("validation: %d-rank reduced image vs unsharded render of passes [%d, %d): %s (max abs diff %.3e)" % (
-            world, last_first, last_first + args.steps*passes_per_step, "ok" if ok else "MISMATCH",
+            world, last_first, last_first + last_passes, "ok" if ok else "MISMATCH",
             float(np.abs(got - want).max())), file=sys.stderr, flush=True)
         if not ok:
             raise SystemExit(3)
@@ -457,20 +482,28 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     fast = None
     if world == 1 and not args.no_fast and args.arith == "exact":
         try:
-            spp = 256
+            spp = cfg_spp           # the configuration's own spp (north_star's tolerance is quoted per configuration)
+            # the distance is per pixel at that spp: where the whole frame at that spp is more than ~4 G samples per arm (veach 4K x 4096) it is
+            # taken on the same view at 1/f of the resolution in both axes (same camera, same seeds rule; SURVEY.md 8c allows sub-sampling)
+            f = 1
+            while (opt.width//f)*(opt.height//f)*spp > 4.0e9 and f < 8:
+                f += 1
+            optL = opt.copy()
+            optL.width, optL.height = opt.width//f, opt.height//f
             rf = tinsel_amd.create_gpu_renderer(scene, local)
             rf.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
-            rf.init(opt.width, opt.height)
+            rf.init(optL.width, optL.height)
             rf.reserve(max(spp, args.steps), opt.max_depth)
-            exact_img = rf.render(cam, opt, passes=spp)
+            exact_img = rf.render(cam, optL, passes=spp)
             rf.set_arithmetic(abi.ARITH_FAST)
-            rf.init(opt.width, opt.height)
+            rf.init(optL.width, optL.height)
             rf.set_pass_index(0)
-            fast_img = rf.render(cam, opt, passes=spp)
+            fast_img = rf.render(cam, optL, passes=spp)
             wa = np.where(exact_img[..., 3:4] > 0, exact_img[..., 3:4], 1.0)
             wb = np.where(fast_img[..., 3:4] > 0, fast_img[..., 3:4], 1.0)
             dd = (exact_img[..., :3]/wa - fast_img[..., :3]/wb).astype(np.float64)
             l2 = float(np.sqrt(np.mean(np.sum(dd*dd, axis=-1))))
+            rf.init(opt.width, opt.height)          # (back at the configuration's own frame, still on the tolerance arm)
             # one pass, path by path: how many paths left the exact path's track (radiance off by > 1e-3 relative)
             rf.set_pass_index(0); rf.render(cam, opt, passes=1, readback=False); rad_f = rf.batch_radiance(1, opt.height, opt.width)
             rf.set_arithmetic(abi.ARITH_EXACT)
@@ -486,7 +519,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
                 fblocks.append(time.perf_counter() - t0)
                 ftotal += fblocks[-1]
             rf.close()
-            fast = {"msamples_s": args.steps*opt.width*opt.height/statistics.median(fblocks)/1e6, "l2_vs_exact_at_spp": [l2, spp],
+            fast = {"msamples_s": args.steps*opt.width*opt.height/statistics.median(fblocks)/1e6, "l2_vs_exact_at_spp": [l2, spp], "l2_frame": [optL.width, optL.height],
                     "divergent_paths_fraction": float((rel > 1e-3).mean()), "identical_paths_fraction": float((rad_f == rad_e).all(axis=-1).mean())}
         except Exception as e:
             fast = {"msamples_s": None, "error": str(e)}
@@ -678,6 +711,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     }
     if world > 1:
         res["ranks"] = {"communicator_world_size": dist.get_world_size(), "backend": backend, "per_rank": per_rank}
+        res["strong"] = strong
     r.close()
     return res
 
@@ -746,13 +780,13 @@ def group_leg(args, world, scene=None, width=None, height=None, maxdepth=None):
            "--scene", scene or args.scene, "--width", str(width or args.width), "--height", str(height or args.height),
            "--maxdepth", str(args.maxdepth if maxdepth is None else maxdepth), "--tile", str(args.tile)]
     try:
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=GROUP_LEG_LIMIT_S)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if p.returncode == 0 and lines:
             return json.loads(lines[-1])
         return {"unavailable": "exit %d: %s" % (p.returncode, (p.stderr or "").strip().splitlines()[-1:] or "")}
     except subprocess.TimeoutExpired:
-        return {"unavailable": "timed out after 240 s"}
+        return {"unavailable": "timed out after %d s" % GROUP_LEG_LIMIT_S}
     except Exception as e:
         return {"unavailable": str(e)}
 
@@ -782,8 +816,7 @@ def first_collective_watchdog(args, rank, world, backend, seconds=None):
     """A timer around the rendezvous + first all-reduce.  When it fires, rank 0 prints the contract's JSON line with value null and a
     readable `unavailable` reason, and every rank leaves (os._exit: a hung collective cannot be interrupted)."""
     import threading
-    # rank 0 may spend up to 2 x 240 s in the tinsel_hip_group legs before it joins: the other ranks' timers allow for that
-    limit = seconds if seconds is not None else (60.0 if args.no_group_leg else 60.0 + 2*240.0)
+    limit = seconds if seconds is not None else 90.0
 
     def fire():
         if rank == 0:
@@ -799,6 +832,110 @@ def first_collective_watchdog(args, rank, world, backend, seconds=None):
     t.daemon = True
     t.start()
     return t
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the contract line: SMALL (the driver reads it from a bounded window of stdout: round 4's 28.5 KB line was not parsed).  Everything
+# else -- per-kernel tables, calibration, yard-sticks, per-rank statistics, the API legs' details -- goes to bench_detail.json.
+
+LINE_LIMIT_BYTES = 6144
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_model", "kernel", "launches", "avg_launch_ms", "traffic",
+                 "frac_hbm_algorithmic", "frac_hbm_counter", "job_counter_over_compulsory", "valu_lanes_active", "wave_cycles_waiting",
+                 "waves_per_simd", "l2_hit_rate")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+BASELINE_INDEX = {"cornell": 1, LARGE: 2, "glass": 3, "veach": 4}      # scene -> index into BASELINE.json's `configs`
+CONFIG_SPP = {"cornell": 256, LARGE: 512, "glass": 1024, "veach": 4096}
+
+
+def _round(o, digits=5):
+    """floats to `digits` significant digits, recursively (the line is for reading and parsing, the detail file keeps everything)"""
+    if isinstance(o, float):
+        return float("%.*g" % (digits, o)) if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _round(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round(v, digits) for v in o]
+    return o
+
+
+def _pick(d, keys):
+    return {k: d.get(k) for k in keys} if isinstance(d, dict) else None
+
+
+def compact_config(res):
+    """one BASELINE configuration in a few fields (the whole record is in bench_detail.json)"""
+    if not isinstance(res, dict) or "value" not in res:
+        return {"workload": (res or {}).get("config", {}).get("workload"), "unavailable": (res or {}).get("unavailable", "not run")}
+    rf, cpu = res.get("roofline") or {}, res.get("cpu_baseline") or {}
+    out = {"workload": res["config"]["workload"], "baseline_config": res.get("baseline_config"), "value": res["value"], "ms_per_step": res["ms_per_step"],
+           "mrays_per_s": res.get("mrays_per_s"), "kernel": rf.get("kernel"), "avg_launch_ms": rf.get("avg_launch_ms"), "bound": rf.get("bound"),
+           "frac": rf.get("frac"), "frac_model": rf.get("frac_model"), "frac_hbm_counter": rf.get("frac_hbm_counter"),
+           "job_counter_over_compulsory": rf.get("job_counter_over_compulsory"),
+           "cpu_msamples_s": cpu.get("value"), "cpu_cores": cpu.get("cores"),
+           "fast_over_exact": res.get("fast_over_exact"), "fast_l2_at_spp": (res.get("fast") or {}).get("l2_vs_exact_at_spp")}
+    if res.get("strong"):
+        out["strong_msamples_s"] = res["strong"]["msamples_s"]
+    return out
+
+
+def compact_group(g):
+    if not isinstance(g, dict):
+        return None
+    if "unavailable" in g:
+        return {"unavailable": str(g["unavailable"])[:160]}
+    return _pick(g, ("kpass_msamples_s", "api_1pass_plain_msamples_s", "api_1pass_lookahead_msamples_s", "one_device_validation"))
+
+
+def contract_line(args, world, head, more=(), group=None, group5=None, detail_file=None):
+    """The ONE JSON line of the contract, from the full records (`head`: the headline configuration's; `more`: the other BASELINE
+    configurations').  Held under LINE_LIMIT_BYTES at any N (tests/test_bench_host.py)."""
+    line = {
+        "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic: the reference's scene files as scene packs (ajax: a procedural 524,288-triangle stand-in); rays, seeds and all downstream generated on the GPU",
+        "config": _pick(head["config"], ("workload", "scene_pack", "parallelism", "rays_per_sample")),
+        "mrays_per_s": head.get("mrays_per_s"),
+        "roofline": _pick(head.get("roofline"), ROOFLINE_KEYS),
+        "cpu_baseline": _pick(head.get("cpu_baseline"), CPU_KEYS),
+        "fast_over_exact": head.get("fast_over_exact"),
+        "fast_l2_at_spp": (head.get("fast") or {}).get("l2_vs_exact_at_spp"),
+        "api_msamples_s": {"kpass_readback": head.get("pcie_inclusive_msamples_s"), "one_pass_plain": head.get("api_1pass_plain_msamples_s"),
+                           "one_pass_lookahead": head.get("api_1pass_msamples_s"), "one_pass_pinned_output": head.get("api_1pass_pinned_output_msamples_s")},
+    }
+    if world > 1:
+        line["api_msamples_s"] = None
+        st = head.get("strong") or {}
+        line["strong_msamples_s"], line["strong_ms_per_step"] = st.get("msamples_s"), st.get("ms_per_step")
+        rk = head.get("ranks") or {}
+        kms = [x.get("kernel_ms") for x in (rk.get("per_rank") or []) if x and x.get("kernel_ms") is not None]
+        line["ranks"] = {"communicator_world_size": rk.get("communicator_world_size"), "backend": rk.get("backend"),
+                         "kernel_ms_min_max": [min(kms), max(kms)] if kms else None}
+        if group is not None:
+            line["group"] = compact_group(group)
+        if group5 is not None:
+            line["group_cfg5"] = compact_group(group5)
+    if more:
+        line["configs"] = [compact_config(m) for m in more]
+    if detail_file:
+        line["detail"] = detail_file
+    return _round(line)
+
+
+def write_detail(detail):
+    """bench_detail.json beside bench.py (and under gpurun_out/ when that exists, so that it travels back from the GPU box); the same
+    record on stderr behind a prefix -- never on stdout, which carries the one contract line."""
+    text = json.dumps(detail)
+    name = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(text + "\n")
+                name = name or "bench_detail.json"
+            except OSError:
+                pass
+    print("bench_detail: " + text, file=sys.stderr, flush=True)
+    return name
 
 
 def main():
@@ -826,25 +963,20 @@ def main():
     if os.environ.get("TINSEL_BENCH_ONE_DEVICE"):
         local = 0
     torch.cuda.set_device(local)
-    group = group5 = None
     default_headline = (args.scene, args.width, args.height) == ("cornell", 1024, 1024)
-    if world > 1 and rank == 0 and not args.no_group_leg:
-        group = group_leg(args, world)
-        if default_headline and not args.no_more_configs:
-            group5 = group_leg(args, world, "veach", 3840, 2160, 0)
     if world == 1 and not args.no_ubench:
         YARD[0] = yard_sticks()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the FIRST collective under a watchdog: if the ranks cannot meet (a rank that never started, an RCCL ring that does not come up),
-        # rank 0 still prints ONE readable JSON line instead of hanging until the driver's clock runs out
+        # rank 0 still prints ONE readable JSON line instead of hanging until the driver's clock runs out.  Nothing runs before it: the
+        # ranks meet within seconds of their start (the tinsel_hip_group legs come AFTER the ranks' timed regions).
         dog = first_collective_watchdog(args, rank, world, backend)
         import datetime
-        # (the other ranks may wait for rank 0's group legs: up to 2 x 240 s before it joins)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=900))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         hello = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(hello)
         if backend == "nccl":
@@ -853,51 +985,56 @@ def main():
         if int(hello.item()) != world:
             raise SystemExit("bench.py: the first all-reduce over %d ranks summed to %d" % (world, int(hello.item())))
 
-    head = run_config(args, args.scene, args.width, args.height, args.maxdepth, rank, world, local, dist, backend, torch, with_extras=True)
+    head = run_config(args, args.scene, args.width, args.height, args.maxdepth, rank, world, local, dist, backend, torch, with_extras=True,
+                      cfg_spp=CONFIG_SPP.get(args.scene, 256))
+    if head is not None:
+        head["baseline_config"] = BASELINE_INDEX.get(args.scene) if default_headline else None
 
     more = []
+
+    def another(name, w, h, d, what):
+        try:
+            res = run_config(args, name, w, h, d, rank, world, local, dist, backend, torch, with_extras=False, cfg_spp=CONFIG_SPP.get(name, 256))
+            if res is not None:
+                res["baseline_config"] = BASELINE_INDEX.get(name)
+                more.append(res)
+        except Exception as e:
+            if world > 1:
+                raise           # (a rank that leaves a collective sequence would hang the others: fail the run loudly instead)
+            more.append({"config": {"workload": what}, "unavailable": "failed: %s" % e})
+
     if world == 1 and default_headline and not args.no_second_config:
         # BASELINE configs[2]: the scene that lives in HBM
         what = "ajax stand-in (524,288 triangles) 1920x1080 maxDepth=4"
         if os.path.exists(os.path.join(ROOT, "tests", "golden", LARGE + ".pack")):
-            try:
-                more.append(run_config(args, LARGE, 1920, 1080, 4, rank, world, local, dist, backend, torch, with_extras=False))
-            except Exception as e:
-                more.append({"config": {"workload": what}, "unavailable": "failed: %s" % e})
+            another(LARGE, 1920, 1080, 4, what)
         else:
             more.append({"config": {"workload": what},
-                         "unavailable": "tests/golden/large/ajax_standin.pack is not on this box (72 MB, git-ignored; written by tests/golden/make_large.py "
-                                        "from the reference's data/ajax.tin where /root/reference is mounted)"})
-        # BASELINE configs[3] and [4]: glass depth 12 at 1080p, veach at 4K
-        if not args.no_more_configs:
-            for name, w, h, d in (("glass", 1920, 1080, 12), ("veach", 3840, 2160, 0)):
-                try:
-                    more.append(run_config(args, name, w, h, d, rank, world, local, dist, backend, torch, with_extras=False))
-                except Exception as e:
-                    more.append({"config": {"workload": "%s.tin %dx%d" % (name, w, h)}, "unavailable": "failed: %s" % e})
+                         "unavailable": "tests/golden/large/ajax_standin.pack is not on this box (72 MB, git-ignored; written by tests/golden/make_large.py)"})
+    if default_headline and not args.no_more_configs:
+        if world == 1:
+            another("glass", 1920, 1080, 12, "glass.tin 1920x1080 maxDepth=12")     # BASELINE configs[3]
+        # BASELINE configs[4], north_star's multi-GPU configuration: at N > 1 the ranks' pixel tiles of the 4K frame, weak and fixed-work
+        another("veach", 3840, 2160, 0, "veach.tin 3840x2160")
 
-    if rank == 0:
-        line = {
-            "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
-            "data": "the reference's own scene files, as written by its loader into scene packs (no dataset, no checkpoint; the ajax mesh is a procedural "
-                    "524,288-triangle stand-in: ajax.obj is not in the reference tree); camera samples, RNG seeds and everything downstream are generated on the GPU",
-        }
-        for k, v in head.items():
-            if k not in line:
-                line[k] = v
-        if YARD[0]:
-            line["yard_sticks"] = YARD[0]
-        if group is not None:
-            line["group"] = group
-        if group5 is not None:
-            line["group_cfg5"] = group5
-        if more:
-            line["configs"] = [{k: head[k] for k in ("metric", "value", "unit", "ms_per_step", "mrays_per_s", "config", "roofline", "cpu_baseline", "timed_blocks", "fast_msamples_s", "fast_l2")}] + more
-        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+
+    # N > 1, rank 0, AFTER the ranks' timed regions (the other ranks have left): the same N devices through the library's own multi-GPU
+    # path (tinsel_hip_group: thread per device, one ncclReduce per read-back) in child processes with a 60 s limit each
+    group = group5 = None
+    if world > 1 and not args.no_group_leg:
+        group = group_leg(args, world)
+        if default_headline and not args.no_more_configs:
+            group5 = group_leg(args, world, "veach", 3840, 2160, 0)
+
+    detail = dict(head, n_gpus=world, steps=args.steps, warmup=args.warmup, yard_sticks=YARD[0], group=group, group_cfg5=group5, configs=more)
+    line = contract_line(args, world, head, more, group, group5, detail_file=None)
+    line["detail"] = write_detail(detail)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

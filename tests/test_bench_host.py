@@ -43,3 +43,76 @@ def test_profiler_kernel_names_map_to_the_timers_names():
     assert K("void tn::k_shade_sorted<true, true>(...)") == "k_shade" and K("void tn::k_shade<true, true>(...)") == "k_shade"
     assert K("void tn::k_bounce<true, true, false>(...)") is None and K("void tn::k_bounce<false, true, false>(...)") == "k_bounce"
     assert K("void tn::k_ub_gather<0>(...)") == "k_ub_gather<0>"
+
+
+def _sample_detail():
+    """a full record as bench.py keeps it in bench_detail.json (round 4's default run: four configurations, per-kernel tables, 28 KB)"""
+    with open(os.path.join(ROOT, "tests", "golden", "bench_detail_sample.json")) as f:
+        d = json.load(f)
+    more = d.pop("configs")
+    return d, more
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline", "cpu_baseline")
+
+
+def test_contract_line_is_small_and_complete():
+    """the driver reads the line from a bounded window; round 4's 28.5 KB line came back `parsed: null`.  The line is built
+    from the full record by bench.contract_line and must stay under 6 KB with every field of the contract in it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    argv, sys.argv = sys.argv, ["bench.py", "--steps", "20", "--warmup", "5"]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    head, more = _sample_detail()
+    assert len(json.dumps(dict(head, configs=more))) > 20000          # (the input really is the big record)
+    line = bench.contract_line(args, 1, head, more, detail_file="bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) <= bench.LINE_LIMIT_BYTES and "\n" not in text, len(text)
+    back = json.loads(text)
+    for k in CONTRACT_KEYS:
+        assert k in back, k
+    assert back["n_gpus"] == 1 and back["steps"] == 20 and back["warmup"] == 5 and back["higher_is_better"] is True and back["vs_baseline"] is None
+    assert abs(back["value"] - head["value"]) < 1e-3*head["value"] and back["unit"] == "Msamples/s" and back["dtype"] == "f32"
+    assert back["config"]["workload"].startswith("cornell.tin 1024x1024")
+    rf = back["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "frac_model"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"]/rf["peak"]) < 1e-3 and rf["kernel"] == "k_bounce" and "kernels" not in rf
+    cpu = back["cpu_baseline"]
+    assert cpu["kind"] == "reference" and cpu["cores"] == 256 and cpu["value"] > 0 and cpu["sample"]
+    # one compact object per OTHER configuration (the headline is not repeated), each naming its BASELINE.json index
+    assert [c["baseline_config"] for c in back["configs"]] == [2, 3, 4]
+    for c in back["configs"]:
+        assert c["value"] > 0 and c["kernel"] and c["frac"] is not None and c["cpu_msamples_s"] > 0 and "roofline" not in c
+        assert len(json.dumps(c)) < 700
+
+
+def test_contract_line_at_eight_ranks_is_small_too():
+    sys.path.insert(0, ROOT)
+    import bench
+    argv, sys.argv = sys.argv, ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    head, more = _sample_detail()
+    head = dict(head, cpu_baseline=None, pcie_inclusive_msamples_s=None,
+                strong={"msamples_s": 20111.5, "ms_per_step": 0.0521, "timed_blocks": 200, "what": "fixed work"},
+                ranks={"communicator_world_size": 8, "backend": "nccl",
+                       "per_rank": [{"rank": r, "samples": 20971520, "rays": 119000000, "kernel_ms": 36.1 + r, "median_block_ms": 37.9, "device": r} for r in range(8)]})
+    veach = dict(more[2], strong={"msamples_s": 15000.0, "ms_per_step": 0.55, "timed_blocks": 30, "what": "fixed work"}, cpu_baseline=None)
+    group = {"metric": "x"*200, "n_gpus": 8, "one_device_validation": False, "kpass_msamples_s": 30000.0, "api_1pass_plain_msamples_s": 900.0,
+             "api_1pass_lookahead_msamples_s": 2500.0, "api_1pass_lookahead_pinned_output_msamples_s": 3000.0, "calls": 64}
+    line = bench.contract_line(args, 8, head, [veach], group, {"unavailable": "timed out after 60 s"}, detail_file="bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) <= bench.LINE_LIMIT_BYTES, len(text)
+    back = json.loads(text)
+    assert back["n_gpus"] == 8 and back["scaling"] == "weak" and back["cpu_baseline"] is None
+    assert back["strong_msamples_s"] == 20112.0 or abs(back["strong_msamples_s"] - 20111.5) < 1.0
+    assert back["ranks"]["communicator_world_size"] == 8 and back["ranks"]["kernel_ms_min_max"] == [36.1, 43.1]
+    assert back["configs"][0]["baseline_config"] == 4 and back["configs"][0]["strong_msamples_s"] == 15000.0
+    assert back["group"]["kpass_msamples_s"] == 30000.0 and "metric" not in back["group"] and back["group_cfg5"]["unavailable"].startswith("timed out")

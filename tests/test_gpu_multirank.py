@@ -1,7 +1,7 @@
 """bench.py's N-rank code path, end to end, on ONE GPU: `python -m torch.distributed.run --nproc-per-node 2 bench.py
 --gpus 2` exactly as the driver launches it, with the two ranks sharing device 0 and `gloo` standing in for RCCL
 (TINSEL_BENCH_ONE_DEVICE / TINSEL_BENCH_BACKEND: validation switches, not a measurement).  Checks the launch, the
-pixel-tile shard, the reduce, the one-line JSON contract and -- inside bench.py -- that the reduced image equals an
+pixel-tile shard, the reduce (weak and fixed-work legs), the small one-line JSON contract and -- inside bench.py -- that the reduced image equals an
 unsharded render of the same passes."""
 import json
 import os
@@ -24,19 +24,24 @@ def test_two_ranks_on_one_device():
     assert "validation: 2-rank reduced image vs unsharded render" in p.stderr and ": ok" in p.stderr, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout            # rank 0 prints ONE json line
+    assert len(lines[0]) <= 6144                # ... a small one (the driver reads it from a bounded window)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["unit"] == "Msamples/s"
     # weak scaling: 2 ranks x (8 steps x 2 passes) over half of the pixels each = 16 full-frame passes of samples
     assert abs(d["value"]*d["ms_per_step"]*1e-3*8*1e6 - 16*512*384) < 1e-3*16*512*384
     assert d["roofline"]["kernel"] and d["cpu_baseline"] is None
-    # rank 0 also timed the SAME devices through the library's own multi-GPU path (tinsel_hip_group, one-device validation here)
+    # the fixed-work leg beside it: the same 8 full-frame passes split over the two ranks' tiles + the reduce
+    assert d["strong_msamples_s"] > 0 and abs(d["strong_msamples_s"]*d["strong_ms_per_step"]*1e-3*8*1e6 - 8*512*384) < 1e-3*8*512*384
+    # AFTER the ranks' timed regions rank 0 timed the SAME devices through the library's own multi-GPU path (tinsel_hip_group, one-device validation here)
     g = d["group"]
-    assert g.get("n_gpus") == 2 and g["one_device_validation"] is True, g
-    assert g["kpass_msamples_s"] > 0 and g["api_1pass_plain_msamples_s"] > 0 and g["api_1pass_lookahead_msamples_s"] > 0, g
-    # the communicator's own rank count and every rank's share of the work are in the line
-    rk = d["ranks"]
-    assert rk["communicator_world_size"] == 2 and [x["rank"] for x in rk["per_rank"]] == [0, 1]
+    assert g["one_device_validation"] is True and g["kpass_msamples_s"] > 0 and g["api_1pass_plain_msamples_s"] > 0 and g["api_1pass_lookahead_msamples_s"] > 0, g
+    assert d["ranks"]["communicator_world_size"] == 2 and d["ranks"]["kernel_ms_min_max"][0] > 0
+    # the full record (stderr, behind a prefix; also bench_detail.json): every rank's share of the work
+    full = json.loads([l for l in p.stderr.splitlines() if l.startswith("bench_detail: ")][-1][len("bench_detail: "):])
+    rk = full["ranks"]
+    assert [x["rank"] for x in rk["per_rank"]] == [0, 1]
     assert sum(x["samples"] for x in rk["per_rank"]) == 16*512*384 and all(x["kernel_ms"] > 0 for x in rk["per_rank"])
+    assert full["group"]["n_gpus"] == 2 and full["strong"]["timed_blocks"] >= 1
 
 
 def test_plain_launch_starts_the_ranks_itself():
@@ -51,7 +56,7 @@ def test_plain_launch_starts_the_ranks_itself():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["ranks"]["communicator_world_size"] == 2 and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["ranks"]["communicator_world_size"] == 2 and d["value"] > 0 and d["strong_msamples_s"] > 0 and "group" not in d
 
 
 def test_group_mode_prints_one_line():
