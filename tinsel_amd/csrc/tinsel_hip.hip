@@ -1210,7 +1210,7 @@ int streaming_grid(const tinsel_hip* r, size_t slots, int pipeline)
     const size_t blocks = (slots + perBlock - 1)/perBlock;
     // (at least as many workgroups as the chip holds at once -- TINSEL_HIP_GRID_MIN per CU, default 3: k_bounce and k_shade run three
     // waves per SIMD -- where the batch has that many 256-path pieces: a 1 M-path batch would otherwise leave the third wave slot empty)
-    static const int gridMin = getenv("TINSEL_HIP_GRID_MIN") ? std::max(1, atoi(getenv("TINSEL_HIP_GRID_MIN"))) : 3;
+    static const int gridMin = getenv("TINSEL_HIP_GRID_MIN") ? std::max(1, atoi(getenv("TINSEL_HIP_GRID_MIN"))) : kBounceWaves;
     const size_t lo = std::min<size_t>((size_t)r->numCUs*(size_t)gridMin, (slots + kBlock - 1)/kBlock), hi = (size_t)r->numCUs*(size_t)grid_mult();
     size_t grid = std::max<size_t>(1, std::min(hi, std::max(lo, blocks)));
     // The workgroups that HAVE work (regions are a whole number of waves long, so fewer than the grid may) as close to a whole number
@@ -1294,11 +1294,13 @@ bool split_one_set(tinsel_hip* r, LaunchArgs& a, size_t slots)
 {
     const uint32_t per = kBlock/kWave;
     const size_t cus = (size_t)r->numCUs;
-    const uint32_t L = (uint32_t)((slots*3/4)/(2*cus*per)/kWave*kWave);
+    // (W = kBounceWaves workgroups resident per CU: W - 1 long groups per CU hold W/(W + 1) of the batch -- three waves: two groups, three quarters)
+    const size_t W = (size_t)kBounceWaves;
+    const uint32_t L = (uint32_t)((slots*W/(W + 1))/((W - 1)*cus*per)/kWave*kWave);
     if (L < 3u*kWave)
         return false;
     const uint32_t S = L/3/kWave*kWave;
-    const uint32_t big = (uint32_t)(2*cus)*per;
+    const uint32_t big = (uint32_t)((W - 1)*cus)*per;
     const size_t covered = (size_t)big*L;
     if (covered >= slots)
         return false;
@@ -1328,7 +1330,7 @@ int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t ma
     if (tailEnv)
         sscanf(tailEnv, "%lf,%d", &share, &divide);
     // (three workgroups per CU are resident: k_bounce)
-    if (share < 0.0 && maxRegions > 0 && (size_t)*grid <= (size_t)r->numCUs*3 && (size_t)*grid > (size_t)r->numCUs*2 && split_one_set(r, a, slots))
+    if (share < 0.0 && maxRegions > 0 && (size_t)*grid <= (size_t)r->numCUs*kBounceWaves && (size_t)*grid > (size_t)r->numCUs*(kBounceWaves - 1) && split_one_set(r, a, slots))
     {
         *grid = (int)(a.ss.numRegions/(kBlock/kWave));
         return 0;
@@ -1338,7 +1340,7 @@ int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t ma
         // a negative share: that multiple of ONE resident set's part of the batch (three workgroups per CU: k_bounce).  The default, half a
         // set's part, against a fixed eighth: cornell x 20 passes 4036 -> 4059, x 64 4203 -> 4221, features 1289 -> 1298, veach 1080p
         // 2610 -> 2621, gloss 10570 -> 10530 (call Z8)
-        const double sets = (double)*grid/(double)(3*r->numCUs);
+        const double sets = (double)*grid/(double)(kBounceWaves*r->numCUs);
         share = std::min(0.25, std::max(0.03, -share/std::max(1.0, sets)));
     }
     if (share > 0.0 && share < 0.9 && divide >= 2)
@@ -1395,8 +1397,9 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
             static const char* repackEnv = getenv("TINSEL_HIP_REPACK");          // 0 / 1: never / always (A/B); default: open scenes
             const bool want = repackEnv ? atoi(repackEnv) != 0 : !r->sceneEnclosed;
             const size_t withPool = (size_t)a.ldsBytes + kPoolWords*sizeof(uint32_t);
-            const size_t perCU = 160u*1024u, blocksPerCU = 3;      // k_bounce runs three waves per SIMD = three workgroups per CU
-            if (want && withPool*blocksPerCU <= perCU && withPool <= (size_t)r->sharedMemLimit)
+            const size_t perCU = 160u*1024u, blocksPerCU = kBounceWaves;      // k_bounce's waves per SIMD = its workgroups per CU
+            // (at four waves per SIMD the pools may cost the fourth workgroup, not the third)
+            if (want && withPool*std::min<size_t>(blocksPerCU, 3) <= perCU && withPool <= (size_t)r->sharedMemLimit)
             {
                 a.fp.repack = 1;
                 a.ldsBytes = (uint32_t)withPool;

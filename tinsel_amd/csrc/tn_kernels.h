@@ -36,6 +36,7 @@ namespace tn {
 #ifndef TN_WAVES_BOUNCE
 #define TN_WAVES_BOUNCE 3
 #endif
+constexpr int kBounceWaves = TN_WAVES_BOUNCE;     // = k_bounce's resident workgroups per CU (256 threads each): what the host sizes its grids and LDS budgets by
 // k_shade: four since the end of round 4 -- with the libm coefficients out of its registers (K64, tn_math.h) the staged-arena variant needs
 // 133 VGPRs and fits 128 without a byte of scratch (glass k_shade 8.9-9.1 -> 8.7-8.9 ms, motionblur 6.3 -> 5.4, many_spheres +1.7 %:
 // profiles/r04_v_ab_k64.md; at three waves it had been 168 VGPRs + 108 B)
@@ -714,7 +715,15 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                         typedef const __attribute__((address_space(4))) BounceKernargs* ArgsPtr;
                         ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
                         asm volatile("" : "+s"(ap));
-                        const FrameParams fpNow = ap->fp;
+                        // (word by word: a struct copy out of the constant address space does not compile in the host pass)
+                        FrameParams fpNow;
+                        {
+                            const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)((const __attribute__((address_space(4))) char*)ap + offsetof(BounceKernargs, fp));
+                            uint32_t* dst = reinterpret_cast<uint32_t*>(&fpNow);
+#pragma unroll
+                            for (int w = 0; w < (int)(sizeof(FrameParams)/4); ++w)
+                                dst[w] = src[w];
+                        }
                         have = begin_path(camNow, fpNow, ap->passSeeds, slot, p, rx, ry);
 #else
                         have = begin_path(camNow, fp, passSeeds, slot, p, rx, ry);
