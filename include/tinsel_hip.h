@@ -344,6 +344,9 @@ typedef struct tinsel_kernel_time {
     float busy_ms;      /* union of their intervals: less than total_ms where a call's chunks overlap on two streams */
 } tinsel_kernel_time;
 int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entries);
+/* sizeof(tinsel_kernel_time) in THIS build of the library (40; 36 before busy_ms was added in round 4): a caller that may be handed an
+ * older library (TINSEL_HIP_LIB) asks before it reads the records -- the symbol's absence says "36-byte records, no busy_ms". */
+int tinsel_hip_kernel_time_bytes(void);
 int tinsel_hip_enable_kernel_timing(tinsel_hip* r, int enable);
 
 /* Extended counters since the last reset: [0]=rays [1]=samples [2]=internal BVH node visits

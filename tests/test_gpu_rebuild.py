@@ -115,3 +115,121 @@ def test_malformed_scene_trees_are_refused():
     with pytest.raises(tinsel_amd.TinselHipError):
         r.rebuild_scene(short)
     r.close()
+
+
+PLANE_SCENE = """
+options
+{
+	width 48
+	height 32
+	maxDepth 4
+	filter gaussian 0.75 2
+}
+
+camera
+{
+	position 0 1 6
+	target 0 0.8 0
+	fov 45
+}
+
+sky
+{
+	horizon 0.4 0.5 0.6
+	zenith 0.1 0.2 0.5
+}
+
+material grey
+{
+	color 0.7 0.7 0.7
+	roughness 0.5
+}
+
+material red
+{
+	color 0.8 0.2 0.2
+	roughness 0.3
+}
+
+material lamp
+{
+	emission 12 11 10
+	color 0 0 0
+}
+
+primitive
+{
+	type plane
+	plane 0 1 0 0
+	material grey
+}
+
+primitive
+{
+	type plane
+%s	plane 0 0 1 2
+	material red
+}
+
+primitive
+{
+	type sphere
+	position -0.6 0.7 0.2
+	radius 0.7
+	material grey
+}
+
+primitive
+{
+	type sphere
+	position 1.2 2.2 1.0
+	radius 0.4
+	material lamp
+	lightSamples 2
+}
+"""
+
+
+def _scene_arrays(scene):
+    P, N = scene.desc.num_primitives, scene.desc.num_bvh_nodes
+    prims = (abi.Primitive*P).from_address(scene.desc.primitives)
+    nodes = (abi.BVHNode*N).from_buffer_copy(C.string_at(scene.desc.bvh_nodes, N*C.sizeof(abi.BVHNode)))
+    return prims, nodes
+
+
+@pytest.mark.skipif(not oa.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("pipe", [abi.PIPELINE_AUTO, abi.PIPELINE_WAVEFRONT_SPLIT])
+def test_a_plane_scaled_out_of_the_plane_table_and_back(pipe, tmp_path):
+    """the split pipeline's flat scan tests the always-hit planes from a table written at create.  PrimitiveBounds of a plane is
+    +-1e8 times the primitive's scale (intersection.h:906-939): scaled to 2e-8 its leaf box is the cube +-2, the reference's QueryBVH box-tests
+    it like any primitive, and the table entry must go (and come back when the plane is scaled up again).  Both scenes are loaded and
+    rendered by the reference on this box (oracle/_ref); the renderer is created from the unscaled one and told the change."""
+    R = oa.RefOracle()
+    packs, refs = [], []
+    for tag, scale in (("a", ""), ("b", "\tscale 0.00000002\n")):
+        tin = tmp_path / ("planes_%s.tin" % tag)
+        tin.write_text(PLANE_SCENE % scale)
+        h = R.load_tin(str(tin))
+        pack = tmp_path / ("planes_%s.pack" % tag)
+        R.write_pack(h, str(pack))
+        cam, opt = R.camera_options(h)
+        accum, rad, _ = R.render_seeded(h, cam, opt, 0, 3, want_accum=True, want_radiance=True)
+        R.free(h)
+        packs.append(tinsel_amd.Scene.load_pack(str(pack)))
+        refs.append((cam, opt, accum, rad))
+    prims_a, nodes_a = _scene_arrays(packs[0])
+    prims_b, nodes_b = _scene_arrays(packs[1])
+    assert prims_b[1].start_transform.s < 0.01 and prims_a[1].start_transform.s == 1.0
+    # (the scaled plane's leaf box is bounded in the reference's own tree)
+    leaf_b = [n for n in nodes_b if (n.right_index_leaf >> 31) and n.left_index == 1][0]
+    assert abs(leaf_b.upper.x) < 1e7 and not np.array_equal(refs[0][3], refs[1][3])
+
+    r = tinsel_amd.create_gpu_renderer(packs[0])
+    r.set_pipeline(pipe)
+    for prims, nodes, (cam, opt, accum, rad) in ((prims_b, nodes_b, refs[1]), (prims_a, nodes_a, refs[0]), (prims_b, nodes_b, refs[1])):
+        r.set_primitive_transform(1, prims[1].start_transform, prims[1].end_transform)
+        r.rebuild_scene(nodes)
+        out, got = _render(r, cam, opt, 3)
+        assert np.array_equal(got, rad), "%d paths differ" % int((got != rad).any(axis=-1).sum())
+        assert np.array_equal(out, accum)
+    r.close()

@@ -81,16 +81,3 @@ def test_fuzz_corpus_through_k_walk(walk_everything):
             bad.append(k)
     assert not bad, "scenes that differ through k_walk: %s" % bad
     assert walked_total > 0
-
-
-def test_pair_records_follow_device_builds_and_refits():
-    """k_walk's opt-in bottom-level records (TINSEL_HIP_WALK_PAIRS=1, tn_scene.h Pair128) hold copies of the leaves' triangles: they are
-    rebuilt with every device-built tree and after every refit.  The switch is read once per process, so the refit and builder tests run
-    again in a child process under it (the walk tests themselves: tests/test_gpu_switches.py)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TINSEL_HIP_WALK_PAIRS="1")
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_refit.py"), os.path.join(root, "tests", "test_gpu_lbvh.py"),
-                        "-q", "-x", "-m", "gpu"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-2000:] + p.stderr[-1000:]

@@ -111,6 +111,11 @@ class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_float), ("busy_ms", C.c_float)]
 
 
+class KernelTimeV1(C.Structure):
+    """tinsel_kernel_time as libraries built before round 4 wrote it (no busy_ms): renderer.HipRenderer.kernel_times"""
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_float)]
+
+
 MODE_NORMALS, MODE_COMPLEXITY, MODE_PATHTRACE = 0, 1, 2
 BVH_REFERENCE, BVH_LBVH, BVH_PLOC = 0, 1, 2
 SCENE_BVH_NODES, SCENE_BVH_DEVICE = 0, 1

@@ -84,13 +84,19 @@ def _resource_job(tmp):
 
 
 def _kernel_name(mangled):
-    """_ZN2tn8k_bounceILb0ELb1ELb0EE... -> k_bounce<0,1,0>   (template arguments of the kernels here are bools and ints)"""
+    """_ZN2tn8k_bounceILb0ELb1ELb0ELi4EEEvNS_8DevSceneE... -> k_bounce<0,1,0,4>   (template arguments of the kernels here are bools and ints).
+    The name is read by its Itanium LENGTH PREFIX (a lazy match up to the first v / E / P / N cut k_lbvh_leaves down to k_lb: ADVICE r04)."""
     import re
-    m = re.match(r"_ZN2tn\d+(k_[a-z_0-9]+?)(I((?:L[bij]-?n?\d+E)+)E)?(?:v|E|P|N|$)", mangled)
+    m = re.match(r"_ZN2tn(\d+)", mangled)
     if not m:
         return mangled
-    args = re.findall(r"L[bij](n?\d+)E", m.group(3) or "")
-    return m.group(1) + ("<" + ",".join(a.replace("n", "-") for a in args) + ">" if args else "")
+    n = int(m.group(1))
+    name, rest = mangled[m.end():m.end() + n], mangled[m.end() + n:]
+    if len(name) != n or not name.startswith("k_"):
+        return mangled
+    t = re.match(r"I((?:L[bij]n?\d+E)+)E", rest)
+    args = re.findall(r"L[bij](n?\d+)E", t.group(1)) if t else []
+    return name + ("<" + ",".join(a.replace("n", "-") for a in args) + ">" if args else "")
 
 
 def _parse_resources(text):

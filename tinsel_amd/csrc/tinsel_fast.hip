@@ -20,9 +20,13 @@ extern "C" void tinsel_fast_launch_path_kernel(int which, const void* launchArgs
     tn_fast::launch_path_kernel(which, *static_cast<const tn_fast::LaunchArgs*>(launchArgs), (hipStream_t)stream);
 }
 
-extern "C" void tinsel_fast_prepare_path_kernels(int sharedMemLimit)
+// returns the number of kernels whose dynamic-LDS limit the runtime refused to raise; *first: the first one's name
+extern "C" int tinsel_fast_prepare_path_kernels(int sharedMemLimit, const char** first)
 {
-    tn_fast::prepare_path_kernels(sharedMemLimit);
+    const tn_fast::PrepReport rep = tn_fast::prepare_path_kernels(sharedMemLimit);
+    if (first)
+        *first = rep.first;
+    return rep.refused;
 }
 
 extern "C" unsigned tinsel_fast_launch_args_size(void) { return (unsigned)sizeof(tn_fast::LaunchArgs); }

@@ -11,8 +11,7 @@
 #include "tn_ubench.h"
 #include "tn_selftest.h"
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
+#include "tn_sort.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types only: the library is dlopen'ed by the first multi-GPU group (no link-time dependency)
@@ -420,6 +419,8 @@ struct tinsel_hip
     size_t arenaOffNodes = 0, arenaOffBoxes = 0;
     std::vector<int32_t> planeTablePrims;       // the planes DevScene::planeEq holds (their PrimBox says 2: re-marked when the boxes are rewritten)
     int sceneStackNeed = 1;
+    std::string prepRefused;            // non-empty: a kernel whose dynamic-LDS limit the runtime refused to raise (prepare_kernels_once)
+    int bounceWaves = 3;                // k_bounce's waves per SIMD = its resident workgroups per CU for the batch being launched (plan_bounce)
     bool sceneEnclosed = false;         // two planes face each other: (practically) no ray leaves the scene (k_bounce's shading pools stay off)
     int bvhMode = TINSEL_BVH_REFERENCE;
     int rrStart = 0;                    // > 0: Russian roulette from this bounce on (opt-in)
@@ -518,7 +519,7 @@ struct tinsel_hip
     tinsel_camera specCamera;
     tinsel_options specOptions;
     int specPasses = 0;
-    int lookaheadDepth = 0;             // calls per speculated batch; 0 = chosen from the batch capacity (TINSEL_HIP_LOOKAHEAD_DEPTH)
+    int lookaheadDepth = 0;             // calls per speculated batch; 0 = chosen from the batch capacity 
     hipStream_t workStream = nullptr, copyStream = nullptr;
     void* pinnedPtr = nullptr;          // caller's output buffer, page-locked in place (hipHostRegister) for the D2H DMA
     size_t pinnedBytes = 0;
@@ -780,72 +781,28 @@ int pick_stack(int need)
     return -1;
 }
 
-// The bottom level of a mesh tree in HBM as Pair128 records (tn_scene.h, k_build_pairs in tn_lbvh.h): k_walk's kWalkPairs mode.
-// `dm.pairs` is allocated on first use (owner: the list that frees it) and (re)filled from the tree as it is NOW -- the reference's as
-// converted, a device-built one, either after a refit.  Built only when the mode is asked for (walk_pairs_enabled).
-bool walk_pairs_enabled()
-{
-    // OPT-IN (TINSEL_HIP_WALK_PAIRS=1).  Measured, bit-identical (profiles/r04_b_ab_walk_pairs2.md): the 524k-triangle config's k_walk 11.34 ms
-    // per 20 passes without, 11.29-11.39 with -- node phases -8 %, but the triangle phases hardly fewer (most visits to a node over two leaves
-    // enter ONE of the two boxes, so there was one triangle phase before and there is one now) and each of them heavier; glass (two walked
-    // primitives: per-lane tree pointers, 8-48 B of scratch at 64 VGPRs) 6.3 -> 8.7 ms.
-    static const bool on = getenv("TINSEL_HIP_WALK_PAIRS") && atoi(getenv("TINSEL_HIP_WALK_PAIRS")) != 0;
-    return on;
-}
-
-int fill_pairs(DevMesh& dm)
-{
-    int* mism = nullptr;
-    int bad = -1;
-    if (hipMalloc((void**)&mism, sizeof(int)) == hipSuccess && hipMemset(mism, 0, sizeof(int)) == hipSuccess)
-    {
-        hipLaunchKernelGGL(k_build_pairs, dim3((unsigned)((dm.numInternal + 255)/256)), dim3(256), 0, nullptr, const_cast<Node64*>(dm.nodes), dm.numInternal,
-                           dm.tris, const_cast<Pair128*>(dm.pairs), mism);
-        // (a blocking copy on the null stream: also orders the records before kernels of non-blocking streams)
-        if (hipMemcpy(&bad, mism, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess)
-            bad = -1;
-    }
-    if (mism)
-        (void)hipFree(mism);
-    if (bad < 0)
-        return fail("k_build_pairs failed");
-    // a tree whose stored leaf boxes are not the min / max of its leaves' vertices (never the reference's, mesh.cpp:321-328): plain walk
-    dm.pairsExact = bad == 0 ? 1 : 0;
-    return 0;
-}
-
-int build_pairs(DevMesh& dm, std::vector<void*>& owner)
-{
-    dm.pairsExact = 0;
-    if (dm.inArena || dm.numInternal <= 0 || !dm.nodes || !walk_pairs_enabled())
-        return 0;
-    if ((unsigned)dm.numInternal >= kPairBit)
-        return 0;                   // (a node index must leave bit 30 free)
-    if (!dm.pairs)
-    {
-        void* d = nullptr;
-        if (hipMalloc(&d, sizeof(Pair128)*(size_t)dm.numInternal) != hipSuccess)
-            return fail("device allocation failed (leaf-pair records)");
-        owner.push_back(d);
-        dm.pairs = (const Pair128*)d;
-    }
-    return fill_pairs(dm);
-}
-
 size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes; }
 
 // The path kernels exist twice (tn_launch.h): this translation unit's, bit-identical to the CPU oracle, and
 // tinsel_fast.hip's, built under the tolerance contract.  tinsel_hip_set_arithmetic picks the arm.
 extern "C" void tinsel_fast_launch_path_kernel(int which, const void* launchArgs, void* stream);
-extern "C" void tinsel_fast_prepare_path_kernels(int sharedMemLimit);
+extern "C" int tinsel_fast_prepare_path_kernels(int sharedMemLimit, const char** first);
 extern "C" unsigned tinsel_fast_launch_args_size(void);
 
+// Raises the dynamic-LDS limit of every kernel that needs more than the default launch limit, for both arithmetic arms (tn_launch.h).  Called by
+// tinsel_hip_create, which refuses the device when the runtime refuses a kernel (r->prepRefused: "kernel name (arm)").
 void prepare_kernels_once(tinsel_hip* r)
 {
     if (r->pathKernelsPrepared)
         return;
-    r->segPrefixLds = prepare_path_kernels(r->sharedMemLimit);
-    tinsel_fast_prepare_path_kernels(r->sharedMemLimit);
+    const PrepReport rep = prepare_path_kernels(r->sharedMemLimit);
+    r->segPrefixLds = rep.segPrefixLds;
+    const char* fastFirst = nullptr;
+    const int fastRefused = tinsel_fast_prepare_path_kernels(r->sharedMemLimit, &fastFirst);
+    if (rep.refused)
+        r->prepRefused = std::string(rep.first ? rep.first : "?") + " (parity arm; " + std::to_string(rep.refused + fastRefused) + " kernels in all)";
+    else if (fastRefused)
+        r->prepRefused = std::string(fastFirst ? fastFirst : "?") + " (tolerance arm; " + std::to_string(fastRefused) + " kernels in all)";
     r->pathKernelsPrepared = true;
 }
 
@@ -861,12 +818,6 @@ void launch_path(tinsel_hip* r, int which, const LaunchArgs& a, hipStream_t st)
 // k_walk's records are used by the scan kernels unless the detail counters are on (those count the inline walk)
 const float4* walk_records(const tinsel_hip* r) { return r->countDetail ? nullptr : r->walkRec; }
 
-bool noBinPrims()
-{
-    static const bool off = getenv("TINSEL_HIP_NO_BIN") != nullptr;
-    return off;
-}
-
 // what every launch of a batch shares
 LaunchArgs batch_args(tinsel_hip* r, const CameraParams& cam, const FrameParams& fp)
 {
@@ -880,7 +831,7 @@ LaunchArgs batch_args(tinsel_hip* r, const CameraParams& cam, const FrameParams&
     a.passSeeds = r->passSeeds;
     a.walkRec = walk_records(r);
     a.walkPrims = (uint32_t)r->walkPrims.count;
-    a.bins = noBinPrims() ? BinPrims{ 0, { 0, 0, 0, 0, 0, 0, 0 } } : r->binPrims;
+    a.bins = r->binPrims;
     a.stackEntries = r->stackNeed;
     a.countDetail = r->countDetail ? 1 : 0;
     a.ldsBytes = (uint32_t)stack_bytes(r);
@@ -901,17 +852,14 @@ uint32_t seg_prefix_max_regions(tinsel_hip* r)
 // workgroups without a staged top.
 int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* regionCounts, bool shadowRays)
 {
-    static const int gridMult = getenv("TINSEL_HIP_WALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_WALK_GRID_MULT")) : 1;
-    static const int refillMin = getenv("TINSEL_HIP_WALK_REFILL") ? atoi(getenv("TINSEL_HIP_WALK_REFILL")) : 24;
-    static const int leafMin = getenv("TINSEL_HIP_WALK_LEAFMIN") ? atoi(getenv("TINSEL_HIP_WALK_LEAFMIN")) : 8;
-    static const int topLimit = getenv("TINSEL_HIP_WALK_TOP") ? atoi(getenv("TINSEL_HIP_WALK_TOP")) : 1 << 20;      // nodes; 0: no staged top (A/B)
+    // (measured and settled, profiles/EXPERIMENTS.md: one resident set of workgroups; a refill once 24 lanes idle; a triangle phase once 8 wait)
+    const int gridMult = 1, refillMin = 24, leafMin = 8;
     static const int forceBlock = getenv("TINSEL_HIP_WALK_BLOCK") ? atoi(getenv("TINSEL_HIP_WALK_BLOCK")) : 0;
     prepare_kernels_once(r);
     // the work list: the front entries of every region (paths / shadow-ray bundles whose ray enters a walked mesh's box)
     const SplitState& ss = a.ss;
     // the list visits the regions a golden-section step apart (TINSEL_HIP_WALK_LIST_STEP=1: in order)
-    static const int stepEnv = getenv("TINSEL_HIP_WALK_LIST_STEP") ? atoi(getenv("TINSEL_HIP_WALK_LIST_STEP")) : 0;
-    uint32_t step = stepEnv > 0 ? (uint32_t)stepEnv : (uint32_t)(ss.numRegions*0.6180339887) | 1u;
+    uint32_t step = (uint32_t)(ss.numRegions*0.6180339887) | 1u;
     {
         auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
         while (step > 1 && gcd(step, ss.numRegions) != 1)
@@ -942,6 +890,7 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     {
         job.prim[k] = k < r->walkPrims.count ? r->walkPrims.prim[k] : 0;
         job.topCount[k] = 0;
+        job.triCount[k] = 0;
         if (k < r->walkPrims.count)
             entries = std::max(entries, r->meshesNow[(size_t)r->walkPrimMesh[k]].stackNeed);
     }
@@ -949,14 +898,15 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     job.prof = r->walkProf;
     job.refillMin = std::min(64, std::max(1, refillMin));
     job.leafMin = std::min(64, std::max(1, leafMin));
-    // the bottom level out of Pair128 records where asked for (TINSEL_HIP_WALK_PAIRS=1) and every walked tree has them; ONE walked primitive:
-    // its tree as kernel-argument scalars (TINSEL_HIP_WALK_SINGLE=0: per-lane pointers as for several)
+#ifdef TN_TUNE_ENV
+    // (developer builds only -- scratch/build_variant.sh NAME -DTN_TUNE_ENV: the two thresholds from the environment for a sweep)
+    if (getenv("TN_TUNE_WALK_REFILL")) job.refillMin = std::min(64, std::max(1, atoi(getenv("TN_TUNE_WALK_REFILL"))));
+    if (getenv("TN_TUNE_WALK_LEAFMIN")) job.leafMin = std::min(64, std::max(1, atoi(getenv("TN_TUNE_WALK_LEAFMIN"))));
+#endif
+    // ONE walked primitive: its tree as kernel-argument scalars (TINSEL_HIP_WALK_SINGLE=0: per-lane pointers as for several; tests)
     {
-        static const bool noSingle = getenv("TINSEL_HIP_WALK_SINGLE") && atoi(getenv("TINSEL_HIP_WALK_SINGLE")) == 0;
-        bool pairs = walk_pairs_enabled();
-        for (int k = 0; k < r->walkPrims.count; ++k)
-            pairs = pairs && r->meshesNow[(size_t)r->walkPrimMesh[k]].pairs != nullptr && r->meshesNow[(size_t)r->walkPrimMesh[k]].pairsExact != 0;
-        a.walkMode = (pairs ? kWalkPairs : 0) | ((r->walkPrims.count == 1 && !noSingle) ? kWalkSingle : 0);
+        const char* singleEnv = getenv("TINSEL_HIP_WALK_SINGLE");
+        a.walkSingle = (r->walkPrims.count == 1 && !(singleEnv && atoi(singleEnv) == 0)) ? 1 : 0;
     }
 
     const size_t ctl = kWalkCtlWords*sizeof(uint32_t);
@@ -965,8 +915,27 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     // LDS: the 524k-triangle config's k_walk 19.0 -> 16.6 ms per 32 passes (2042 -> 2199 Msamples/s; 6 entries 17.2, 12 entries 16.7),
     // glass 10.4 -> 9.9; results unchanged (a stack entry is a stack entry wherever it lives)
     static const int ldsStackEnv = getenv("TINSEL_HIP_WALK_LDS_STACK") ? atoi(getenv("TINSEL_HIP_WALK_LDS_STACK")) : 8;
-    const bool twoPerCU = ldsStackEnv > 0 && !forceBlock;
-    const int ldsEntries = twoPerCU ? std::min(entries, std::max(1, ldsStackEnv)) : entries;
+    // THE WHOLE MESH IN LDS (k_walk's kWalkLdsTris, tn_walk.h) where every walked tree is numbered breadth-first to its last node and all of
+    // them, with their triangles' vertices (36 B each), fit beside the stacks of ONE 1024-thread workgroup per CU with at least four stack
+    // entries per lane in LDS: glass.tin's sphere + cube (1290 nodes, 1292 triangles: 126 KB).  TINSEL_HIP_WALK_LDS_MESH=0: off (A/B, tests).
+    int ldsMeshEntries = 0;
+    {
+        const char* meshEnv = getenv("TINSEL_HIP_WALK_LDS_MESH");
+        size_t bytes = ctl;
+        bool whole = !(meshEnv && atoi(meshEnv) == 0) && !forceBlock && r->walkPrims.count > 0;
+        for (int k = 0; k < r->walkPrims.count && whole; ++k)
+        {
+            const DevMesh& dm = r->meshesNow[(size_t)r->walkPrimMesh[k]];
+            whole = dm.topCount == dm.numInternal && dm.numInternal > 0;
+            bytes += (size_t)dm.numInternal*sizeof(Node64) + (size_t)dm.numTris*36u;
+        }
+        if (whole)
+            for (int e = std::min(entries, 8); e >= std::min(entries, 4) && !ldsMeshEntries; --e)
+                if (bytes + (size_t)(e + kWalkLaneRows)*1024*sizeof(uint32_t) <= (size_t)r->sharedMemLimit)
+                    ldsMeshEntries = e;
+    }
+    const bool twoPerCU = ldsStackEnv > 0 && !forceBlock && !ldsMeshEntries;
+    const int ldsEntries = ldsMeshEntries ? ldsMeshEntries : twoPerCU ? std::min(entries, std::max(1, ldsStackEnv)) : entries;
     job.stackEntries = ldsEntries;
     job.overflow = nullptr;
     job.overflowEntries = 0;
@@ -979,7 +948,6 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     {
         // what is left of the CU's LDS goes to the tree tops, in primitive order
         size_t room = (ldsBudget - lds)/sizeof(Node64);
-        room = std::min<size_t>(room, (size_t)std::max(0, topLimit));
         for (int k = 0; k < r->walkPrims.count && room > 0; ++k)
         {
             const int n = (int)std::min<size_t>(room, (size_t)r->meshesNow[(size_t)r->walkPrimMesh[k]].topCount);
@@ -987,7 +955,14 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
             room -= (size_t)n;
             lds += (size_t)n*sizeof(Node64);
         }
+        if (ldsMeshEntries)
+            for (int k = 0; k < r->walkPrims.count; ++k)
+            {
+                job.triCount[k] = r->meshesNow[(size_t)r->walkPrimMesh[k]].numTris;
+                lds += (size_t)job.triCount[k]*36u;
+            }
     }
+    a.walkLdsMesh = (big && ldsMeshEntries) ? 1 : 0;
     const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1)*(size_t)r->walkPrims.count;
     const int perCU = big ? gridMult*(twoPerCU ? 2 : 1) : gridMult*4;
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
@@ -1024,15 +999,12 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
 // entry of every region (front and back), regions in index order -- the workgroups' static ranges are image patches, coherent rays.
 int launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* front, const uint32_t* back, bool shadowRays)
 {
-    static const int refillMin = getenv("TINSEL_HIP_SWALK_REFILL") ? atoi(getenv("TINSEL_HIP_SWALK_REFILL")) : 32;
-    static const int leafMin = getenv("TINSEL_HIP_SWALK_LEAFMIN") ? atoi(getenv("TINSEL_HIP_SWALK_LEAFMIN")) : 16;
-    static const int gridMultEnv = getenv("TINSEL_HIP_SWALK_GRID_MULT") ? atoi(getenv("TINSEL_HIP_SWALK_GRID_MULT")) : 0;
-    static const int stepEnv = getenv("TINSEL_HIP_SWALK_LIST_STEP") ? atoi(getenv("TINSEL_HIP_SWALK_LIST_STEP")) : 0;
+    const int refillMin = 32, leafMin = 16;         // (settled: profiles/r03_d_ab_swalk.txt, r03_e_ab_swalk.txt)
     static const bool noLds = getenv("TINSEL_HIP_SWALK_NO_LDS") != nullptr;
     const SplitState& ss = a.ss;
     // the list visits the regions a golden-section step apart: every workgroup's static range gets the same mix of rays
     // (k_walk's lesson; in index order a 256-thread grid of 8 workgroups per CU took 14.4 ms where 32 per CU took 9.2)
-    uint32_t step = stepEnv > 0 ? (uint32_t)stepEnv : (uint32_t)(ss.numRegions*0.6180339887) | 1u;
+    uint32_t step = (uint32_t)(ss.numRegions*0.6180339887) | 1u;
     {
         auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
         while (step > 1 && gcd(step, ss.numRegions) != 1)
@@ -1062,7 +1034,7 @@ int launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* fr
         allInArena = allInArena && dm.inArena;
     a.swalkMode = big ? (allInArena ? 1 : 2) : 0;
     const int block = big ? 1024 : kBlock;
-    const int gridMult = gridMultEnv > 0 ? gridMultEnv : (big ? 1 : 32);
+    const int gridMult = big ? 1 : 32;
     const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1);
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)gridMult));
     if (big)
@@ -1169,17 +1141,15 @@ int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, floa
         if (tiles > 0)
         {
             const int span = 1 + (int)floorf(fp.filterWidth) + (int)ceilf(fp.filterWidth) + 1;     // reachLo + reachHi + 1
-            static const bool noSpan = getenv("TINSEL_HIP_ACC_NO_SPAN") != nullptr;
-            // few tiles (a wave per SIMD or less): 512-thread workgroups, the second half only stages (tn_kernels.h); TINSEL_HIP_ACC_WIDE=0/1: never / always (A/B)
-            const char* wideEnv = getenv("TINSEL_HIP_ACC_WIDE");      // (read per call: tests switch it)
-            const bool wide = wideEnv ? atoi(wideEnv) != 0 : tiles <= r->numCUs*4;
-            if (span == 3 && !noSpan && wide)
+            // few tiles (a wave per SIMD or less): 512-thread workgroups, the second half only stages (tn_kernels.h; profiles/r03_y_ab_acc_wide.md)
+            const bool wide = tiles <= r->numCUs*4;
+            if (span == 3 && wide)
                 hipLaunchKernelGGL((k_accumulate_tiled<3, 2*kBlock>), dim3(tiles), dim3(2*kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
-            else if (span == 4 && !noSpan && wide)
+            else if (span == 4 && wide)
                 hipLaunchKernelGGL((k_accumulate_tiled<4, 2*kBlock>), dim3(tiles), dim3(2*kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
-            else if (span == 3 && !noSpan)
+            else if (span == 3)
                 hipLaunchKernelGGL((k_accumulate_tiled<3>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
-            else if (span == 4 && !noSpan)
+            else if (span == 4)
                 hipLaunchKernelGGL((k_accumulate_tiled<4>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
             else
                 hipLaunchKernelGGL((k_accumulate_tiled<0>), dim3(tiles), dim3(kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
@@ -1204,22 +1174,20 @@ int streaming_grid(const tinsel_hip* r, size_t slots, int pipeline)
 {
     // (where the fused kernel's waves share their workgroup's regions -- three or more shadow rays per bounce, k_bounce -- the
     // regions may be twice as long: features 707 -> 740, features + probe 595 -> 622, veach +-0)
-    static const int regionEnv = getenv("TINSEL_HIP_REGION_LEN") ? std::max(64, atoi(getenv("TINSEL_HIP_REGION_LEN"))) : 0;
-    const size_t regionTarget = regionEnv ? (size_t)regionEnv : (pipeline == TINSEL_PIPELINE_WAVEFRONT && r->neePerPath >= 3) ? 2048 : 1024;
+    const size_t regionTarget = (pipeline == TINSEL_PIPELINE_WAVEFRONT && r->neePerPath >= 3) ? 2048 : 1024;
     const size_t perBlock = regionTarget*(kBlock/kWave);
     const size_t blocks = (slots + perBlock - 1)/perBlock;
     // (at least as many workgroups as the chip holds at once -- TINSEL_HIP_GRID_MIN per CU, default 3: k_bounce and k_shade run three
     // waves per SIMD -- where the batch has that many 256-path pieces: a 1 M-path batch would otherwise leave the third wave slot empty)
-    static const int gridMin = getenv("TINSEL_HIP_GRID_MIN") ? std::max(1, atoi(getenv("TINSEL_HIP_GRID_MIN"))) : kBounceWaves;
+    const int gridMin = pipeline == TINSEL_PIPELINE_WAVEFRONT ? r->bounceWaves : 3;
     const size_t lo = std::min<size_t>((size_t)r->numCUs*(size_t)gridMin, (slots + kBlock - 1)/kBlock), hi = (size_t)r->numCUs*(size_t)grid_mult();
     size_t grid = std::max<size_t>(1, std::min(hi, std::max(lo, blocks)));
     // The workgroups that HAVE work (regions are a whole number of waves long, so fewer than the grid may) as close to a whole number
     // of resident sets (gridMin per CU) as the region length allows within +-25 %: the last set of a launch is then full instead
     // of, say, two thirds empty.  Glass at 20 passes per batch 1262 -> 1291 Msamples/s, the 524k-triangle config 2024 -> 2034, the
     // fused configs +-0 (profiles/r03_s_ab_grid_round.txt); TINSEL_HIP_GRID_ROUND=0: off (A/B)
-    static const bool roundGrid = !(getenv("TINSEL_HIP_GRID_ROUND") && atoi(getenv("TINSEL_HIP_GRID_ROUND")) == 0);
     const size_t resident = (size_t)r->numCUs*(size_t)gridMin;
-    if (roundGrid && grid > 2*resident)
+    if (grid > 2*resident)
     {
         auto busy = [&](size_t g) {         // workgroups with work for a grid of g (set_regions' region length)
             const size_t regions = g*(kBlock/kWave);
@@ -1294,8 +1262,8 @@ bool split_one_set(tinsel_hip* r, LaunchArgs& a, size_t slots)
 {
     const uint32_t per = kBlock/kWave;
     const size_t cus = (size_t)r->numCUs;
-    // (W = kBounceWaves workgroups resident per CU: W - 1 long groups per CU hold W/(W + 1) of the batch -- three waves: two groups, three quarters)
-    const size_t W = (size_t)kBounceWaves;
+    // (W workgroups resident per CU: W - 1 long groups per CU hold W/(W + 1) of the batch -- three waves: two groups, three quarters)
+    const size_t W = (size_t)r->bounceWaves;
     const uint32_t L = (uint32_t)((slots*W/(W + 1))/((W - 1)*cus*per)/kWave*kWave);
     if (L < 3u*kWave)
         return false;
@@ -1330,7 +1298,7 @@ int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t ma
     if (tailEnv)
         sscanf(tailEnv, "%lf,%d", &share, &divide);
     // (three workgroups per CU are resident: k_bounce)
-    if (share < 0.0 && maxRegions > 0 && (size_t)*grid <= (size_t)r->numCUs*kBounceWaves && (size_t)*grid > (size_t)r->numCUs*(kBounceWaves - 1) && split_one_set(r, a, slots))
+    if (share < 0.0 && maxRegions > 0 && (size_t)*grid <= (size_t)r->numCUs*r->bounceWaves && (size_t)*grid > (size_t)r->numCUs*(r->bounceWaves - 1) && split_one_set(r, a, slots))
     {
         *grid = (int)(a.ss.numRegions/(kBlock/kWave));
         return 0;
@@ -1340,13 +1308,35 @@ int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t ma
         // a negative share: that multiple of ONE resident set's part of the batch (three workgroups per CU: k_bounce).  The default, half a
         // set's part, against a fixed eighth: cornell x 20 passes 4036 -> 4059, x 64 4203 -> 4221, features 1289 -> 1298, veach 1080p
         // 2610 -> 2621, gloss 10570 -> 10530 (call Z8)
-        const double sets = (double)*grid/(double)(kBounceWaves*r->numCUs);
+        const double sets = (double)*grid/(double)(r->bounceWaves*r->numCUs);
         share = std::min(0.25, std::max(0.03, -share/std::max(1.0, sets)));
     }
     if (share > 0.0 && share < 0.9 && divide >= 2)
         split_tail_regions(r, a, slots, share, divide, maxRegions);
     *grid = (int)(a.ss.numRegions/(kBlock/kWave));
     return 0;
+}
+
+// k_bounce's LDS plan for the scene: does it close ranks through the waves' shading pools (returned), and how many waves per SIMD = workgroups
+// per CU does it run at (r->bounceWaves: what the grid and the region cut are sized by).
+//   * Pools (25 KB of LDS per workgroup) where rays can LEAVE the scene -- veach 1515 -> 1866 Msamples/s, features 755 -> 865, env_loft 3598 ->
+//     3793, gloss 7584 -> 7934; between two facing planes every ray hits something and the pools only cost (cornell 2919 -> 2894) -- and
+//     where they do not cost the third resident workgroup (features' 32-KB arena + pools would leave two).
+//   * FOUR waves per SIMD (the 128-VGPR variant: 36 registers of loop invariants spilled in the prologue) where four workgroups' LDS fits
+//     the CU, i.e. without the pools: cornell 4503 -> 4989 Msamples/s, cfg1 2961 -> 3100, features 1020 -> 1055; with the pools three
+//     workgroups fit and the spills only cost (veach 2929 -> 2812, gloss 11 771 -> 11 190, env_loft 5064 -> 4915: profiles/r05_a_ab_waves4.md).
+//     TINSEL_HIP_BOUNCE_WAVES=3 / 4 forces either (A/B, tests).
+bool plan_bounce(tinsel_hip* r)
+{
+    static const char* repackEnv = getenv("TINSEL_HIP_REPACK");          // 0 / 1: never / always (A/B); default: open scenes
+    const char* wavesEnv = getenv("TINSEL_HIP_BOUNCE_WAVES");            // (read per call: tests switch it)
+    const size_t perCU = 160u*1024u;
+    const size_t lds = stack_bytes(r), withPool = lds + kPoolWords*sizeof(uint32_t);
+    const bool want = repackEnv ? atoi(repackEnv) != 0 : !r->sceneEnclosed;
+    const bool repack = want && withPool*3 <= perCU && withPool <= (size_t)r->sharedMemLimit;
+    const size_t perGroup = repack ? withPool : lds;
+    r->bounceWaves = wavesEnv ? (atoi(wavesEnv) >= 4 ? 4 : 3) : (perGroup*4 <= perCU && !r->countDetail) ? 4 : 3;
+    return repack;
 }
 
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp, bool accumulate = true)
@@ -1357,18 +1347,24 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     if (slots >= (size_t)0xffffffffu)
         return fail("render: batch too large");
     fp.shardPerPass = (uint32_t)perPass;
+    {
+        auto magic = [](uint32_t d) { return 0xffffffffu/std::max(1u, d); };      // (tn_kernels.h div_magic)
+        fp.perPassM = magic(fp.shardPerPass);
+        fp.tileSqM = magic((uint32_t)fp.shardTile*(uint32_t)fp.shardTile);
+        fp.tileM = magic((uint32_t)fp.shardTile);
+        fp.tilesXM = magic((uint32_t)fp.shardTilesX);
+    }
     fp.genCount = (uint32_t)slots;
     fp.accBegin = 0;
     fp.accEnd = fp.numPasses;
     fp.rrStart = r->rrStart;
     fp.repack = 0;
     fp.share = 0;
-    fp.groupStep = 1;
     const int gridFlat = (int)std::max<size_t>(1, (slots + kBlock - 1)/kBlock);
+    const bool repackPlan = resolve_pipeline(r) == TINSEL_PIPELINE_WAVEFRONT && plan_bounce(r);
     int gridPersist = streaming_grid(r, slots, resolve_pipeline(r));
     // the trace kernels stride over the regions: by default one block per four regions like the others
-    static const int gridMultTrace = getenv("TINSEL_HIP_GRID_MULT_TRACE") ? atoi(getenv("TINSEL_HIP_GRID_MULT_TRACE")) : 0;
-    int gridTrace = gridMultTrace > 0 ? std::max(1, std::min(gridPersist, r->numCUs*gridMultTrace)) : gridPersist;
+    int gridTrace = gridPersist;
     r->lastBatchSlots = slots;
 
     const int pipeline = resolve_pipeline(r);
@@ -1388,91 +1384,45 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         if (cut_regions(r, a, slots, &gridPersist, r->splitMaxRegions))
             return -1;
         a.grid = gridPersist;
-        // k_bounce closes ranks between the closest-hit trace and the shading half (the waves' shading pools, tn_kernels.h:
-        // 27 KB of LDS per workgroup) where rays can LEAVE the scene -- veach 1515 -> 1866 Msamples/s, features 755 -> 865, env_loft
-        // 3598 -> 3793, gloss 7584 -> 7934; between two facing planes every ray hits something and the pools only cost (cornell
-        // 2919 -> 2894: not one ray of its 5.68 per sample misses) -- and where the pools do not cost a resident workgroup: two
-        // per CU at three waves per SIMD (features' 32-KB arena + pools would leave two: there the third wave is worth more)
+        // (the shading pools and the waves per SIMD were planned before the batch was cut: plan_bounce)
+        if (repackPlan)
         {
-            static const char* repackEnv = getenv("TINSEL_HIP_REPACK");          // 0 / 1: never / always (A/B); default: open scenes
-            const bool want = repackEnv ? atoi(repackEnv) != 0 : !r->sceneEnclosed;
-            const size_t withPool = (size_t)a.ldsBytes + kPoolWords*sizeof(uint32_t);
-            const size_t perCU = 160u*1024u, blocksPerCU = kBounceWaves;      // k_bounce's waves per SIMD = its workgroups per CU
-            // (at four waves per SIMD the pools may cost the fourth workgroup, not the third)
-            if (want && withPool*std::min<size_t>(blocksPerCU, 3) <= perCU && withPool <= (size_t)r->sharedMemLimit)
-            {
-                a.fp.repack = 1;
-                a.ldsBytes = (uint32_t)withPool;
-            }
+            a.fp.repack = 1;
+            a.ldsBytes += (uint32_t)(kPoolWords*sizeof(uint32_t));
         }
+        a.bounceWaves = r->bounceWaves;
         // bounces > 0: a workgroup's four regions as ONE stream dealt to its waves -- where a round is long (three or more shadow rays)
         // and where the regions are short (a small batch: the ragged last round of every region and bounce weighs more)
         {
             const char* shareEnv = getenv("TINSEL_HIP_BOUNCE_SHARE");            // 0 / 1: never / always (A/B, tests: read per call)
-            static const int shareLen = getenv("TINSEL_HIP_BOUNCE_SHARE_LEN") ? atoi(getenv("TINSEL_HIP_BOUNCE_SHARE_LEN")) : 512;     // cornell 256^2 x 16 passes (regions of 384): 2258 -> 2311 Msamples/s; 1024^2 x 20 (regions of 2048) +0.3 %
+            const int shareLen = 512;       // cornell 256^2 x 16 passes (regions of 384): 2258 -> 2311 Msamples/s; 1024^2 x 20 (regions of 2048) +0.3 %
             a.fp.share = shareEnv ? (atoi(shareEnv) != 0) : (r->neePerPath >= 3 || (int)a.ss.regionLen <= shareLen);
         }
-        static const bool noOrder = getenv("TINSEL_HIP_NO_REGION_ORDER") != nullptr;
-        // ONE launch takes every region through all the bounces (k_bounce, tn_kernels.h); TINSEL_HIP_BOUNCE_LAUNCHES=per: one
-        // launch per bounce with the regions longest first, as before (A/B)
-        static const bool perBounce = getenv("TINSEL_HIP_BOUNCE_LAUNCHES") && !strcmp(getenv("TINSEL_HIP_BOUNCE_LAUNCHES"), "per");
-        if (!perBounce)
-        {
-            a.bounce = 0;
-            a.bounceEnd = fp.maxDepth;
-            a.order = nullptr;
-            {
-                // workgroup b takes region group (b*step) mod groups.  Index order (step 1) is the default: a golden-section step,
-                // which k_walk's static ranges need, loses here -- the dispatcher already hands workgroups out dynamically
-                // (veach 1970 -> 1904 Msamples/s, features 898 -> 880, cornell 2999 -> 2979, env_loft 3812 -> 3820)
-                static const int stepEnv = getenv("TINSEL_HIP_BOUNCE_GROUP_STEP") ? atoi(getenv("TINSEL_HIP_BOUNCE_GROUP_STEP")) : 1;
-                const uint32_t groups = a.ss.numRegions/kRegionsPerBlock;
-                uint32_t step = stepEnv > 0 ? (uint32_t)stepEnv : (uint32_t)(groups*0.6180339887) | 1u;
-                auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
-                while (step > 1 && gcd(step, groups) != 1)
-                    step -= 1;
-                a.fp.groupStep = (step >= groups || groups > 65535u) ? 1u : step;        // (the kernel multiplies in 32 bits)
-            }
-            ScopedTimer t(r, KN_BOUNCE, st);
-            launch_path(r, PK_BOUNCE, a, st);
-        }
-        else
-        for (int bounce = 0; bounce < fp.maxDepth; ++bounce)
-        {
-            a.bounce = bounce;
-            a.bounceEnd = bounce + 1;
-            a.order = nullptr;
-            if (bounce > 0 && !noOrder && gridPersist > r->numCUs*2)
-            {
-                // longest regions first (k_region_order, tn_kernels.h); bounce 0's regions are all full
-                ScopedTimer t(r, KN_SEG, st);
-                const size_t W = a.ss.numRegions;
-                hipLaunchKernelGGL(k_region_order, dim3(1), dim3(kOrderBlock), 0, st, (const uint32_t*)(r->ss.segFront + (size_t)bounce*W),
-                                   (const uint32_t*)(r->ss.segBack + (size_t)bounce*W), a.ss.numRegions, r->regionOrder);
-                a.order = r->regionOrder;
-            }
-            ScopedTimer t(r, KN_BOUNCE, st);
-            launch_path(r, PK_BOUNCE, a, st);
-        }
+        // ONE launch takes every region through all the bounces (k_bounce, tn_kernels.h).  (Workgroup b takes region group b: a golden-section
+        // step, which k_walk's static ranges need, loses here -- the dispatcher already hands workgroups out dynamically: veach 1970 -> 1904
+        // Msamples/s, features 898 -> 880, cornell 2999 -> 2979.  The per-bounce launches of rounds 1-2, regions longest first, went in round 5.)
+        a.bounce = 0;
+        a.bounceEnd = fp.maxDepth;
+        a.order = nullptr;
+        ScopedTimer t(r, KN_BOUNCE, st);
+        launch_path(r, PK_BOUNCE, a, st);
     }
     else
     {
         const bool walk = walk_records(r) != nullptr;
         // every mesh primitive walked by k_walk: the scan kernels run their lean variants with the scene-level stack only
-        static const bool noLeanScan = getenv("TINSEL_HIP_NO_LEAN_SCAN") != nullptr;
         int meshPrims = 0;
         for (int m : r->primMesh)
             meshPrims += m >= 0 ? 1 : 0;
-        const bool walkedOnly = walk && !noLeanScan && meshPrims == r->walkPrims.count && !r->scene.allInArena;
+        const bool walkedOnly = walk && meshPrims == r->walkPrims.count && !r->scene.allInArena;
         const int stackScan = walkedOnly ? std::max(1, pick_stack(r->sceneStackNeed)) : r->stackNeed;
         const uint32_t ldsTrace = walkedOnly ? (uint32_t)(((size_t)stackScan*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes) : a.ldsBytes;
         // k_shade has no traversal stacks in LDS and reads a material per path: an arena too large to sit beside the stacks of the
         // trace kernels (32 KB) is still staged by it up to 60 KB (many_spheres, 39 KB of primitive and material records: k_shade
         // 7.8 -> 6.7 ms; staged in the trace kernels too it costs them their fourth wave per SIMD, 1380 -> 1280 Msamples/s, and
         // k_lights reads too little of it to repay the copy, 2.7 -> 3.1 ms)
-        static const bool noShadeArena = getenv("TINSEL_HIP_NO_SHADE_ARENA") != nullptr;
         const uint32_t arenaLdsTrace = r->scene.arenaLdsBytes;
-        const uint32_t arenaLdsShade = (arenaLdsTrace == 0 && !noShadeArena && r->scene.arenaBytes <= 61440u && !getenv("TINSEL_HIP_NO_LDS_SCENE")) ? r->scene.arenaBytes : arenaLdsTrace;
+        const uint32_t arenaLdsShade = (arenaLdsTrace == 0 && r->scene.arenaBytes <= 61440u && !getenv("TINSEL_HIP_NO_LDS_SCENE")) ? r->scene.arenaBytes : arenaLdsTrace;
         const uint32_t ldsShade = r->scene.allInArena ? r->scene.arenaBytes : arenaLdsShade;
         a.walkedOnly = walkedOnly ? 1 : 0;
         static const bool noSceneWalkEarly = getenv("TINSEL_HIP_NO_SCENE_WALK") != nullptr;
@@ -1480,41 +1430,33 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         // ... and so does the variant for a staged arena with meshes in HBM (glass): without the SLP vectoriser it fits 128 VGPRs and
         // saves k_lights' pass over the path state (k_extend 5.7 + k_lights 7.1 -> 11.2 ms per 32 passes, glass 1366 -> 1425 Msamples/s;
         // round 2, 170 VGPRs: 29.1 apart, 31.5 together).  TINSEL_HIP_LIGHTS_IN_EXTEND=0: k_lights as a kernel of its own (A/B)
-        static const bool lightsInExtendEnv = !(getenv("TINSEL_HIP_LIGHTS_IN_EXTEND") && atoi(getenv("TINSEL_HIP_LIGHTS_IN_EXTEND")) == 0);
         const bool mixedArena = !r->scene.allInArena && r->scene.arenaLdsBytes != 0 && r->scene.arenaLdsBytes == r->scene.arenaBytes;
-        const bool lightsInMixed = lightsInExtendEnv && !walkedOnly && !r->countDetail && mixedArena && !(!noSceneWalkEarly && !r->scene.flatScan);
+        const bool lightsInMixed = !walkedOnly && !r->countDetail && mixedArena && !(!noSceneWalkEarly && !r->scene.flatScan);
         a.lightsInExtend = lightsInMixed ? 1 : 0;
         const bool lightsInExtend = (walkedOnly && !r->countDetail) || lightsInMixed;
-        // k_shade's variant that traces the shadow rays itself, after k_walk has done their mesh parts (no k_shadow launch, no pass over
-        // the shadow-ray records of its own): staged arena + meshes in HBM, flat scan.  TINSEL_HIP_SHADOW_IN_SHADE=1 (A/B)
-        const char* shadowInShadeEnv = getenv("TINSEL_HIP_SHADOW_IN_SHADE");        // (read per call: tests switch it)
-        const bool shadowInShade = shadowInShadeEnv && atoi(shadowInShadeEnv) != 0 && mixedArena && r->scene.flatScan && !r->countDetail &&
-                                   r->neePerPath > 0 && arenaLdsShade == arenaLdsTrace;
         // No short regions at the end by default here (TINSEL_HIP_TAIL_SPLIT_SPLIT=1: A/B): the launches are many and short, k_walk cuts its
         // own list into static ranges, and more regions cost k_seg_prefix / k_walk more than the other kernels' tails gain -- the 524k-triangle
         // config 2319 -> 2254 Msamples/s, many_spheres 2108 -> 2082, glass +-0 (profiles/r03_z5_ab_tail_split.md).  (k_seg_prefix stages
         // the regions' counts in LDS: (sharedMemLimit - 1024)/4 of them at most where a walk list is built.)
-        static const bool tailInSplit = getenv("TINSEL_HIP_TAIL_SPLIT_SPLIT") && atoi(getenv("TINSEL_HIP_TAIL_SPLIT_SPLIT")) != 0;
         // (k_seg_prefix stages one count per region in LDS: where a walk list is built the grid is clamped to what fits)
         if (r->walkList != nullptr)
             gridPersist = std::max(1, std::min(gridPersist, (int)(seg_prefix_max_regions(r)/(kBlock/kWave))));
-        if (cut_regions(r, a, slots, &gridPersist, !tailInSplit ? (size_t)0 : r->walkList != nullptr ? (size_t)seg_prefix_max_regions(r) : (size_t)r->splitMaxRegions))
+        if (cut_regions(r, a, slots, &gridPersist, (size_t)0))
             return -1;
-        gridTrace = gridMultTrace > 0 ? std::max(1, std::min(gridPersist, r->numCUs*gridMultTrace)) : gridPersist;
+        gridTrace = gridPersist;
         const size_t W = a.ss.numRegions;
         {
             ScopedTimer t(r, KN_GENERATE, st);
             a.grid = gridPersist;
             launch_path(r, PK_GENERATE, a, st);
         }
-        static const bool noOrder = getenv("TINSEL_HIP_NO_REGION_ORDER") != nullptr;
         // (not where k_walk does the walking: what is left for the scan kernels is too short for the two extra launches per
         // bounce to pay -- glass 1087 -> 1077, config 3 1891 -> 1881; many_spheres, scene BVH walked inline, 1168 -> 1290)
         // scenes the flat scan cannot take (more than 64 primitives): the scene-level walk with ray replacement (k_swalk, tn_swalk.h)
         // in the place of k_extend / k_shadow; the detail counters count the inline walks
         static const bool noSceneWalk = getenv("TINSEL_HIP_NO_SCENE_WALK") != nullptr;
         const bool sceneWalk = !noSceneWalk && !r->scene.flatScan && !r->countDetail && r->walkList != nullptr && !walk;
-        const bool ordered = !noOrder && !walk && gridPersist > r->numCUs*2;
+        const bool ordered = !walk && gridPersist > r->numCUs*2;
         auto order_regions = [&](const uint32_t* front, const uint32_t* back, uint32_t* out) {
             ScopedTimer t(r, KN_SEG, st);
             hipLaunchKernelGGL(k_region_order, dim3(1), dim3(kOrderBlock), 0, st, front, back, a.ss.numRegions, out);
@@ -1572,7 +1514,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                     if (launch_swalk(r, st, a, r->ss.neeFront + (size_t)bounce*W, r->ss.neeBack + (size_t)bounce*W, true))
                         return -1;
                 }
-                else if (!shadowInShade)
+                else
                 {
                     if (ordered && bounce > 0)
                     {
@@ -1598,9 +1540,8 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 static const char* sortedEnv = getenv("TINSEL_HIP_SHADE_SORTED");
                 const bool shadeSorted = sortedEnv ? atoi(sortedEnv) != 0 : (!r->sceneEnclosed && !walk);
                 a.grid = gridPersist;
-                a.shadeSorted = (shadeSorted && !shadowInShade) ? 1 : 0;
-                a.shadowInShade = shadowInShade ? 1 : 0;
-                a.ldsBytes = shadowInShade ? ldsTrace : ldsShade + (shadeSorted ? (uint32_t)(kShadeListWords*sizeof(uint32_t)) : 0u);
+                a.shadeSorted = shadeSorted ? 1 : 0;
+                a.ldsBytes = ldsShade + (shadeSorted ? (uint32_t)(kShadeListWords*sizeof(uint32_t)) : 0u);
                 a.stackEntries = stackScan;
                 a.scene.arenaLdsBytes = arenaLdsShade;
                 launch_path(r, PK_SHADE, a, st);
@@ -1643,6 +1584,8 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
     FrameParams fp;
     fp.width = options->width;
     fp.height = options->height;
+    fp.npixM = 0xffffffffu/(uint32_t)std::max(1, options->width*options->height);
+    fp.widthM = 0xffffffffu/(uint32_t)std::max(1, options->width);
     fp.maxDepth = options->max_depth;
     fp.shardRank = r->shardRank;
     fp.shardWorld = r->shardWorld;
@@ -1733,7 +1676,7 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
     int lanes = 1;
     {
         const char* overlapEnv = getenv("TINSEL_HIP_OVERLAP");         // (read per call: tests switch it)
-        static const size_t minPaths = getenv("TINSEL_HIP_OVERLAP_MIN_PATHS") ? (size_t)atoll(getenv("TINSEL_HIP_OVERLAP_MIN_PATHS")) : ((size_t)8u << 20);
+        const size_t minPaths = (size_t)8u << 20;
         const int pipeline = resolve_pipeline(r);
         const bool can = !traceOnly && perBatch >= 2 && pipeline != TINSEL_PIPELINE_MEGAKERNEL;
         static const bool noSceneWalk = getenv("TINSEL_HIP_NO_SCENE_WALK") != nullptr;
@@ -1799,7 +1742,12 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
         if (!rc)
             rc = hipStreamWaitEvent(st, r->laneJoin, 0) == hipSuccess ? 0 : fail("render: hipStreamWaitEvent");
         if (rc)
+        {
+            // kernels already enqueued on the second stream still run over the path state and the accumulator: nothing the caller does
+            // next (another render on another stream, init, destroy) may overtake them (lookahead_cancel does the same)
+            (void)hipStreamSynchronize(r->laneStream);
             return -1;
+        }
         // the test hooks read a whole batch (tinsel_hip_read_batch_radiance; queue_counts reports the second chunk's regions)
         r->lastBatchSlots = perPass*(size_t)n;
         r->lastFp.passBase = done;
@@ -2025,10 +1973,8 @@ struct ScratchPool
 int build_device_bvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out, int mode)
 {
     const int n = dm.numTris;
-    size_t sortBytes = 0, scanBytes = 0;
-    if (rocprim::radix_sort_keys(nullptr, sortBytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)n, 0, 62, nullptr) != hipSuccess ||
-        rocprim::exclusive_scan(nullptr, scanBytes, (int*)nullptr, (int*)nullptr, 0, (size_t)n, rocprim::plus<int>(), nullptr) != hipSuccess)
-        return fail("build_mesh_bvh: sort / scan sizing failed");
+    // scratch of the library's own sort and scan (tn_sort.h), in bytes
+    const size_t sortBytes = sort_scratch_ints((size_t)n)*sizeof(int), scanBytes = scan_scratch_ints((size_t)n)*sizeof(int);
     const size_t N = (size_t)n;
     ScratchPool tmp;
     if (!tmp.reserve(ScratchPool::padded(6*4) + 2*ScratchPool::padded(N*8) + ScratchPool::padded((N - 1)*8) + 2*ScratchPool::padded((2*N - 1)*4) +
@@ -2067,7 +2013,9 @@ int build_device_bvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out, int mode)
             hipMemsetAsync(visits, 0, sizeof(int)*(size_t)n, nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: init failed"); break; }
         hipLaunchKernelGGL(k_lbvh_bounds, dim3(grid < 256u ? grid : 256u), dim3(256), 0, nullptr, dm.tris, n, bounds);
         hipLaunchKernelGGL(k_lbvh_keys, dim3(grid), dim3(256), 0, nullptr, dm.tris, n, bounds, keys);
-        if (rocprim::radix_sort_keys(sortTmp, sortBytes, keys, sorted, (size_t)n, 0, 62, nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: sort failed"); break; }
+        // keys = Morton code << 32 | triangle index, written in index order: a STABLE sort by the code's bytes (bits 32..63) is the sort by the
+        // whole key
+        radix_sort_keys(keys, sorted, (size_t)n, 32, 64, reinterpret_cast<int*>(sortTmp), nullptr);
         hipLaunchKernelGGL(k_lbvh_leaves, dim3(grid), dim3(256), 0, nullptr, dm.tris, sorted, n, boxes, height);
         if (mode == TINSEL_BVH_PLOC)
         {
@@ -2084,7 +2032,7 @@ int build_device_bvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out, int mode)
                 const unsigned g = (unsigned)((c + 255)/256);
                 hipLaunchKernelGGL(k_ploc_nearest, dim3(g), dim3(256), 0, nullptr, (const int*)cur, c, (const float*)boxes, visits);
                 hipLaunchKernelGGL(k_ploc_merge, dim3(g), dim3(256), 0, nullptr, cur, c, (const int*)visits, boxes, children, height, nextId, keep);
-                if (rocprim::exclusive_scan(scanTmp, scanBytes, keep, offsets, 0, (size_t)c, rocprim::plus<int>(), nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: scan failed"); break; }
+                exclusive_scan(keep, offsets, (size_t)c, reinterpret_cast<int*>(scanTmp), nullptr);
                 hipLaunchKernelGGL(k_ploc_compact, dim3(g), dim3(256), 0, nullptr, (const int*)cur, c, (const int*)keep, (const int*)offsets, nxt, nextId + 1);
                 int left = 0;
                 if (hipMemcpy(&left, nextId + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("build_mesh_bvh: read-back failed"); break; }
@@ -2132,7 +2080,7 @@ int build_device_bvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out, int mode)
             hipMemcpy(topIds, topOrder.data(), sizeof(int)*(size_t)top, hipMemcpyHostToDevice) != hipSuccess) { rc = fail("build_mesh_bvh: upload failed"); break; }
         int* rank = keep;           // (free again)
         hipLaunchKernelGGL(k_bfs_mark, dim3((unsigned)((top + 255)/256)), dim3(256), 0, nullptr, (const int*)topIds, top, isTop, rank);
-        if (rocprim::exclusive_scan(scanTmp, scanBytes, isTop, offsets, 0, N - 1, rocprim::plus<int>(), nullptr) != hipSuccess) { rc = fail("build_mesh_bvh: scan failed"); break; }
+        exclusive_scan(isTop, offsets, N - 1, reinterpret_cast<int*>(scanTmp), nullptr);
         hipLaunchKernelGGL(k_bfs_perm, dim3(grid), dim3(256), 0, nullptr, n - 1, top, (const int*)isTop, (const int*)rank, (const int*)offsets, perm);
         hipLaunchKernelGGL(k_lbvh_emit_perm, dim3(grid), dim3(256), 0, nullptr, sorted, n, children, boxes, (const int*)perm, nodes);
         int rootHeight = 0;
@@ -2143,15 +2091,11 @@ int build_device_bvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out, int mode)
         out.stackNeed = rootHeight + 1;
         out.topCount = top;
         out.numInternal = n - 1;
-        out.pairs = nullptr;            // this tree's own bottom-level records (the reference tree keeps its)
     } while (false);
     if (rc)
         (void)hipFree(nodes);
     else
-    {
         r->lbvhAllocs.push_back(nodes);
-        rc = build_pairs(out, r->lbvhAllocs);
-    }
     return rc;
 }
 
@@ -2189,6 +2133,15 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
     {
         r->numCUs = prop.multiProcessorCount;
         r->sharedMemLimit = (int)prop.sharedMemPerBlock;
+    }
+    // every kernel's dynamic-LDS limit is raised here, once, and the results are checked: a device that grants less than it reports is
+    // refused now, by the kernel's name, not at some later launch with a generic error
+    prepare_kernels_once(r);
+    if (!r->prepRefused.empty())
+    {
+        fail("create: the device refused " + std::to_string(r->sharedMemLimit) + " B of dynamic LDS for " + r->prepRefused);
+        delete r;
+        return nullptr;
     }
 
     if (const char* e = getenv("TINSEL_HIP_BATCH_PATHS"))
@@ -2330,8 +2283,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 dm.topCount = cb.topCount;
                 dm.numInternal = (int32_t)cb.nodes.size();
                 // one internal node over two one-triangle leaves (a quad): walked without stack or loop (ray_mesh_two_leaves)
-                dm.twoLeaves = (cb.nodes.size() == 1 && !(cb.root & kLeafBit) && (cb.nodes[0].left & kLeafBit) && (cb.nodes[0].right & kLeafBit) &&
-                                !getenv("TINSEL_HIP_NO_TWO_LEAVES")) ? 1 : 0;
+                dm.twoLeaves = (cb.nodes.size() == 1 && !(cb.root & kLeafBit) && (cb.nodes[0].left & kLeafBit) && (cb.nodes[0].right & kLeafBit)) ? 1 : 0;
                 const size_t meshBytes = cb.nodes.size()*sizeof(Node64) + tris.size()*sizeof(Tri48) + (size_t)g.num_vertices*12 + (size_t)numTris*4;
                 if (lives_in_arena(meshBytes, numTris))
                 {
@@ -2348,7 +2300,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                     dm.tris = r->sceneMem.upload(tris.data(), tris.size());
                     dm.normals = r->sceneMem.upload(&g.normals[0].x, (size_t)g.num_vertices*3);
                     dm.cdf = r->sceneMem.upload(g.cdf, (size_t)numTris);
-                    if ((!cb.nodes.empty() && !dm.nodes) || !dm.tris || !dm.normals || !dm.cdf || build_pairs(dm, r->sceneMem.allocs))
+                    if ((!cb.nodes.empty() && !dm.nodes) || !dm.tris || !dm.normals || !dm.cdf)
                     {
                         fail("create: device allocation failed (mesh)");
                         ok = false;
@@ -2455,7 +2407,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         // the always-hit planes once more, four by four, for the flat scan (trace_flat; TINSEL_HIP_NO_PLANE_TABLE: A/B)
         std::vector<float> planeEq;
         std::vector<int32_t> planeIdx;
-        if (flatScan && !getenv("TINSEL_HIP_NO_PLANE_TABLE"))
+        if (flatScan)
         {
             for (int k = 0; k < P; ++k)
                 if (prims[(size_t)k].type == kPrimPlane && boxes[(size_t)k].alwaysHit)
@@ -2536,7 +2488,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 int meshPrimCount = 0;
                 for (int k = 0; k < P; ++k)
                     meshPrimCount += prims[(size_t)k].type == kPrimMesh ? 1 : 0;
-                sc.deferMeshes = (meshPrimCount >= 2 && !getenv("TINSEL_HIP_NO_DEFER_MESHES")) ? 1 : 0;
+                sc.deferMeshes = (meshPrimCount >= 2) ? 1 : 0;
             }
             // Fused kernel: sort the next bounce's queue by "meets the box of a bounded primitive" (tn_isect.h) when the
             // scene is open.  Measured (cornell-sized frames, fused kernel): env_loft (1 plane) +16 %, gloss (1 plane) +4 %;
@@ -2546,7 +2498,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                 int planes = 0;
                 for (int k = 0; k < P; ++k)
                     planes += boxes[(size_t)k].alwaysHit ? 1 : 0;
-                sc.sortQueues = (sc.flatScan && planes <= 2 && planes < P && !getenv("TINSEL_HIP_NO_SORT_QUEUES")) ? 1 : 0;
+                sc.sortQueues = (sc.flatScan && planes <= 2 && planes < P) ? 1 : 0;
             }
             // two infinite planes with opposite normals (a floor and a ceiling): every ray between them that is not parallel to
             // them hits one -- a scene no ray leaves, whatever else is in it (cornell.tin, glass.tin)
@@ -2562,7 +2514,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
             bool all = sc.arenaLdsBytes != 0;
             for (const DevMesh& dmesh : meshes)
                 all = all && dmesh.inArena;
-            sc.allInArena = (all && !getenv("TINSEL_HIP_NO_LDS_TEMPLATE")) ? 1 : 0;
+            sc.allInArena = all ? 1 : 0;
         }
         sc.root = sceneBvh.root;
         sc.numPrims = P;
@@ -2745,8 +2697,6 @@ int tinsel_hip_set_lookahead(tinsel_hip* r, int enable)
         r->pinnedBytes = 0;
     }
     r->lookahead = enable == TINSEL_LOOKAHEAD_PIN_OUTPUT ? TINSEL_LOOKAHEAD_PIN_OUTPUT : (enable ? TINSEL_LOOKAHEAD_ON : TINSEL_LOOKAHEAD_OFF);
-    if (const char* e = getenv("TINSEL_HIP_LOOKAHEAD_DEPTH"))
-        r->lookaheadDepth = std::max(0, atoi(e));
     return 0;
 }
 
@@ -2974,9 +2924,6 @@ int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_x
                 }
                 if (!rootGen)
                     rc = fail("refit_mesh: the refit did not reach the root");
-                // the bottom-level records hold copies of the triangles (tn_scene.h Pair128)
-                if (!rc && tree->pairs)
-                    rc = fill_pairs(*const_cast<DevMesh*>(tree));
             }
             if (rc)
                 break;
@@ -3274,9 +3221,25 @@ int tinsel_hip_rebuild_scene(tinsel_hip* r, int mode, const tinsel_bvh_node* nod
     unsigned char* arenaDev = const_cast<unsigned char*>(r->scene.arena);
     if (!sceneBvh.nodes.empty())
         HIP_TRY(hipMemcpy(arenaDev + r->arenaOffNodes, sceneBvh.nodes.data(), sizeof(Node64)*sceneBvh.nodes.size(), hipMemcpyHostToDevice));
-    for (int32_t k : r->planeTablePrims)
-        if (boxes[(size_t)k].alwaysHit)
-            boxes[(size_t)k].alwaysHit = 2u;
+    // The plane table (flat scan of the split pipeline's kernels: the always-hit planes' equations, tested ahead of the loop) follows the new
+    // boxes: a table plane whose leaf box is no longer "infinite" (the primitive was scaled below 0.1, or the caller's tree has a tighter
+    // leaf) is box-tested in the loop like everything else -- its table entry becomes d == 0, IntersectRayPlane's own "no hit" -- and one
+    // whose box is infinite again gets its equation back (the table used to be written at create only).
+    if (!r->planeTablePrims.empty() && r->scene.planeEq)
+    {
+        std::vector<float> eq(r->planeTablePrims.size()*4, 0.0f);
+        for (size_t t = 0; t < r->planeTablePrims.size(); ++t)
+        {
+            const int32_t k = r->planeTablePrims[t];
+            if (boxes[(size_t)k].alwaysHit)
+            {
+                boxes[(size_t)k].alwaysHit = 2u;
+                const Prim64& pp = r->primsHost[(size_t)k];
+                eq[t*4 + 0] = pp.g0; eq[t*4 + 1] = pp.g1; eq[t*4 + 2] = pp.g2; eq[t*4 + 3] = pp.g3;
+            }
+        }
+        HIP_TRY(hipMemcpy(const_cast<float4*>(r->scene.planeEq), eq.data(), eq.size()*sizeof(float), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(arenaDev + r->arenaOffBoxes, boxes.data(), sizeof(PrimBox)*(size_t)P, hipMemcpyHostToDevice));
     r->scene.root = sceneBvh.root;
     r->sceneStackNeed = sceneBvh.maxLeafDepth + 1;
@@ -3483,6 +3446,8 @@ int tinsel_hip_enable_kernel_timing(tinsel_hip* r, int enable)
     r->timing = enable != 0;
     return 0;
 }
+
+int tinsel_hip_kernel_time_bytes(void) { return (int)sizeof(tinsel_kernel_time); }
 
 int tinsel_hip_kernel_times(tinsel_hip* r, tinsel_kernel_time* out, int max_entries)
 {
@@ -3945,6 +3910,9 @@ struct RcclApi
 
 RcclApi g_rccl;
 
+} // namespace
+
+namespace tn {
 // validation arm of the reduce (members sharing one device): total = sum over members in rank order
 struct SumSources { const float4* src[16]; int n; };
 __global__ void k_sum_accums(SumSources s, float4* __restrict__ total, size_t count)
@@ -3960,6 +3928,9 @@ __global__ void k_sum_accums(SumSources s, float4* __restrict__ total, size_t co
     }
     total[i] = a;
 }
+} // namespace tn
+
+namespace {
 
 enum { GJ_NONE = 0, GJ_INIT, GJ_RENDER, GJ_REDUCE, GJ_AHEAD, GJ_QUIT };
 

@@ -154,35 +154,6 @@ TN_D bool ray_plane(V3 p, V3 dir, float px, float py, float pz, float pw, float&
     return t > 0.0f;
 }
 
-// IntersectRayPlane for a closest-hit scan that already holds a hit at `bound`: the same answer wherever the answer can matter, without
-// the IEEE division (a dozen instructions; a flat scan of cornell's five planes makes ten per round) where it cannot --
-//   * t = -num/d > 0 needs num and d of opposite signs: a quotient's sign is exact, and +-0 is not > 0;
-//   * a plane farther than `bound` by more than the scan's tie window (trace_flat: 1e-5 relative) neither becomes the closest hit nor
-//     raises the tie flag: |num| * v_rcp(|d|) is within 2^-21 of |num/d|, the margin is 4e-5.
-// bound == FLT_MAX (every caller but the flat scan): IntersectRayPlane as it is.
-// OFF (-DTN_PLANE_PRUNE=1 builds it in): bit-identical (the whole GPU suite ran with it), and it LOSES -- cornell 4177 -> 4014 Msamples/s,
-// cfg1 2745 -> 2648, veach 4K 2845 -> 2819 (profiles/r04_g_ab_plane_prune.md): the flat scan is wave-uniform, a lane-dependent early-out
-// saves the division only when all 64 lanes take it, and pays its exec-mask branches always.
-#ifndef TN_PLANE_PRUNE
-#define TN_PLANE_PRUNE 0
-#endif
-TN_D bool ray_plane_bounded(V3 p, V3 dir, float px, float py, float pz, float pw, float bound, float& t)
-{
-    float d = px*dir.x + py*dir.y + pz*dir.z + pw*0.0f;
-    if (d == 0.0f)
-        return false;
-    const float num = px*p.x + py*p.y + pz*p.z + pw*1.0f;
-    if (TN_PLANE_PRUNE && bound < kFltMax)
-    {
-        if (((num > 0.0f) == (d > 0.0f)) || num == 0.0f)
-            return false;
-        if (fabsf(num)*__builtin_amdgcn_rcpf(fabsf(d)) > bound*1.00004f)
-            return false;
-    }
-    t = -num/d;
-    return t > 0.0f;
-}
-
 // IntersectRayTriTwoSided (intersection.h:117-145)
 TN_D bool ray_tri(V3 p, V3 dir, V3 a, V3 b, V3 c, float& t, float& u, float& v, float& w, float& sign, V3& n)
 {
@@ -429,20 +400,11 @@ TN_D Prim64 load_prim_uniform(ConstF4 prims, int idx)
     return p;
 }
 
-// The first words {t, u, v, w} of a ray's first two walk records, requested by the scan kernels BEFORE the trace for the rays at the front
-// of their region (the ones k_walk walked): they arrive behind the plane tests instead of being waited for, one after the other, where the
-// scan meets the walked primitives.  By value, all the way down: values the register allocator can keep where it likes.  n == 0: none --
-// which is what the default build passes (TN_WALK_PREFETCH, tn_kernels.h: measured, a wash), and every use below folds away.
-struct WalkPre { float4 r0, r1; uint32_t n; };
-TN_D WalkPre no_walk_pre() { WalkPre p = { make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), 0u }; return p; }
-
 // PrimitiveIntersect (intersection.h:951-1020)
 // UNIFORM: `index` is the same in every lane (the flat scan's loop counter)
-// `bound`: the closest hit a scene-level SCAN already holds (trace_flat) -- lets a plane skip its division where it cannot matter
-// (ray_plane_bounded); every other caller leaves it at FLT_MAX.
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false, bool UNIFORM = false>
 TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f,
-                         float bound = kFltMax, const V3* rcpWorld = nullptr, WalkPre pre = no_walk_pre())
+                         const V3* rcpWorld = nullptr)
 {
     const Prim64 p = UNIFORM ? load_prim_uniform(sc.kPrims, index) : load_prim(sc.prims, index);
     if (COUNT) ctr.prims++;
@@ -450,7 +412,7 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
     if (p.type == kPrimPlane)
     {
         // the reference interpolates the pose here too but the plane test never reads it
-        bool hit = ray_plane_bounded(o, d, p.g0, p.g1, p.g2, p.g3, bound, outT);
+        bool hit = ray_plane(o, d, p.g0, p.g1, p.g2, p.g3, outT);
         if (hit)
             outN = V3(p.g0, p.g1, p.g2);
         return hit;
@@ -476,15 +438,7 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
         // on the same lo / ld (tn_walk.h); t == FLT_MAX marks "no hit" (ray_mesh's own `closestT < FLT_MAX`)
         const uint32_t kb = (p.flags >> kPrimWalkLaneShift) & 7u;
         const float4* rp = sc.walkRec + (size_t)(sc.walkItem + kb)*2;
-        float4 ra;
-        if (kb < pre.n)
-        {
-            // requested before the trace (walk_prefetch, tn_kernels.h)
-            ra.x = kb == 0u ? pre.r0.x : pre.r1.x; ra.y = kb == 0u ? pre.r0.y : pre.r1.y;
-            ra.z = kb == 0u ? pre.r0.z : pre.r1.z; ra.w = kb == 0u ? pre.r0.w : pre.r1.w;
-        }
-        else
-            ra = rp[0];
+        const float4 ra = rp[0];
         if (!(ra.x < kFltMax))
             return false;
         const float4 rb = rp[1];
@@ -532,8 +486,7 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
 // re-traces that ray with the BVH walk, which IS the oracle's order.  Results are therefore identical
 // to the BVH walk in all cases.
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false>
-TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, float& outT, V3& outN, bool& tie, TraceCounters& ctr, float tStop = 0.0f,
-                    WalkPre pre = no_walk_pre())
+TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, float& outT, V3& outN, bool& tie, TraceCounters& ctr, float tStop = 0.0f)
 {
     float minT = kFltMax;
     int closest = -1;
@@ -630,7 +583,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
         }
         float t;
         V3 n;
-        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, minT, &rcp, pre);
+        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, &rcp);
 #ifdef TN_PROFILE_TRACE
         { const uint32_t ty = __builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float4*>(sc.prims + i)[3].x)); TN_TTICK(ctr, ty == kPrimPlane ? 1 : ty == kPrimSphere ? 2 : 3) }
 #endif
@@ -650,7 +603,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
             meshes &= meshes - 1ull;
             float t;
             V3 n;
-            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, kFltMax, &rcp, pre))
+            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, &rcp))
                 accept(i, t, n);
             if (ANYHIT && minT < tStop)
                 break;
@@ -700,7 +653,7 @@ TN_D float shadow_stop(float dist)
 }
 
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false>
-TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f, WalkPre pre = no_walk_pre())
+TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f)
 {
     float minT = kFltMax;
     int closest = -1;
@@ -719,7 +672,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
         // (the flat scan always runs to its end: stopping it early was measured and costs more in the scan's shape than the
         // skipped tests give back -- cornell 2835 -> 2713 Msamples/s, veach 1454 -> 1366; what stops early is the walks)
         if (sane)
-            prim = trace_flat<SC, Stack, COUNT, false>(sc, st, o, d, rcp, time, outT, outN, tie, ctr, 0.0f, pre);
+            prim = trace_flat<SC, Stack, COUNT, false>(sc, st, o, d, rcp, time, outT, outN, tie, ctr, 0.0f);
         if (sane && !tie)
             return prim;
     }
@@ -737,7 +690,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
             float t;
             V3 n;
             const int index = (int)(ref & ~kLeafBit);
-            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, index, st, sp, o, d, time, t, n, ctr, tStop, kFltMax, &rcp, pre))
+            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, index, st, sp, o, d, time, t, n, ctr, tStop, &rcp))
             {
                 if (t < minT && t > 0.0f)
                 {

@@ -28,15 +28,11 @@ namespace tn {
 #ifndef TN_WAVES_FUSED
 #define TN_WAVES_FUSED 2
 #endif
-// k_bounce and k_shade: THREE waves per SIMD (168 VGPRs) in both arithmetic arms.  The parity arm's k_bounce needs ~250 registers and
-// k_shade ~230; with the SLP vectoriser on (round 2) squeezing them cost 364-416 B of scratch and ran 1.4-1.8x slower.  Without it
-// (tinsel_amd/build.py) the squeeze spills 48-80 registers and the third wave pays for them several times over -- the kernels
-// wait on dependent fp32 / fp64 chains, not on issue slots: cornell 2989 -> 3805 Msamples/s, veach 1961 -> 2575, gloss 8276 -> 9614
-// (k_bounce); glass 1320 -> 1372, the 524k-triangle config 2190 -> 2254 (k_shade; many_spheres 2081 -> 2016).
-#ifndef TN_WAVES_BOUNCE
-#define TN_WAVES_BOUNCE 3
-#endif
-constexpr int kBounceWaves = TN_WAVES_BOUNCE;     // = k_bounce's resident workgroups per CU (256 threads each): what the host sizes its grids and LDS budgets by
+// k_bounce: its waves per SIMD are a template parameter (3: 168 VGPRs, no scratch; 4: 128 VGPRs, loop invariants spilled in the prologue) that
+// the host picks per scene from the LDS a workgroup needs (plan_bounce, tinsel_hip.hip).  History: the parity arm's k_bounce needed ~250 registers
+// until the SLP vectoriser went (tinsel_amd/build.py); the third wave then paid several times over -- the kernel waits on dependent fp32 / fp64
+// chains, not on issue slots: cornell 2989 -> 3805 Msamples/s, veach 1961 -> 2575 -- and since round 4 took the libm coefficients, a dead double
+// atan2 and the late-read kernel arguments out of its registers the fourth does too where four workgroups fit a CU (cornell 4503 -> 4989).
 // k_shade: four since the end of round 4 -- with the libm coefficients out of its registers (K64, tn_math.h) the staged-arena variant needs
 // 133 VGPRs and fits 128 without a byte of scratch (glass k_shade 8.9-9.1 -> 8.7-8.9 ms, motionblur 6.3 -> 5.4, many_spheres +1.7 %:
 // profiles/r04_v_ab_k64.md; at three waves it had been 168 VGPRs + 108 B)
@@ -82,6 +78,8 @@ struct CameraParams
 struct FrameParams
 {
     int width, height;
+    uint32_t npixM, widthM;         // floor((2^32 - 1)/(width*height)), floor((2^32 - 1)/width): slot_pixel's divisions as a multiply-high + one correction
+    uint32_t perPassM, tileSqM, tileM, tilesXM;     // the same for shardPerPass, shardTile^2, shardTile, shardTilesX (several shards)
     int passBase;           // first pass of this batch (index into passSeeds)
     int numPasses;          // passes in this batch
     int accBegin, accEnd;   // the batch passes [accBegin, accEnd) the accumulate kernels add (all of them, or one call's worth: look-ahead)
@@ -93,7 +91,6 @@ struct FrameParams
     int rrStart;                        // > 0: Russian roulette from this bounce on (opt-in, not the reference's behaviour)
     int repack;                         // k_bounce: paths that hit a surface close ranks (per-wave LDS pool) before the shading half
     int share;                          // k_bounce, bounces > 0: the workgroup's four regions form one stream dealt to its waves (host: >= 3 light samples, or short regions)
-    uint32_t groupStep;                 // k_bounce over all bounces: workgroup b takes region group (b*groupStep) mod groups (coprime; 1: in order)
     int filterType;
     float filterWidth, filterFalloff, filterOffset;
     float clampLen;
@@ -109,13 +106,6 @@ struct FrameParams
 
 constexpr int kStatShards = 2048;       // stats[kStatShards][8]
 constexpr int kStatWords = 8;
-#ifndef TN_SCAN_PREFETCH
-#define TN_SCAN_PREFETCH 0          // -DTN_SCAN_PREFETCH=1: k_extend / k_shadow request round i + 1's rays before they trace round i's (A/B)
-#endif
-#ifndef TN_WALK_PREFETCH
-#define TN_WALK_PREFETCH 0          // -DTN_WALK_PREFETCH=1: the scan kernels request a front ray's first two walk records before its trace (A/B:
-                                    // a wash on glass and the 524k-triangle config, -1 % where seven primitives are walked: profiles/r04_p_ab_walk_prefetch.md)
-#endif
 constexpr int kScanWords = 16;           // LDS words kept between the traversal stacks and the staged arena
 
 TN_D int lane_id() { return (int)__lane_id(); }
@@ -203,25 +193,34 @@ TN_D bool pixel_owned(const FrameParams& fp, int i, int j)
 // arrays hold exactly the paths it traces whatever the number of ranks, the generation kernels' lanes are all busy and
 // consecutive slots are consecutive pixels of a tile.  Tiles that stick out of the frame are padded to full size; the
 // padding slots are never generated, written or read.
+// n / d and n % d with the host's m = floor((2^32 - 1)/d): mulhi(n, m) is the quotient or one less (n < 2^32, d >= 1)
+TN_D void div_magic(uint32_t n, uint32_t d, uint32_t m, uint32_t& q, uint32_t& rem)
+{
+    q = __umulhi(n, m);
+    rem = n - q*d;
+    if (rem >= d) { ++q; rem -= d; }
+}
+
 TN_D bool slot_pixel(const FrameParams& fp, uint32_t slot, int& s, int& i, int& j)
 {
     if (fp.shardWorld <= 1)
     {
-        const uint32_t npix = (uint32_t)(fp.width*fp.height);
-        const uint32_t ss = slot/npix;
-        const uint32_t pix = slot - ss*npix;
-        const uint32_t jj = pix/(uint32_t)fp.width;
-        s = (int)ss; j = (int)jj; i = (int)(pix - jj*(uint32_t)fp.width);
+        // slot/npix and pix/width with the host's reciprocals (FrameParams::npixM / widthM): q' = mulhi(n, floor((2^32 - 1)/d)) is q or q - 1
+        // for n < 2^32.  The compiler's own expansion computes a float reciprocal of each (wave-uniform) divisor on the VALU, hoists it out
+        // of every loop and keeps it in a VGPR for the whole kernel -- four of k_bounce's spilled registers at four waves per SIMD.
+        uint32_t ss, pix, jj, ii;
+        div_magic(slot, (uint32_t)(fp.width*fp.height), fp.npixM, ss, pix);
+        div_magic(pix, (uint32_t)fp.width, fp.widthM, jj, ii);
+        s = (int)ss; j = (int)jj; i = (int)ii;
         return true;
     }
     const uint32_t T = (uint32_t)fp.shardTile;
-    const uint32_t ss = slot/fp.shardPerPass;
-    const uint32_t o = slot - ss*fp.shardPerPass;
-    const uint32_t k = o/(T*T);
-    const uint32_t within = o - k*T*T;
+    uint32_t ss, o, k, within, ty, tx, wy, wx;
+    div_magic(slot, fp.shardPerPass, fp.perPassM, ss, o);
+    div_magic(o, T*T, fp.tileSqM, k, within);
     const uint32_t t = (uint32_t)fp.shardRank + k*(uint32_t)fp.shardWorld;
-    const uint32_t ty = t/(uint32_t)fp.shardTilesX, tx = t - ty*(uint32_t)fp.shardTilesX;
-    const uint32_t wy = within/T, wx = within - wy*T;
+    div_magic(t, (uint32_t)fp.shardTilesX, fp.tilesXM, ty, tx);
+    div_magic(within, T, fp.tileM, wy, wx);
     s = (int)ss; i = (int)(tx*T + wx); j = (int)(ty*T + wy);
     return i < fp.width && j < fp.height;
 }
@@ -330,6 +329,11 @@ struct SplitState
 };
 
 TN_D uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// this wave's index in its workgroup, as a SCALAR (threadIdx.x/64 is wave-uniform, but only readfirstlane tells the compiler: what hangs off it --
+// region index, base, length, pool pointer -- then lives in SGPRs, or their spill lanes, instead of a VGPR each)
+TN_D uint32_t wave_in_block() { return wave_uniform(threadIdx.x/kWave); }
+// set bits of a wave mask below this lane: v_mbcnt_lo / _hi (no per-lane 64-bit mask kept in two registers)
+TN_D uint32_t bits_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 // the i-th live entry of a region packed at both ends
 TN_D uint32_t region_pos(uint32_t base, uint32_t len, uint32_t nFront, uint32_t i)
@@ -352,10 +356,9 @@ struct RegionAppend
     uint32_t base, len, nFront, nBack;      // wave-uniform
     TN_D uint32_t push(bool keep, bool front)
     {
-        const unsigned long long below = (1ull << __lane_id()) - 1ull;
         const unsigned long long fm = __ballot(keep && front), bm = __ballot(keep && !front);
-        const uint32_t pos = front ? base + nFront + (uint32_t)__popcll(fm & below)
-                                   : base + len - 1u - (nBack + (uint32_t)__popcll(bm & below));
+        const uint32_t pos = front ? base + nFront + bits_below(fm)
+                                   : base + len - 1u - (nBack + bits_below(bm));
         nFront += (uint32_t)__popcll(fm);
         nBack += (uint32_t)__popcll(bm);
         return pos;
@@ -461,9 +464,9 @@ __global__ __launch_bounds__(kOrderBlock) void k_region_order(const uint32_t* __
 // is skipped this round.  A region thus runs ceil(hits/64) shading rounds instead of one per trace round, no barrier, no
 // atomic; a path's arithmetic does not know which lane runs it, so no result changes.  Layout: pool[field][entry], one
 // dword per field, consecutive lanes on consecutive entries.
-constexpr int kPoolFields = 28;
+constexpr int kPoolFields = 25;         // (28 until round 5: the medium's absorption vector is looked up again from the medium's index, like load_state does)
 constexpr int kPoolWordsPerWave = kPoolFields*kWave;
-constexpr int kPoolWords = kPoolWordsPerWave*(kBlock/kWave);     // per workgroup: 27 KB
+constexpr int kPoolWords = kPoolWordsPerWave*(kBlock/kWave);     // per workgroup: 25 KB
 
 TN_D void pool_store(uint32_t* pool, uint32_t e, const PathRegs& p, uint32_t slot, int prim, float t, V3 n)
 {
@@ -475,14 +478,13 @@ TN_D void pool_store(uint32_t* pool, uint32_t e, const PathRegs& p, uint32_t slo
     q[10*kWave] = __float_as_uint(p.rad.x); q[11*kWave] = __float_as_uint(p.rad.y); q[12*kWave] = __float_as_uint(p.rad.z);
     q[13*kWave] = p.rng.s1; q[14*kWave] = p.rng.s2;
     q[15*kWave] = __float_as_uint(p.eta);
-    q[16*kWave] = __float_as_uint(p.absorption.x); q[17*kWave] = __float_as_uint(p.absorption.y); q[18*kWave] = __float_as_uint(p.absorption.z);
-    q[19*kWave] = __float_as_uint(p.bsdfPdf);
-    q[20*kWave] = (uint32_t)p.rayType;
-    q[21*kWave] = slot;
-    q[22*kWave] = (uint32_t)prim;
-    q[23*kWave] = __float_as_uint(t);
-    q[24*kWave] = __float_as_uint(n.x); q[25*kWave] = __float_as_uint(n.y); q[26*kWave] = __float_as_uint(n.z);
-    q[27*kWave] = (uint32_t)p.medium;
+    q[16*kWave] = __float_as_uint(p.bsdfPdf);
+    q[17*kWave] = (uint32_t)p.rayType;
+    q[18*kWave] = slot;
+    q[19*kWave] = (uint32_t)prim;
+    q[20*kWave] = __float_as_uint(t);
+    q[21*kWave] = __float_as_uint(n.x); q[22*kWave] = __float_as_uint(n.y); q[23*kWave] = __float_as_uint(n.z);
+    q[24*kWave] = (uint32_t)p.medium;
 }
 
 TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slot, int& prim, float& t, V3& n)
@@ -495,14 +497,13 @@ TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slo
     p.rad = V3(__uint_as_float(q[10*kWave]), __uint_as_float(q[11*kWave]), __uint_as_float(q[12*kWave]));
     p.rng.s1 = q[13*kWave]; p.rng.s2 = q[14*kWave];
     p.eta = __uint_as_float(q[15*kWave]);
-    p.absorption = V3(__uint_as_float(q[16*kWave]), __uint_as_float(q[17*kWave]), __uint_as_float(q[18*kWave]));
-    p.bsdfPdf = __uint_as_float(q[19*kWave]);
-    p.rayType = (int)q[20*kWave];
-    slot = q[21*kWave];
-    prim = (int)q[22*kWave];
-    t = __uint_as_float(q[23*kWave]);
-    n = V3(__uint_as_float(q[24*kWave]), __uint_as_float(q[25*kWave]), __uint_as_float(q[26*kWave]));
-    p.medium = (int)q[27*kWave];
+    p.bsdfPdf = __uint_as_float(q[16*kWave]);
+    p.rayType = (int)q[17*kWave];
+    slot = q[18*kWave];
+    prim = (int)q[19*kWave];
+    t = __uint_as_float(q[20*kWave]);
+    n = V3(__uint_as_float(q[21*kWave]), __uint_as_float(q[22*kWave]), __uint_as_float(q[23*kWave]));
+    p.medium = (int)q[24*kWave];
 }
 
 // ---------------------------------------------------------------------------
@@ -547,33 +548,29 @@ TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slo
 // VGPRs those displace in scratch -- through every bounce: 340 -> 131 v_readlane, scratch 268 -> 216 B in cornell's variant; cornell
 // 4297 -> 4404 Msamples/s at 20 passes, veach 4K 2813 -> 2902, gloss 11 062 -> 11 838, env_loft 5537 -> 5753, a 1 M-path batch 2782 -> 2881
 // (profiles/r04_r_ab_late_kernargs.md; -DTN_LATE_CAMERA=0 -DTN_LATE_SKY=0 -DTN_LATE_STATE=0: the plain arm)
-#ifndef TN_LATE_CAMERA
-#define TN_LATE_CAMERA 1
-#endif
-#ifndef TN_LATE_SKY
-#define TN_LATE_SKY 1
-#endif
-#ifndef TN_LATE_STATE
-#define TN_LATE_STATE 1
-#endif
-#ifndef TN_LATE_FRAME
-#define TN_LATE_FRAME 0             // a lead for the next round (needs TN_LATE_CAMERA): compiles, not yet run on a GPU
-#endif
-// k_bounce's kernel arguments as the launch lays them out (a C struct of the parameters in order): for offsetof
-struct BounceKernargs { DevScene scIn; SplitState ss; QueueCtl q; int bounceBegin, bounceEnd, stackEntries; CameraParams cam; FrameParams fp; const uint32_t* passSeeds; const uint32_t* order; };
-template <bool COUNT, bool LDS, bool DEFER>
-__global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scIn, SplitState ss, QueueCtl q, int bounceBegin, int bounceEnd, int stackEntries, CameraParams cam,
-                                                   FrameParams fp, const uint32_t* __restrict__ passSeeds, const uint32_t* __restrict__ order)
+// k_bounce's kernel arguments: ONE struct, passed by value as the kernel's only parameter -- so the kernel-argument segment IS this struct
+// and the offsetof() of the late reads below cannot drift from what the launch lays out (the struct used to mirror a parameter
+// list by hand).
+struct BounceKernargs { DevScene scIn; SplitState ss; QueueCtl q; int bounceBegin, bounceEnd, stackEntries; CameraParams cam; FrameParams fp; const uint32_t* passSeeds; };
+template <bool COUNT, bool LDS, bool DEFER, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_bounce(BounceKernargs ka)
 {
+    const DevScene& scIn = ka.scIn;
+    const SplitState& ss = ka.ss;
+    const QueueCtl& q = ka.q;
+    const int bounceBegin = ka.bounceBegin, bounceEnd = ka.bounceEnd, stackEntries = ka.stackEntries;
+    const CameraParams& cam = ka.cam;
+    const FrameParams& fp = ka.fp;
+    const uint32_t* __restrict__ const passSeeds = ka.passSeeds;
     extern __shared__ uint32_t s_stack[];      // [stackEntries][kBlock], sized at launch
     LdsStack<kBlock> st = { s_stack + threadIdx.x };
 
     // LDS: [stackEntries][kBlock] stack words, kScanWords, (fp.repack) the waves' shading pools, the staged arena
     const bool repack = fp.repack != 0;
-    uint32_t* const pool = s_stack + stackEntries*kBlock + kScanWords + (threadIdx.x/kWave)*kPoolWordsPerWave;
+    const uint32_t wave = wave_in_block();
+    uint32_t* const pool = s_stack + stackEntries*kBlock + kScanWords + wave*kPoolWordsPerWave;
     SceneT<LDS, false, DEFER ? 1 : 0> sc;
     stage_scene_lds(sc, scIn, s_stack + stackEntries*kBlock + kScanWords + (repack ? kPoolWords : 0));
-#if TN_LATE_STATE
     // the path state's pointers (ten of them and the radiance array: 22 SGPRs that a round needs for a dozen instructions at its start
     // and its end) from the kernel-argument segment where they are used: `ssIn(buf)` what load_state reads of buffer `buf`, `ssOut(buf)`
     // what store_state writes, `radOutNow()` the radiance array of finished paths
@@ -591,11 +588,6 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
     auto radOutNow = [&]() { return state_args()->radOut; };
 #define TN_SS_BUF(buf) ssBuf(buf)
 #define TN_RAD_OUT radOutNow()
-#else
-#define TN_SS_BUF(buf) state_buf(ss, buf)
-#define TN_RAD_OUT ss.radOut
-#endif
-#if TN_LATE_SKY
     // the sky (probe tables, horizon, zenith: 20 words that only a ray that LEFT the scene or a probe sample reads) from the kernel-argument
     // segment where it is needed, like the camera below: on_miss / nee_sample_probe read nothing else of the scene
     auto late_sky = [&]() {
@@ -612,25 +604,19 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         }
         return s;
     };
-#endif
 
     const uint32_t lane = __lane_id();
-    const unsigned long long below = (1ull << lane) - 1ull;
     const bool hasMedia = sc.hasMedia != 0;
     uint32_t rays = 0, shadowRays = 0, samples = 0;
     TraceCounters ctr = { 0, 0, 0 };
     TN_PROF_DECL
 
     // a wave takes a region: bounce 0 generates its camera paths, the others read what the previous bounce packed there
-    // (one workgroup per group of four regions; `order`: the groups with the most live entries first, k_region_order)
+    // (one workgroup per group of four regions, in index order)
     for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
-        // (one launch over all bounces: the dispatcher hands out workgroups in index order and paths die in patches of the image
-        // -- a golden-section step between consecutive workgroups' region groups gives every stretch of the launch the same
-        // mix of long-lived and short-lived regions, as k_walk's work list does)
-        const uint32_t groups = ss.numRegions/kRegionsPerBlock;
-        const uint32_t r0 = (order ? order[b] : (b*fp.groupStep) % groups)*kRegionsPerBlock;      // (both below 2^16: checked by the host)
-        const uint32_t r = r0 + threadIdx.x/kWave;            // the region this wave generates / appends to
+        const uint32_t r0 = b*kRegionsPerBlock;
+        const uint32_t r = r0 + wave;                         // the region this wave generates / appends to
         const uint32_t rLen = region_len(ss, r);           // (the same for the four regions of a group)
         const uint32_t base = region_base(ss, r);
       for (int bounce = bounceBegin; bounce < bounceEnd; ++bounce)
@@ -677,7 +663,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
         RegionAppend out = { base, rLen, 0u, 0u };
 
         uint32_t poolCount = 0;         // wave-uniform: paths that hit a surface and wait for the shading half
-        for (uint32_t j0 = share ? threadIdx.x/kWave*kWave : 0u; ; j0 += share ? kBlock : kWave)
+        for (uint32_t j0 = share ? wave*kWave : 0u; ; j0 += share ? kBlock : kWave)
         {
             // the region's rounds are done: what still waits in the pool is shaded, then the region ends
             const bool flush = j0 >= n;
@@ -699,7 +685,6 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                     if (gen_slot(fp, base + j, slot))
                     {
                         float rx, ry;
-#if TN_LATE_CAMERA
                         // the camera (21 words, read by bounce 0 only) is fetched from the kernel-argument segment HERE, by scalar loads the
                         // compiler may not hoist: as a by-value argument it sat in SGPRs (or their spill lanes) through every bounce
                         typedef const __attribute__((address_space(4))) CameraParams* CamPtr;
@@ -710,27 +695,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                             camNow.r2w[w] = camp->r2w[w];
                         camNow.ox = camp->ox; camNow.oy = camp->oy; camNow.oz = camp->oz;
                         camNow.shutterStart = camp->shutterStart; camNow.shutterEnd = camp->shutterEnd;
-#if TN_LATE_FRAME
-                        // (prepared, unmeasured: the frame parameters and the seed table that only bounce 0 reads, fetched here as well)
-                        typedef const __attribute__((address_space(4))) BounceKernargs* ArgsPtr;
-                        ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-                        asm volatile("" : "+s"(ap));
-                        // (word by word: a struct copy out of the constant address space does not compile in the host pass)
-                        FrameParams fpNow;
-                        {
-                            const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)((const __attribute__((address_space(4))) char*)ap + offsetof(BounceKernargs, fp));
-                            uint32_t* dst = reinterpret_cast<uint32_t*>(&fpNow);
-#pragma unroll
-                            for (int w = 0; w < (int)(sizeof(FrameParams)/4); ++w)
-                                dst[w] = src[w];
-                        }
-                        have = begin_path(camNow, fpNow, ap->passSeeds, slot, p, rx, ry);
-#else
                         have = begin_path(camNow, fp, passSeeds, slot, p, rx, ry);
-#endif
-#else
-                        have = begin_path(cam, fp, passSeeds, slot, p, rx, ry);
-#endif
                         if (!have)
                             TN_RAD_OUT[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         else
@@ -746,7 +711,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
 #pragma unroll
                         for (uint32_t q2 = 1; q2 < kRegionsPerBlock; ++q2)
                             if (j >= gStart[q2]) { k = q2; f = gF[q2]; s0 = gStart[q2]; }
-                        pos = region_pos(base + (k - threadIdx.x/kWave)*rLen, rLen, f, j - s0);     // region r0 + k of this group
+                        pos = region_pos(base + (k - wave)*rLen, rLen, f, j - s0);     // region r0 + k of this group
                     }
                     else
                         pos = region_pos(base, rLen, nFront, j);
@@ -764,11 +729,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                 TN_TICK(1)
                 if (prim < 0)
                 {
-#if TN_LATE_SKY
                     on_miss(late_sky(), p, bounce);
-#else
-                    on_miss(sc, p, bounce);
-#endif
                     TN_RAD_OUT[slot] = make_float4(p.rad.x, p.rad.y, p.rad.z, 0.0f);
                     have = false;
                 }
@@ -782,10 +743,11 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                 if (flush || poolCount + nLive >= (uint32_t)kWave)
                 {
                     const uint32_t take = (poolCount < (uint32_t)kWave - nLive) ? poolCount : (uint32_t)kWave - nLive;
-                    const uint32_t rank = (uint32_t)__popcll(~live & below);
+                    const uint32_t rank = bits_below(~live);
                     if (!have && rank < take)
                     {
                         pool_load(pool, poolCount - 1u - rank, p, slot, prim, t, n3);
+                        p.absorption = medium_absorption(sc, p.medium, hasMedia);
                         have = true;
                     }
                     poolCount -= take;
@@ -793,7 +755,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                 else
                 {
                     if (have)
-                        pool_store(pool, poolCount + (uint32_t)__popcll(live & below), p, slot, prim, t, n3);
+                        pool_store(pool, poolCount + bits_below(live), p, slot, prim, t, n3);
                     poolCount += nLive;
                     have = false;           // waits in the pool
                 }
@@ -818,11 +780,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_BOUNCE) void k_bounce(DevScene scI
                             float skyPdf = 0.0f;
                             int light = -1;
                             if (sc.probe.valid && k == 0)
-#if TN_LATE_SKY
                                 nee_sample_probe(late_sky(), h.p, h.n, p.rng, g, skyColor, skyPdf);
-#else
-                                nee_sample_probe(sc, h.p, h.n, p.rng, g, skyColor, skyPdf);
-#endif
                             else
                             {
                                 light = lights.next(sc);
@@ -941,7 +899,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(SplitState ss, QueueCtl 
 {
     const uint32_t lane = __lane_id();
     uint32_t samples = 0;
-    for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
+    for (uint32_t r = blockIdx.x*(kBlock/kWave) + wave_in_block(); r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
     {
         const uint32_t begin = region_base(ss, r), rLen = region_len(ss, r);
         RegionAppend out = { begin, rLen, 0u, 0u };
@@ -1053,24 +1011,6 @@ TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& b
     }
 }
 
-// the scan kernels' request for a front ray's first two walk records (WalkPre, tn_isect.h), ahead of its trace
-template <class SC>
-TN_D WalkPre walk_prefetch(const SC& sc, uint32_t walkPrims, bool front)
-{
-    WalkPre pre = { make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), 0u };
-    if (TN_WALK_PREFETCH && sc.walkRec != nullptr && front && walkPrims > 0u)
-    {
-        const float4* rp = sc.walkRec + (size_t)sc.walkItem*2;
-        pre.r0 = rp[0];
-        pre.n = 1u;
-        if (walkPrims > 1u)
-        {
-            pre.r1 = rp[2];
-            pre.n = 2u;
-        }
-    }
-    return pre;
-}
 
 // k_extend: closest hit of every live path.  The lean variant (WONLY: every mesh of the scene is walked by k_walk, the
 // kernel is the flat scan + record reads) also draws the light samples, the hit still in registers: there a kernel of its
@@ -1100,19 +1040,11 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_
 
     for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
-        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + wave_in_block();
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
         RegionAppend out = { rBase, rLen, 0u, 0u };
-#if TN_SCAN_PREFETCH
-        float4 nro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nrd = nro;
-        if (lane < n)
-        {
-            const uint32_t p0 = region_pos(rBase, rLen, nFront, lane);
-            nro = ss.rayO[cur][p0]; nrd = ss.rayD[cur][p0];
-        }
-#endif
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
@@ -1120,25 +1052,14 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_
             bool has = false;
             V3 hitP, hitN;
             float time = 0.0f;
-#if TN_SCAN_PREFETCH
-            const float4 ro = nro, rd = nrd;
-            if (j + kWave < n)
-            {
-                const uint32_t pn = region_pos(rBase, rLen, nFront, j + kWave);
-                nro = ss.rayO[cur][pn]; nrd = ss.rayD[cur][pn];
-            }
-#endif
             if (j < n)
             {
-#if !TN_SCAN_PREFETCH
                 const float4 ro = ss.rayO[cur][pos];
                 const float4 rd = ss.rayD[cur][pos];
-#endif
                 sc.walkItem = pos*walkPrims;        // only front rays ever reach a walked primitive
-                const WalkPre pre = walk_prefetch(sc, walkPrims, j < nFront);
 
                 float t;
-                const int prim = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, hitN, ctr, 0.0f, pre);
+                const int prim = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, hitN, ctr);
 
                 ss.hit[pos] = make_float4(t, hitN.x, hitN.y, hitN.z);
                 ss.hitPrim[pos] = prim;
@@ -1178,7 +1099,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
 
     for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
-        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + wave_in_block();
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
@@ -1250,59 +1171,31 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
 
     for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
-        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + wave_in_block();
         const uint32_t nFront = wave_uniform(ss.neeFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.neeBack[(size_t)bounce*ss.numRegions + r]);
         const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
-#if TN_SCAN_PREFETCH
-        float4 na = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nb = na;
-        float ntime = 0.0f;
-        if (lane < n)
-        {
-            const uint32_t q0 = region_pos(rBase, rLen, nFront, lane);
-            na = ss.neeRay[q0]; nb = ss.neeRay[(size_t)ss.capacity + q0]; ntime = ss.neeTime[q0];
-        }
-#endif
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
-#if TN_SCAN_PREFETCH
-            const float4 a0 = na, b0 = nb;
-            const float time0 = ntime;
-            if (j + kWave < n)
-            {
-                const uint32_t q1 = region_pos(rBase, rLen, nFront, j + kWave);
-                na = ss.neeRay[q1]; nb = ss.neeRay[(size_t)ss.capacity + q1]; ntime = ss.neeTime[q1];
-            }
-#endif
             if (j >= n)
                 continue;
             const uint32_t qn = region_pos(rBase, rLen, nFront, j);
-#if TN_SCAN_PREFETCH
-            const float time = time0;
-#else
             const float time = ss.neeTime[qn];
-#endif
 
             for (int k = 0; k < K; ++k)
             {
                 const float4* src = ss.neeRay + (size_t)(k*2)*ss.capacity + qn;
-#if TN_SCAN_PREFETCH
-                float4 a, b;
-                if (k == 0) { a = a0; b = b0; } else { a = src[0]; b = src[ss.capacity]; }
-#else
                 const float4 a = src[0], b = src[ss.capacity];
-#endif
                 NeeGeo ray;
                 ray.o = V3(a.x, a.y, a.z); ray.dist = a.w;
                 ray.wi = V3(b.x, b.y, b.z); ray.nl = b.w;
                 float t;
                 V3 n3;
                 sc.walkItem = (qn*(uint32_t)K + (uint32_t)k)*walkPrims;
-                const WalkPre pre = walk_prefetch(sc, walkPrims, j < nFront);
                 // the walks of a shadow ray stop at an occluder that decides the sample (shadow_stop, tn_isect.h: the scene BVH here,
                 // meshes in HBM in k_walk; many_spheres 1309 -> 1369 Msamples/s, config 3 1923 -> 1959)
-                const int hp = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT, !COUNT>(sc, st, ray.o, ray.wi, time, t, n3, ctr, shadow_stop(ray.dist), pre);
+                const int hp = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT, !COUNT>(sc, st, ray.o, ray.wi, time, t, n3, ctr, shadow_stop(ray.dist));
                 rays++;
                 int arrives;
                 if (ray.dist < 0.0f)
@@ -1325,9 +1218,6 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) voi
 }
 
 // what k_shade reads of a path before it can do anything: its state, its hit, where its shadow rays are
-#ifndef TN_SHADE_PREFETCH
-#define TN_SHADE_PREFETCH 0
-#endif
 struct ShadeFetch
 {
     float4 ro, rd, th, ra, rr, hh;
@@ -1376,14 +1266,9 @@ struct ShadeFetch
 
 // the shading half of one path (shared by the two k_shade kernels): on_hit_begin / on_miss, the BSDF terms of the arriving light
 // samples, the BSDF step; true when the path goes on (its state in `p`, `front`: its next ray enters a mesh in HBM)
-// SHADOW: the shadow rays are traced HERE, between on_hit_begin and the BSDF terms (k_shade's variant that replaces k_shadow: the rays'
-// mesh parts already lie in k_walk's records) -- the same trace<> call on the same ray as k_shadow's, the same acceptance tests
-struct NoStack {};
-struct NoSky {};
-// `sky`: a callable that returns a DevScene with the probe / horizon / zenith fields set (k_shade's late loads), or NoSky: read them from sc
-template <class SC, bool SHADOW = false, class Stack = NoStack, class Sky = NoSky>
+template <class SC>
 TN_D bool shade_path(SC& sc, const SplitState& ss, const ShadeFetch& f, int bounce, int maxDepth, int rrStart, const BinPrims& bp,
-                     PathRegs& p, uint32_t& slot, bool& front, Stack* st = nullptr, uint32_t walkPrims = 0u, uint32_t* shadowRays = nullptr, Sky sky = Sky())
+                     PathRegs& p, uint32_t& slot, bool& front)
 {
     const int K = ss.neePerPath;
     bool alive = false;
@@ -1392,10 +1277,7 @@ TN_D bool shade_path(SC& sc, const SplitState& ss, const ShadeFetch& f, int boun
     const int prim = f.prim;
     if (prim < 0)
     {
-        if constexpr (std::is_same<Sky, NoSky>::value)
-            on_miss(sc, p, bounce);
-        else
-            on_miss(sky(), p, bounce);
+        on_miss(sc, p, bounce);
     }
     else
     {
@@ -1414,29 +1296,7 @@ TN_D bool shade_path(SC& sc, const SplitState& ss, const ShadeFetch& f, int boun
             const float2* res = ss.neeRes + qn;
             const float4* wis = ss.neeRay + (size_t)ss.capacity + qn;       // {wi, nl} of ray k at wis[k*2*capacity]
             V3 sum = nee_sum(sc, [&](int k) -> V3 {
-                float2 rk;
-                if constexpr (SHADOW)
-                {
-                    const float4* src = ss.neeRay + (size_t)(k*2)*ss.capacity + qn;
-                    const float4 a = src[0], b = src[ss.capacity];
-                    NeeGeo ray;
-                    ray.o = V3(a.x, a.y, a.z); ray.dist = a.w;
-                    ray.wi = V3(b.x, b.y, b.z); ray.nl = b.w;
-                    float t;
-                    V3 n3;
-                    TraceCounters ctr = { 0, 0, 0 };
-                    sc.walkItem = (qn*(uint32_t)K + (uint32_t)k)*walkPrims;
-                    const int hit = trace<SC, Stack, false, true>(sc, *st, ray.o, ray.wi, p.time, t, n3, ctr, shadow_stop(ray.dist));
-                    (*shadowRays)++;
-                    int arrives;
-                    if (ray.dist < 0.0f)
-                        arrives = (hit < 0) ? 0 : -1;
-                    else
-                        arrives = nee_light_reached(ray, hit, t) ? hit : -1;
-                    rk = make_float2(__int_as_float(arrives), t);
-                }
-                else
-                    rk = res[(size_t)k*ss.capacity];
+                const float2 rk = res[(size_t)k*ss.capacity];
                 const int hp = __float_as_int(rk.x);
                 if (sc.probe.valid && k == 0)
                 {
@@ -1467,55 +1327,20 @@ TN_D bool shade_path(SC& sc, const SplitState& ss, const ShadeFetch& f, int boun
     return alive;
 }
 
-#ifndef TN_LATE_SHADE
-#define TN_LATE_SHADE 0
-#endif
-// k_shade's kernel arguments as the launch lays them out (for offsetof)
-struct ShadeKernargs { DevScene scIn; SplitState ss; int bounce, maxDepth, rrStart; BinPrims bp; const uint32_t* order; QueueCtl q; int stackEntries; const float4* walkRec; uint32_t walkPrims; };
-// SHADOW (with WONLY as in k_shadow): the variant that traces the shadow rays itself (shade_path) -- LDS laid out like k_shadow's (stacks,
-// kScanWords, arena), k_walk's records and the ray counters as arguments
-template <bool LDS, bool MIXED = false, bool SHADOW = false, bool WONLY = false>
-__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp, const uint32_t* __restrict__ order,
-                                                                 QueueCtl q = QueueCtl{ nullptr }, int stackEntries = 0, const float4* __restrict__ walkRec = nullptr, uint32_t walkPrims = 0u)
+template <bool LDS, bool MIXED = false>
+__global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_arena[];
-    SceneT<LDS, WONLY, 2, MIXED> sc;
-    LdsStack<kBlock> st = { s_arena + threadIdx.x };
-    stage_scene_lds(sc, scIn, SHADOW ? s_arena + stackEntries*kBlock + kScanWords : s_arena);
-    sc.walkRec = walkRec;
-    uint32_t shadowRays = 0;
+    SceneT<LDS, false, 2, MIXED> sc;
+    stage_scene_lds(sc, scIn, s_arena);
     const uint32_t lane = __lane_id();
     const int cur = bounce & 1, nxt = cur ^ 1;
     const int K = ss.neePerPath;
     const bool hasMedia = sc.hasMedia != 0;
-#if TN_LATE_SHADE
-    // like k_bounce (above): the path state's and the hand-over records' pointers, and the sky, from the kernel-argument segment where a
-    // round uses them, not in SGPRs (or their spill lanes) through the whole of it
-    typedef const __attribute__((address_space(4))) SplitState* StatePtr;
-    auto state_args = [&]() {
-        StatePtr sp = (StatePtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ShadeKernargs, ss));
-        asm volatile("" : "+s"(sp));
-        return sp;
-    };
-    auto late_sky = [&]() {
-        typedef const __attribute__((address_space(4))) DevScene* ScenePtr;
-        ScenePtr sp = (ScenePtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ShadeKernargs, scIn));
-        asm volatile("" : "+s"(sp));
-        DevScene s2;
-        s2.probe.data = sp->probe.data; s2.probe.pdfX = sp->probe.pdfX; s2.probe.cdfX = sp->probe.cdfX; s2.probe.pdfY = sp->probe.pdfY; s2.probe.cdfY = sp->probe.cdfY;
-        s2.probe.width = sp->probe.width; s2.probe.height = sp->probe.height; s2.probe.valid = sp->probe.valid; s2.probe.alias = sp->probe.alias;
-        for (int c = 0; c < 3; ++c)
-        {
-            s2.horizon[c] = sp->horizon[c];
-            s2.zenith[c] = sp->zenith[c];
-        }
-        return s2;
-    };
-#endif
 
     for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
-        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + wave_in_block();
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
@@ -1526,69 +1351,25 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade(DevScene scIn,
         // 124 B instead of 196 and runs 3-9 % faster on the 524k-triangle config and many_spheres, +-1 % on glass,
         // profiles/r03_z3_ab_shade_fetch.md; -DTN_SHADE_PREFETCH=1 is the old arm.  Requesting the shadow-ray records a round ahead too, in
         // registers or through LDS with global_load_lds, spills 352-400 B and doubles the kernel's time.)
-#if TN_SHADE_PREFETCH
-        ShadeFetch next;
-        next.issue(ss, cur, region_pos(rBase, rLen, nFront, lane < n ? lane : 0u), lane < n, hasMedia, K > 0, bounce == 0);
-#endif
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
             const uint32_t j = j0 + lane;
-#if TN_SHADE_PREFETCH
-            const ShadeFetch f = next;
-            {
-                const uint32_t jn = j + kWave;
-                next.issue(ss, cur, region_pos(rBase, rLen, nFront, jn < n ? jn : 0u), jn < n, hasMedia, K > 0, bounce == 0);
-            }
-#else
             ShadeFetch f;
-#if TN_LATE_SHADE
-            {
-                StatePtr sp = state_args();
-                const StateBuf sb = { sp->rayO[cur], sp->rayD[cur], sp->thr[cur], sp->rad[cur], sp->rngId[cur] };
-                f.issue(sb, sp->hit, sp->hitPrim, sp->pathNee, region_pos(rBase, rLen, nFront, j < n ? j : 0u), j < n, K > 0, bounce == 0);
-            }
-#else
             f.issue(ss, cur, region_pos(rBase, rLen, nFront, j < n ? j : 0u), j < n, hasMedia, K > 0, bounce == 0);
-#endif
-#endif
             bool alive = false, front = true;
             PathRegs p;
             uint32_t slot = 0;
-#if TN_LATE_SHADE
             if (j < n)
-            {
-                // what shade_path reads of the state: the shadow rays' records and results, the radiance of finished paths
-                StatePtr sp = state_args();
-                SplitState sl;
-                sl.neePerPath = ss.neePerPath; sl.capacity = ss.capacity;
-                sl.neeRes = sp->neeRes; sl.neeRay = sp->neeRay; sl.neeSky = sp->neeSky; sl.radOut = sp->radOut;
-                alive = shade_path<SceneT<LDS, WONLY, 2, MIXED>, SHADOW, LdsStack<kBlock>>(sc, sl, f, bounce, maxDepth, rrStart, bp, p, slot, front, &st, walkPrims, &shadowRays, late_sky);
-            }
-            const uint32_t np = out.push(alive, front);
-            if (alive)
-            {
-                StatePtr sp = state_args();
-                const StateBuf sb = { sp->rayO[nxt], sp->rayD[nxt], sp->thr[nxt], sp->rad[nxt], sp->rngId[nxt] };
-                store_state(sb, np, p, slot);
-            }
-#else
-            if (j < n)
-                alive = shade_path<SceneT<LDS, WONLY, 2, MIXED>, SHADOW, LdsStack<kBlock>>(sc, ss, f, bounce, maxDepth, rrStart, bp, p, slot, front, &st, walkPrims, &shadowRays);
+                alive = shade_path(sc, ss, f, bounce, maxDepth, rrStart, bp, p, slot, front);
             const uint32_t np = out.push(alive, front);
             if (alive)
                 store_state(ss, nxt, np, p, slot);
-#endif
         }
         if (lane == 0)
         {
             ss.segFront[(size_t)(bounce + 1)*ss.numRegions + r] = out.nFront;
             ss.segBack[(size_t)(bounce + 1)*ss.numRegions + r] = out.nBack;
         }
-    }
-    if (SHADOW)
-    {
-        wave_add_stat(q.stats, 0, shadowRays);
-        wave_add_stat(q.stats, 5, shadowRays);
     }
 }
 
@@ -1611,18 +1392,17 @@ template <bool LDS, bool MIXED = false>
 __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade_sorted(DevScene scIn, SplitState ss, int bounce, int maxDepth, int rrStart, BinPrims bp, const uint32_t* __restrict__ order)
 {
     extern __shared__ uint32_t s_arena[];       // the waves' class lists, then the staged arena
-    uint32_t* const list = s_arena + (threadIdx.x/kWave)*kShadeListWordsPerWave;
+    uint32_t* const list = s_arena + wave_in_block()*kShadeListWordsPerWave;
     SceneT<LDS, false, 2, MIXED> sc;
     stage_scene_lds(sc, scIn, s_arena + kShadeListWords);
     const uint32_t lane = __lane_id();
-    const unsigned long long below = (1ull << lane) - 1ull;
     const int cur = bounce & 1, nxt = cur ^ 1;
     const int K = ss.neePerPath;
     const bool hasMedia = sc.hasMedia != 0;
 
     for (uint32_t b = blockIdx.x; b < ss.numRegions/kRegionsPerBlock; b += gridDim.x)
     {
-        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + threadIdx.x/kWave;
+        const uint32_t r = (order ? order[b] : b)*kRegionsPerBlock + wave_in_block();
         const uint32_t nFront = wave_uniform(ss.segFront[(size_t)bounce*ss.numRegions + r]);
         const uint32_t n = nFront + wave_uniform(ss.segBack[(size_t)bounce*ss.numRegions + r]);
         const uint32_t rBase = region_base(ss, r), rLen = region_len(ss, r);
@@ -1679,7 +1459,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade_sorted(DevScen
                 {
                     const unsigned long long m = __ballot(cls == c);
                     if (cls == c)
-                        list[c*kShadeListLen + cnt[c] + (uint32_t)__popcll(m & below)] = at;
+                        list[c*kShadeListLen + cnt[c] + bits_below(m)] = at;
                     cnt[c] += (uint32_t)__popcll(m);
                 }
                 j0 += kWave;
@@ -1732,7 +1512,7 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
     constexpr uint32_t kWaves = kSegBlock/kWave;
     __shared__ uint32_t s_wave[kWaves];
     extern __shared__ uint32_t s_counts[];      // [numRegions]: the counts (and later the prefixes) by region
-    const uint32_t lane = __lane_id(), wave = threadIdx.x/kWave;
+    const uint32_t lane = __lane_id(), wave = wave_in_block();
     // The scan visits the regions `step` apart: read through that permutation the counts would be 2 x numRegions scattered 4-B loads
     // by ONE workgroup (53 us per launch, 616 launches per default bench run: 4 % of glass's frame).  So they are staged into LDS
     // with coalesced loads first (numRegions <= 32768: 128 KB), scanned there, and the prefixes leave coalesced too.
@@ -1797,7 +1577,7 @@ __global__ __launch_bounds__(kSegBlock) void k_seg_prefix(const uint32_t* __rest
 __global__ __launch_bounds__(kBlock) void k_seg_expand(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix, SplitState ss, uint32_t* __restrict__ list)
 {
     const uint32_t lane = __lane_id();
-    for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
+    for (uint32_t r = blockIdx.x*(kBlock/kWave) + wave_in_block(); r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
     {
         const uint32_t n = wave_uniform(counts[r]), at = wave_uniform(prefix[r]), base = region_base(ss, r);
         for (uint32_t i = lane; i < n; i += kWave)

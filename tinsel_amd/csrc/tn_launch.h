@@ -37,11 +37,12 @@ struct LaunchArgs
     SwalkJob swalk;                 // PK_SWALK_*
     int swalkMode;                  // PK_SWALK_*: 0 = 256-thread workgroups, generic pointers; 1 / 2 = 1024-thread workgroups, arena in LDS (2: meshes in HBM too)
     int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
-    int walkMode;                   // PK_WALK: kWalkPairs | kWalkSingle (tn_walk.h)
+    int walkSingle;                 // PK_WALK: ONE walked primitive: the kWalkSingle variant (tn_walk.h)
+    int walkLdsMesh;                // PK_WALK: trees AND triangles staged whole (kWalkLdsTris; 1024-thread workgroups, one per CU)
     int shadeSorted;                // PK_SHADE: k_shade_sorted (paths taken class by class) instead of k_shade
-    int shadowInShade;              // PK_SHADE: the variant that traces the shadow rays itself (no PK_SHADOW launch; staged arena + meshes in HBM)
     int lightsInExtend;             // PK_EXTEND, arena staged + meshes in HBM: the variant that draws the light samples too (A/B)
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
+    int bounceWaves;                // PK_BOUNCE: 3 or 4 waves per SIMD (the 168- / 128-VGPR variant; the host's LDS plan decides: plan_bounce)
     int bounce;
     int bounceEnd;                  // PK_BOUNCE: the launch covers the bounces [bounce, bounceEnd)
     int stackEntries;
@@ -107,26 +108,29 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             else if (lds) hipLaunchKernelGGL((KERNEL<true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order); \
             else hipLaunchKernelGGL((KERNEL<false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order); \
         } while (0)
-        if (a.shadowInShade && mixed && a.walkedOnly)
-            hipLaunchKernelGGL((k_shade<true, true, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order, a.ctl, a.stackEntries, a.walkRec, a.walkPrims);
-        else if (a.shadowInShade && mixed)
-            hipLaunchKernelGGL((k_shade<true, true, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.bins, a.order, a.ctl, a.stackEntries, a.walkRec, a.walkPrims);
-        else if (a.shadeSorted) TN_LAUNCH_SHADE(k_shade_sorted); else TN_LAUNCH_SHADE(k_shade);
+        if (a.shadeSorted) TN_LAUNCH_SHADE(k_shade_sorted); else TN_LAUNCH_SHADE(k_shade);
 #undef TN_LAUNCH_SHADE
         break;
     case PK_BOUNCE:
-#define TN_LAUNCH_BOUNCE(DEFER)                                                                                        \
+#define TN_LAUNCH_BOUNCE(DEFER, WAVES)                                                                                 \
         do {                                                                                                           \
-            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, true, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); \
-                         else hipLaunchKernelGGL((k_bounce<true, false, false>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); } \
-            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, true, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); \
-                         else hipLaunchKernelGGL((k_bounce<false, false, DEFER>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds, a.order); } \
+            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, true, false, 3>), grid, block, a.ldsBytes, st, ka); \
+                         else hipLaunchKernelGGL((k_bounce<true, false, false, 3>), grid, block, a.ldsBytes, st, ka); } \
+            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, true, DEFER, WAVES>), grid, block, a.ldsBytes, st, ka); \
+                         else hipLaunchKernelGGL((k_bounce<false, false, DEFER, WAVES>), grid, block, a.ldsBytes, st, ka); } \
         } while (0)
-        // (the detail-counting variants walk the scene BVH: nothing to defer)
-        if (a.scene.deferMeshes)
-            TN_LAUNCH_BOUNCE(true);
-        else
-            TN_LAUNCH_BOUNCE(false);
+        {
+            const BounceKernargs ka = { a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds };
+            // (the detail-counting variants walk the scene BVH: nothing to defer)
+            if (a.scene.deferMeshes)
+            {
+                if (a.bounceWaves >= 4) TN_LAUNCH_BOUNCE(true, 4); else TN_LAUNCH_BOUNCE(true, 3);
+            }
+            else
+            {
+                if (a.bounceWaves >= 4) TN_LAUNCH_BOUNCE(false, 4); else TN_LAUNCH_BOUNCE(false, 3);
+            }
+        }
 #undef TN_LAUNCH_BOUNCE
         break;
     case PK_SWALK_EXTEND:
@@ -147,13 +151,12 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             else if (a.walkBig) hipLaunchKernelGGL((k_walk<1024, 4, MODE>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk); \
             else hipLaunchKernelGGL((k_walk<256, 5, MODE>), grid, dim3(256), a.ldsBytes, st, a.scene, a.walk);            \
         } while (0)
-        switch (a.walkMode & 3)
+        if (a.walkLdsMesh && a.walkBig == 1)
         {
-        case 0: TN_LAUNCH_WALK(0); break;
-        case 1: TN_LAUNCH_WALK(1); break;
-        case 2: TN_LAUNCH_WALK(2); break;
-        default: TN_LAUNCH_WALK(3); break;
+            if (a.walkSingle) hipLaunchKernelGGL((k_walk<1024, 4, kWalkSingle | kWalkLdsTris>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
+            else hipLaunchKernelGGL((k_walk<1024, 4, kWalkLdsTris>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
         }
+        else if (a.walkSingle) TN_LAUNCH_WALK(kWalkSingle); else TN_LAUNCH_WALK(0);
 #undef TN_LAUNCH_WALK
         break;
     default:
@@ -161,35 +164,49 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
     }
 }
 
-// k_walk (tree tops) and k_bounce (shading pools beside a staged arena) ask for more dynamic LDS than the default launch limit allows
-// Returns the dynamic LDS k_seg_prefix may ask for (one count per region: the host clamps its grids to that).
-inline int prepare_path_kernels(int sharedMemLimit)
+// k_walk (tree tops), k_swalk, k_shade_sorted and k_bounce (shading pools beside a staged arena) ask for more dynamic LDS than the default
+// launch limit allows: every variant's limit is raised ONCE, at create, and every result is checked -- a device that grants less fails there
+// with the kernel's name instead of at some later launch with a generic error.
+struct PrepReport
 {
-    // (k_seg_prefix has static LDS too; a refused attribute leaves the default launch limit of 64 KB)
-    const int segPrefixLds = hipFuncSetAttribute((const void*)k_seg_prefix, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit - 1024) == hipSuccess
-                                 ? sharedMemLimit - 1024 : (sharedMemLimit < 65536 ? sharedMemLimit : 65536) - 1024;
-#define TN_PREP_WALK(MODE) (void)hipFuncSetAttribute((const void*)k_walk<1024, 4, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
-                           (void)hipFuncSetAttribute((const void*)k_walk<1024, 8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
-                           (void)hipFuncSetAttribute((const void*)k_walk<256, 5, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
-    TN_PREP_WALK(0); TN_PREP_WALK(1); TN_PREP_WALK(2); TN_PREP_WALK(3);
-#undef TN_PREP_WALK
-    (void)hipFuncSetAttribute((const void*)k_shade<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
-    (void)hipFuncSetAttribute((const void*)k_shade<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
-    (void)hipFuncSetAttribute((const void*)k_shade_sorted<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
-    (void)hipFuncSetAttribute((const void*)k_shade_sorted<true>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
-    (void)hipFuncSetAttribute((const void*)k_shade_sorted<false>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit);
-#define TN_PREP_SWALK(SH) (void)hipFuncSetAttribute((const void*)k_swalk<SH, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
-                          (void)hipFuncSetAttribute((const void*)k_swalk<SH, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit); \
-                          (void)hipFuncSetAttribute((const void*)k_swalk<SH, 256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
-    TN_PREP_SWALK(false); TN_PREP_SWALK(true);
-#undef TN_PREP_SWALK
-    (void)hipGetLastError();        // a refused attribute must not surface as the next launch's error
-#define TN_PREP_BOUNCE(C, L, D) (void)hipFuncSetAttribute((const void*)k_bounce<C, L, D>, hipFuncAttributeMaxDynamicSharedMemorySize, sharedMemLimit)
-    TN_PREP_BOUNCE(true, true, false); TN_PREP_BOUNCE(true, false, false);
-    TN_PREP_BOUNCE(false, true, false); TN_PREP_BOUNCE(false, false, false); TN_PREP_BOUNCE(false, true, true); TN_PREP_BOUNCE(false, false, true);
-#undef TN_PREP_BOUNCE
-    (void)hipGetLastError();
-    return segPrefixLds;
+    int refused = 0;                // attributes the runtime refused
+    const char* first = nullptr;    // the first kernel it refused
+    int segPrefixLds = 0;           // the dynamic LDS k_seg_prefix may ask for (one count per region: the host clamps its grids to that)
+};
+
+inline void prep_lds(const void* kernel, const char* name, int bytes, PrepReport& rep)
+{
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    {
+        (void)hipGetLastError();        // (a refused attribute must not surface as the next launch's error)
+        if (!rep.first)
+            rep.first = name;
+        ++rep.refused;
+    }
+}
+
+inline PrepReport prepare_path_kernels(int sharedMemLimit)
+{
+    PrepReport rep;
+#define TN_PREP(...) prep_lds((const void*)__VA_ARGS__, #__VA_ARGS__, sharedMemLimit, rep)
+    // (k_seg_prefix has static LDS too)
+    {
+        PrepReport seg;
+        prep_lds((const void*)k_seg_prefix, "k_seg_prefix", sharedMemLimit - 1024, seg);
+        rep.segPrefixLds = seg.refused ? (sharedMemLimit < 65536 ? sharedMemLimit : 65536) - 1024 : sharedMemLimit - 1024;
+        if (seg.refused) { rep.refused += 1; rep.first = rep.first ? rep.first : "k_seg_prefix"; }
+    }
+    TN_PREP(k_walk<1024, 4, 0>); TN_PREP(k_walk<1024, 8, 0>); TN_PREP(k_walk<256, 5, 0>);
+    TN_PREP(k_walk<1024, 4, kWalkLdsTris>); TN_PREP(k_walk<1024, 4, kWalkSingle | kWalkLdsTris>);
+    TN_PREP(k_walk<1024, 4, kWalkSingle>); TN_PREP(k_walk<1024, 8, kWalkSingle>); TN_PREP(k_walk<256, 5, kWalkSingle>);
+    TN_PREP(k_shade_sorted<true, true>); TN_PREP(k_shade_sorted<true>); TN_PREP(k_shade_sorted<false>);
+    TN_PREP(k_swalk<false, 1024, 1>); TN_PREP(k_swalk<false, 1024, 2>); TN_PREP(k_swalk<false, 256, 0>);
+    TN_PREP(k_swalk<true, 1024, 1>); TN_PREP(k_swalk<true, 1024, 2>); TN_PREP(k_swalk<true, 256, 0>);
+    TN_PREP(k_bounce<true, true, false, 3>); TN_PREP(k_bounce<true, false, false, 3>);
+    TN_PREP(k_bounce<false, true, false, 3>); TN_PREP(k_bounce<false, false, false, 3>); TN_PREP(k_bounce<false, true, true, 3>); TN_PREP(k_bounce<false, false, true, 3>);
+    TN_PREP(k_bounce<false, true, false, 4>); TN_PREP(k_bounce<false, false, false, 4>); TN_PREP(k_bounce<false, true, true, 4>); TN_PREP(k_bounce<false, false, true, 4>);
+#undef TN_PREP
+    return rep;
 }
 
 } // namespace tn

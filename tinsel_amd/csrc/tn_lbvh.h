@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_lbvh_emit(const unsigned long long* __r
     o.rminx = br[0]; o.rminy = br[1]; o.rminz = br[2]; o.rmaxx = br[3]; o.rmaxy = br[4]; o.rmaxz = br[5];
     o.left = ch.x >= n - 1 ? (kLeafBit | (uint32_t)keys[ch.x - (n - 1)]) : (uint32_t)ch.x;
     o.right = ch.y >= n - 1 ? (kLeafBit | (uint32_t)keys[ch.y - (n - 1)]) : (uint32_t)ch.y;
-    o.pairKids = 0; o.pad1 = 0;
+    o.pad0 = 0; o.pad1 = 0;
     out[i] = o;
 }
 
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_lbvh_emit_perm(const unsigned long long
     o.rminx = br[0]; o.rminy = br[1]; o.rminz = br[2]; o.rmaxx = br[3]; o.rmaxy = br[4]; o.rmaxz = br[5];
     o.left = ch.x >= n - 1 ? (kLeafBit | (uint32_t)keys[ch.x - (n - 1)]) : (uint32_t)perm[ch.x];
     o.right = ch.y >= n - 1 ? (kLeafBit | (uint32_t)keys[ch.y - (n - 1)]) : (uint32_t)perm[ch.y];
-    o.pairKids = 0; o.pad1 = 0;
+    o.pad0 = 0; o.pad1 = 0;
     out[perm[i]] = o;
 }
 
@@ -414,48 +414,6 @@ __global__ __launch_bounds__(256) void k_refit_pass(Node64* __restrict__ nodes, 
         own[(size_t)k*6 + 3 + q] = fmaxf(b[0][3 + q], b[1][3 + q]);
     }
     gen[k] = pass;
-}
-
-// ---------------------------------------------------------------------------
-// The bottom level of a tree as Pair128 records (tn_scene.h; k_walk reads them): for every internal node over two one-triangle leaves
-// the two triangles' vertices and indices, at the node's own index; and in every node which of its children are such nodes
-// (Node64::pairKids; only that word is written, and nobody reads it here).  k_walk computes a pair's leaf boxes from the vertices, so
-// every such node's STORED boxes are compared with min / max of the vertices here: *mismatches counts the nodes that differ (the host
-// then keeps the plain walk for this tree).  Works on any Node64 tree -- the reference's as converted, a device-built one -- and is run
-// again after a refit.
-__global__ __launch_bounds__(256) void k_build_pairs(Node64* __restrict__ nodes, int numNodes, const Tri48* __restrict__ tris, Pair128* __restrict__ pairs,
-                                                     int* __restrict__ mismatches)
-{
-    const int k = blockIdx.x*256 + threadIdx.x;
-    if (k >= numNodes)
-        return;
-    const Node64 n = nodes[k];
-    auto over_two_leaves = [&](uint32_t ref) -> bool {
-        if (ref & kLeafBit)
-            return false;
-        return (nodes[ref].left & kLeafBit) && (nodes[ref].right & kLeafBit);
-    };
-    nodes[k].pairKids = (over_two_leaves(n.left) ? 1u : 0u) | (over_two_leaves(n.right) ? 2u : 0u);
-    if ((n.left & kLeafBit) && (n.right & kLeafBit))
-    {
-        const Tri48 a = tris[n.left & ~kLeafBit], b = tris[n.right & ~kLeafBit];
-        Pair128 p;
-        p.a0[0] = a.ax; p.a0[1] = a.ay; p.a0[2] = a.az; p.index0 = n.left & ~kLeafBit;
-        p.b0[0] = a.bx; p.b0[1] = a.by; p.b0[2] = a.bz; p.index1 = n.right & ~kLeafBit;
-        p.c0[0] = a.cx; p.c0[1] = a.cy; p.c0[2] = a.cz; p.a1x = b.ax;
-        p.b1[0] = b.bx; p.b1[1] = b.by; p.b1[2] = b.bz; p.a1y = b.ay;
-        p.c1[0] = b.cx; p.c1[1] = b.cy; p.c1[2] = b.cz; p.a1z = b.az;
-        p.box[0] = n.lminx; p.box[1] = n.lminy; p.box[2] = n.lminz; p.box[3] = n.lmaxx; p.box[4] = n.lmaxy; p.box[5] = n.lmaxz;
-        p.box[6] = n.rminx; p.box[7] = n.rminy; p.box[8] = n.rminz; p.box[9] = n.rmaxx; p.box[10] = n.rmaxy; p.box[11] = n.rmaxz;
-        pairs[k] = p;
-        // (== : a zero's sign may differ with the order of the reference's Min / Max; no slab test can tell)
-        const bool same = n.lminx == fminf(fminf(a.ax, a.bx), a.cx) && n.lminy == fminf(fminf(a.ay, a.by), a.cy) && n.lminz == fminf(fminf(a.az, a.bz), a.cz) &&
-                          n.lmaxx == fmaxf(fmaxf(a.ax, a.bx), a.cx) && n.lmaxy == fmaxf(fmaxf(a.ay, a.by), a.cy) && n.lmaxz == fmaxf(fmaxf(a.az, a.bz), a.cz) &&
-                          n.rminx == fminf(fminf(b.ax, b.bx), b.cx) && n.rminy == fminf(fminf(b.ay, b.by), b.cy) && n.rminz == fminf(fminf(b.az, b.bz), b.cz) &&
-                          n.rmaxx == fmaxf(fmaxf(b.ax, b.bx), b.cx) && n.rmaxy == fmaxf(fmaxf(b.ay, b.by), b.cy) && n.rmaxz == fmaxf(fmaxf(b.az, b.bz), b.cz);
-        if (!same)
-            atomicAdd(mismatches, 1);
-    }
 }
 
 } // namespace tn

@@ -281,6 +281,16 @@ TN_D double k64_here(double c)
 #else
 #define K64(c) (c)
 #endif
+// The same for an fp32 constant that a VOP3 instruction needs in a register (select operands: gfx950's VOP3 takes no literal): written plainly,
+// pi, pi/2 and their negatives (m_atan2f), 1e-3f and FLT_MAX are loop invariants that sat in six VGPRs from the first instruction of k_bounce
+// to the last; K32 puts the value in a scalar register at the point of use.
+TN_D float k32_here(float c)
+{
+    unsigned u = __builtin_bit_cast(unsigned, c);
+    asm volatile("" : "+s"(u));
+    return __uint_as_float(u);
+}
+#define K32(c) k32_here(c)
 TN_D void sincos_wide(double x, float& s, float& c)
 {
     const double kd = ::rint(x*K64(0.63661977236758138));            // 2/pi
@@ -490,7 +500,9 @@ TN_D float m_atanf(float x)
 
 TN_D float m_atan2f(float y, float x)
 {
-    const float tiny = 1.0e-30f, pi_o_2 = __uint_as_float(0x3fc90fdbu), pi = __uint_as_float(0x40490fdbu), pi_lo = __uint_as_float(0xb3bbbd2eu);
+    const float tiny = 1.0e-30f, pi_lo = __uint_as_float(0xb3bbbd2eu);
+#define pi_o_2 K32(__uint_as_float(0x3fc90fdbu))
+#define pi K32(__uint_as_float(0x40490fdbu))
     const int hx = __float_as_int(x), hy = __float_as_int(y);
     const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
     if (ix > 0x7f800000 || iy > 0x7f800000)
@@ -525,6 +537,8 @@ TN_D float m_atan2f(float y, float x)
     if (m == 1) return -z;
     if (m == 2) return pi - (z - pi_lo);
     return (z - pi_lo) - pi;
+#undef pi_o_2
+#undef pi
 }
 #elif TN_FAST
 // tolerance arm.  TN_FAST_NATIVE_TRIG=1: v_sin_f32 / v_cos_f32 / v_exp_f32 (absolute error ~1e-6: visibly more paths leave

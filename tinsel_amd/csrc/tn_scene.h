@@ -23,11 +23,6 @@ namespace tn {
 
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kNoNode = 0xffffffffu;
-// k_walk's own refs (tn_walk.h): an INTERNAL node both of whose children are one-triangle leaves -- the bottom level of a tree -- whose
-// boxes and triangles sit in ONE 128-B record (Pair128 below, at the node's own index).  Never stored in a Node64's child refs: the
-// parent's `pairKids` says which of its children are such nodes, so every other walker reads the same records as before.
-constexpr uint32_t kPairBit = 0x40000000u;
-
 struct alignas(64) Node64
 {
     // children L and R of one internal node; boxes exactly as in the reference nodes
@@ -35,29 +30,9 @@ struct alignas(64) Node64
     float lmaxy, lmaxz, rminx, rminy;
     float rminz, rmaxx, rmaxy, rmaxz;
     uint32_t left, right;       // child refs
-    uint32_t pairKids;          // bit 0 / 1: the left / right child is an internal node over two leaves with a Pair128 record (k_build_pairs; else 0)
-    uint32_t pad1;
+    uint32_t pad0, pad1;
 };
 static_assert(sizeof(Node64) == 64, "Node64");
-
-// The bottom level of a mesh tree in one cache line (k_walk): the six vertices and two triangle indices of an internal node over two
-// one-triangle leaves.  The reference fetches node, two children, then per leaf 3 indices + 3 vertices (intersection.h:696-722, 638-644);
-// here ONE request gives a lane all it tests at that node.  The two leaf BOXES are not read: a leaf's box is the min / max of its three
-// vertices (Mesh::RebuildBVH, mesh.cpp:321-328: Bounds::AddPoint of a, b, c; min / max do not round), so the lane computes them -- 12
-// v_min / v_max instead of 48 B and 12 registers -- and k_build_pairs CHECKS that the tree's stored leaf boxes are exactly those
-// (a tree for which they are not keeps the plain walk).  Five 16-B words: [0..2] the LEFT triangle in Tri48's arrangement (a, b, c in
-// .xyz: a lane tests a leaf's Tri48 and a pair's left triangle out of the same registers) with the left and right triangle indices in
-// [0].w, [1].w and the right triangle's a.x in [2].w; [3] = right b, a.y; [4] = right c, a.z; then the stored boxes (never read by k_walk).
-struct alignas(128) Pair128
-{
-    float a0[3]; uint32_t index0;
-    float b0[3]; uint32_t index1;
-    float c0[3]; float a1x;
-    float b1[3]; float a1y;
-    float c1[3]; float a1z;
-    float box[12];
-};
-static_assert(sizeof(Pair128) == 128, "Pair128");
 
 struct alignas(16) Tri48
 {
@@ -147,9 +122,8 @@ struct DevMesh
     uint32_t offNodes, offTris, offNormals, offCdf;     // byte offsets inside the arena (inArena only)
     int32_t topCount;           // nodes [0, topCount) are the top of the tree in breadth-first order (k_walk stages a prefix into LDS)
     int32_t twoLeaves;          // 1: the tree is one internal node over two one-triangle leaves (a quad): ray_mesh_two_leaves
-    const Pair128* pairs;       // [numInternal], valid at the indices of nodes over two leaves (meshes in HBM; null: none built)
     int32_t numInternal;        // Node64 records of this tree
-    int32_t pairsExact;         // 1: every node over two leaves stores exactly the min / max of its leaves' vertices (k_build_pairs checked): k_walk may use `pairs`
+    int32_t pad0;
 };
 
 struct DevProbe

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_expand_all(const uint32_t* __res
                                                            SplitState ss, uint32_t* __restrict__ list)
 {
     const uint32_t lane = __lane_id();
-    for (uint32_t r = blockIdx.x*(kBlock/kWave) + threadIdx.x/kWave; r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
+    for (uint32_t r = blockIdx.x*(kBlock/kWave) + wave_in_block(); r < ss.numRegions; r += gridDim.x*(kBlock/kWave))
     {
         const uint32_t nF = wave_uniform(front[r]), n = nF + wave_uniform(back[r]), at = wave_uniform(prefix[r]);
         const uint32_t base = region_base(ss, r), len = region_len(ss, r);

@@ -58,6 +58,7 @@ struct WalkJob
     int numPrims;                   // walked primitives (1..7)
     int prim[kWalkMaxPrims];
     int topCount[kWalkMaxPrims];    // Node64 records of each walked primitive's tree staged into LDS (a prefix: breadth-first order)
+    int triCount[kWalkMaxPrims];    // kWalkLdsTris: triangles of each walked primitive's mesh staged into LDS behind the tree tops (all of them)
     int stackEntries;               // LDS stack entries per lane (the deepest walked tree's need, or fewer: see overflow)
     uint32_t* overflow;             // [lane of the grid][overflowEntries]: stack entries beyond the LDS ones (null: the LDS stack holds the deepest tree)
     int overflowEntries;
@@ -99,24 +100,21 @@ TN_D Node64 load_node_from(Ptr nodes, uint32_t idx)
     n.rminz = c.x; n.rmaxx = c.y; n.rmaxy = c.z; n.rmaxz = c.w;
     n.left = __float_as_uint(d.x);
     n.right = __float_as_uint(d.y);
-    n.pairKids = __float_as_uint(d.z);
     return n;
 }
 
-// Walk modes (template parameter MODE of k_walk; launch_walk picks one, TINSEL_HIP_WALK_PAIRS / TINSEL_HIP_WALK_SINGLE):
-//   kWalkPairs   THE BOTTOM LEVEL IN ONE RECORD (opt-in: measured neutral, profiles/r04_c_ab_walk_pairs3.md).  A node over two one-triangle
-//                leaves is not visited as a node: its parent hands the lane a pair ref (kPairBit | node index, from Node64::pairKids), the
-//                lane waits for the triangle phase like a lane at a leaf, and there ONE request -- the five 16-B words of a Pair128 --
-//                gives it both triangles; the two leaf boxes are the min / max of their vertices (tn_scene.h).  Box tests (`tChild <
-//                tmax` against the closest hit so far, intersection.h:696-705), both triangle tests, and the outcome of the sequence
-//                the reference's stack produces for that node (push far, push near, pop near, pop far: :706-722 -- the far leaf is NOT
-//                culled again after the near one's hit, and a strict `t < closestT` keeps the first of two equal hits).
-//                (Its first version fetched boxes, then the near triangle, then the far one inside the phase: 15.3 ms against 11.1 on the
-//                524k-triangle config; "draining" a second leaf in the same phase: 11.1 -> 11.8.  A phase must hold ONE memory round trip.)
-//   kWalkSingle  ONE walked primitive (the host knows): tree, triangles, pair records and the staged top are the same for every lane --
-//                kernel-argument scalars instead of five per-lane registers (what lets kWalkPairs run at 64 VGPRs).
-constexpr int kWalkPairs = 1;
+// Walk mode (template parameter MODE of k_walk; launch_walk picks it):
+//   kWalkSingle  ONE walked primitive (the host knows): tree, triangles and the staged top are the same for every lane -- kernel-argument
+//                scalars instead of five per-lane registers.
+// (Round 4's kWalkPairs -- a node over two one-triangle leaves fetched as ONE 128-B record in the triangle phase -- was built in three
+// versions, bit-identical, and never paid: 10.8-10.9 ms without, 10.96-11.02 with on the 524k-triangle config, glass 6.5 -> 8.8 ms;
+// profiles/r04_a..c_ab_walk_pairs*.md have the numbers, `git log -- tinsel_amd/csrc/tn_walk.h` the code.)
+//   kWalkLdsTris THE WHOLE MESH IN LDS (small meshes: every walked tree AND its triangles' vertices -- 36 B each -- fit beside the stacks of ONE
+//                1024-thread workgroup per CU; glass.tin's 1280-triangle sphere + cube: 126 KB).  No walk step touches memory: node visits are
+//                ds_read_b128, triangle tests read nine floats, only the refill (queue -> ray) and the finished record go to HBM.  The host
+//                chooses it when it fits (launch_walk); otherwise the tree top is staged and the rest comes through L2 as before.
 constexpr int kWalkSingle = 2;
+constexpr int kWalkLdsTris = 4;
 
 // The closest hit's normal for its record: n*sign with n = Cross(b - a, c - a) as IntersectRayTriTwoSided forms it (intersection.h:122-124),
 // computed again from the triangle where the record is written -- the lane's next refill, whose chain of dependent loads hides the
@@ -129,6 +127,13 @@ TN_D V3 hit_normal(GlobalF4 tris, int tri, float sign)
     return cross(b - a, c - a)*sign;
 }
 
+TN_D V3 hit_normal_lds(const float* tris, int tri, float sign)
+{
+    const float* t = tris + (size_t)tri*9;
+    const V3 a(t[0], t[1], t[2]), b(t[3], t[4], t[5]), c(t[6], t[7], t[8]);
+    return cross(b - a, c - a)*sign;
+}
+
 // LDS of one workgroup: [stackEntries][BLOCK] stack words, [kWalkLaneRows][BLOCK] per-lane words that are touched once or twice per
 // RAY and have no business in a register of a 64-VGPR kernel (row 0: the ray's record index, row 1: a shadow ray's stop distance),
 // then 16 control words, then the staged tree tops.
@@ -138,8 +143,8 @@ constexpr int kWalkLaneRows = 2;
 template <int BLOCK, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 {
-    constexpr bool PAIRS = (MODE & kWalkPairs) != 0, SINGLE = (MODE & kWalkSingle) != 0;
-    constexpr uint32_t kAtLeaf = PAIRS ? (kLeafBit | kPairBit) : kLeafBit;      // refs that wait for the triangle phase
+    constexpr bool SINGLE = (MODE & kWalkSingle) != 0, LDSTRIS = (MODE & kWalkLdsTris) != 0;
+    constexpr uint32_t kAtLeaf = kLeafBit;      // refs that wait for the triangle phase
     extern __shared__ __attribute__((aligned(16))) uint32_t s_walk[];
     uint32_t* const stack = s_walk + threadIdx.x;               // this lane's column: entry i at stack[i*BLOCK]
     // a SHORT LDS stack leaves room for a second workgroup per CU (8 waves per SIMD at 64 VGPRs): the rare entries beyond it
@@ -192,6 +197,28 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                 base += (uint32_t)n;
             }
         }
+        if (LDSTRIS)
+        {
+            // every walked mesh's triangles behind the tops: the three vertices of a Tri48 as nine floats
+            float* dst = reinterpret_cast<float*>(s_top + (size_t)base*4);
+#pragma unroll 1
+            for (int kb = 0; kb < job.numPrims; ++kb)
+            {
+                int primIndex = job.prim[0], n = job.triCount[0];
+#pragma unroll
+                for (int q = 1; q < kWalkMaxPrims; ++q)
+                    if (q == kb) { primIndex = job.prim[q]; n = job.triCount[q]; }
+                const Prim64 p = load_prim(sc.prims, primIndex);
+                GlobalF4 src = as_global(sc.meshes[p.mesh].tris);
+                for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += BLOCK)
+                {
+                    const WalkF4 a = src[(size_t)i*3], b = src[(size_t)i*3 + 1], c = src[(size_t)i*3 + 2];
+                    float* d9 = dst + (size_t)i*9;
+                    d9[0] = a.x; d9[1] = a.y; d9[2] = a.z; d9[3] = b.x; d9[4] = b.y; d9[5] = b.z; d9[6] = c.x; d9[7] = c.y; d9[8] = c.z;
+                }
+                dst += (size_t)n*9;
+            }
+        }
     }
     __syncthreads();
 
@@ -207,9 +234,17 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     }
     const DevMesh* mesh0p = sc.meshes + prim0.mesh;
     GlobalF4 mesh0nodes = as_global(mesh0p->nodes), mesh0tris = as_global(mesh0p->tris);
-    GlobalF4 mesh0pairs = PAIRS ? as_global(mesh0p->pairs) : nullptr;
     const uint32_t mesh0root = mesh0p->root;
     const uint32_t top0N = (uint32_t)job.topCount[0];
+    // (kWalkLdsTris) the staged triangles start behind ALL the staged tops
+    uint32_t topsAll = 0;
+    if (LDSTRIS)
+    {
+#pragma unroll
+        for (int q = 0; q < kWalkMaxPrims; ++q)
+            topsAll += (uint32_t)job.topCount[q];
+    }
+    const float* const s_tris = reinterpret_cast<const float*>(s_top + (size_t)topsAll*4);
 
     // per-lane walk state
     // (no flags: a lane is ACTIVE iff ref != kNoNode; a finished ray's record is PENDING in its registers iff *s_item != kNoItem)
@@ -224,8 +259,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     float hsign = 0.0f;                 // the hit's `sign` (IntersectRayTriTwoSided's d): its normal n*sign is formed where the record is written
     GlobalF4 mnodes = nullptr;
     GlobalF4 mtris = nullptr;
-    GlobalF4 mpairs = nullptr;
     uint32_t topBase = 0, topN = 0;     // this lane's tree: refs < topN are staged at s_top[(topBase + ref)*4 ..]
+    uint32_t triBase = 0;               // (kWalkLdsTris, several primitives) this lane's mesh: its triangles start at s_tris[triBase*9]
     bool finiteAll = true;              // wave-uniform: every active lane's 1/d is finite
     bool exhausted = bbeg >= end;       // wave-uniform: the workgroup's range has been handed out
     TN_WP_DECL
@@ -259,7 +294,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     out[0] = make_float4(closestT, 1.0f - hv - hw, hv, hw);
                     if (closestT < kFltMax)
                     {
-                        const V3 hn = hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
+                        const V3 hn = LDSTRIS ? hit_normal_lds(s_tris + (size_t)(SINGLE ? 0u : triBase)*9, htri, hsign) : hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
                         out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
                     }
                     *s_item = kNoItem;
@@ -293,6 +328,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 
                     int index = job.prim[0];
                     uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
+                    uint32_t trb = 0, trun = (uint32_t)job.triCount[0];
                     if (!SINGLE)
                     {
 #pragma unroll
@@ -303,8 +339,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                                 index = job.prim[q];
                                 tb = run;
                                 tn = (uint32_t)job.topCount[q];
+                                trb = trun;
                             }
                             run += (uint32_t)job.topCount[q];
+                            trun += (uint32_t)job.triCount[q];
                         }
                     }
 
@@ -339,7 +377,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         {
                             mnodes = mesh0nodes;
                             mtris = mesh0tris;
-                            if (PAIRS) mpairs = mesh0pairs;
                             ref = mesh0root;
                         }
                         else
@@ -347,13 +384,14 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                             const DevMesh* m = sc.meshes + p.mesh;
                             mnodes = as_global(m->nodes);
                             mtris = as_global(m->tris);
-                            if (PAIRS) mpairs = as_global(m->pairs);
                             ref = m->root;
                         }
                         if (!SINGLE)
                         {
                             topBase = tb;
                             topN = tn;
+                            if (LDSTRIS)
+                                triBase = trb;
                         }
                         sp = 0;
                         closestT = kFltMax;
@@ -404,9 +442,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
             }
             hL = hL && tL < closestT;       // `tLeft < tmax`, tmax == closestT after every leaf (intersection.h:701-702)
             hR = hR && tR < closestT;
-            // (kWalkPairs) a child that is a node over two leaves travels as a pair ref
-            const uint32_t refL = PAIRS ? (nd.left | ((nd.pairKids & 1u) << 30)) : nd.left;
-            const uint32_t refR = PAIRS ? (nd.right | ((nd.pairKids & 2u) << 29)) : nd.right;
+            const uint32_t refL = nd.left, refR = nd.right;
 
             if (hL && hR)
             {
@@ -438,89 +474,32 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
             TN_WP_COUNT(10, __popcll(leafMask))
             if (atLeaf)
             {
-                // ONE round trip per phase (a second dependent fetch inside a phase costs every lane of the wave another ~3000 cycles:
-                // the first version of the pair record fetched boxes, then the near triangle, then the far one, and its triangle phases
-                // took 15,200 cycles against 3,300): every lane requests ALL it will test before anybody waits -- a leaf its Tri48
-                // into q3..q5, a pair the five words of its Pair128, whose left triangle sits in the first three in the Tri48 arrangement.
-                const bool isPair = PAIRS && (ref & kPairBit) != 0u;
-                const uint32_t idx = ref & ~(kLeafBit | kPairBit);
-                GlobalF4 tp = (SINGLE ? mesh0tris : mtris) + (size_t)idx*3;
-                if (isPair)
-                    tp = (SINGLE ? mesh0pairs : mpairs) + (size_t)idx*8;
-                const WalkF4 q3 = tp[0], q4 = tp[1], q5 = tp[2];
-                WalkF4 q6 = { 0.0f, 0.0f, 0.0f, 0.0f }, q7 = q6;
-                if (isPair)
+                // ONE round trip per phase: every lane requests its leaf's Tri48 before anybody waits
+                const uint32_t idx = ref & ~kLeafBit;
+                WalkF4 q3, q4, q5;
+                if (LDSTRIS)
                 {
-                    q6 = tp[3]; q7 = tp[4];
+                    const float* t9 = s_tris + ((size_t)(SINGLE ? 0u : triBase) + idx)*9;
+                    q3 = WalkF4{ t9[0], t9[1], t9[2], 0.0f }; q4 = WalkF4{ t9[3], t9[4], t9[5], 0.0f }; q5 = WalkF4{ t9[6], t9[7], t9[8], 0.0f };
                 }
-
-                // a pair's two box tests, as the node phase would have made them at that node (`tChild < tmax`, intersection.h:696-705); the
-                // leaf boxes are the min / max of the leaves' vertices (tn_scene.h Pair128: checked against the stored ones at upload)
-                bool hL = true, hR = false, leftFirst = true;
-                if (isPair)
+                else
                 {
-                    // (one box after the other, each behind its own branch on finiteAll: written as one if / else over both, the twelve
-                    // (bound - origin)*rcp products common to the two arms are hoisted above it and live at once -- 12 more registers)
-                    auto slab = [&](float minx, float miny, float minz, float maxx, float maxy, float maxz, float& t) -> bool {
-                        if (finiteAll)
-                            return ray_aabb_minmax(o, rcp, minx, miny, minz, maxx, maxy, maxz, t);
-                        t = 0.0f;
-                        return ray_aabb(o, rcp, minx, miny, minz, maxx, maxy, maxz, t);
-                    };
-                    float tL, tR;
-                    hL = slab(fminf(fminf(q3.x, q4.x), q5.x), fminf(fminf(q3.y, q4.y), q5.y), fminf(fminf(q3.z, q4.z), q5.z),
-                              fmaxf(fmaxf(q3.x, q4.x), q5.x), fmaxf(fmaxf(q3.y, q4.y), q5.y), fmaxf(fmaxf(q3.z, q4.z), q5.z), tL);
-                    hL = hL && tL < closestT;
-                    __builtin_amdgcn_sched_barrier(0);
-                    hR = slab(fminf(fminf(q5.w, q6.x), q7.x), fminf(fminf(q6.w, q6.y), q7.y), fminf(fminf(q7.w, q6.z), q7.z),
-                              fmaxf(fmaxf(q5.w, q6.x), q7.x), fmaxf(fmaxf(q6.w, q6.y), q7.y), fmaxf(fmaxf(q7.w, q6.z), q7.z), tR);
-                    hR = hR && tR < closestT;
-                    leftFirst = hL && (!hR || tL < tR);      // the child the stack would pop first (both hit: the left one iff tL < tR)
+                    GlobalF4 tp = (SINGLE ? mesh0tris : mtris) + (size_t)idx*3;
+                    q3 = tp[0]; q4 = tp[1]; q5 = tp[2];
                 }
-
-                // The triangle tests.  A leaf: its own triangle.  A pair: the reference's stack pops the nearer box's triangle first, then the
-                // other's; each is accepted iff 0 < t < closestT -- strict, so of two equal hits the FIRST stays -- and the second is NOT
-                // culled again by the first one's hit (intersection.h:706-722): both are tested against the closest hit BEFORE the pair
-                // (t0), and the outcome is the smaller t, a tie going to whichever the stack would have popped first.  Here the left
-                // triangle is always tested first and the right one replaces it under exactly that rule; a shadow ray that its first
-                // triangle decides (t < tStop) never sees the second.
-                const float t0 = closestT;
-                bool validA = false, any = false;
-                if (hL)
+                bool any = false;
                 {
                     float t, u, v, w, sign;
                     V3 n;
                     if (ray_tri(o, d, V3(q3.x, q3.y, q3.z), V3(q4.x, q4.y, q4.z), V3(q5.x, q5.y, q5.z), t, u, v, w, sign, n))
                     {
-                        if (t > 0.0f && t < t0)
+                        if (t > 0.0f && t < closestT)
                         {
-                            validA = any = true;
+                            any = true;
                             closestT = t;
                             hv = v; hw = w;
-                            htri = isPair ? __float_as_int(q3.w) : (int)idx;
+                            htri = (int)idx;
                             hsign = sign;
-                        }
-                    }
-                }
-                if (PAIRS && hR)
-                {
-                    float t, u, v, w, sign;
-                    V3 n;
-                    if (ray_tri(o, d, V3(q5.w, q6.w, q7.w), V3(q6.x, q6.y, q6.z), V3(q7.x, q7.y, q7.z), t, u, v, w, sign, n))
-                    {
-                        if (t > 0.0f && t < t0)
-                        {
-                            // (closestT is the left triangle's t when validA)
-                            const float tStop = *s_stop;
-                            const bool take = !validA || (leftFirst ? (t < closestT && !(closestT < tStop)) : (!(closestT < t) || t < tStop));
-                            if (take)
-                            {
-                                any = true;
-                                closestT = t;
-                                hv = v; hw = w;
-                                htri = __float_as_int(q4.w);
-                                hsign = sign;
-                            }
                         }
                     }
                 }
@@ -552,7 +531,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
         out[0] = make_float4(closestT, 1.0f - hv - hw, hv, hw);
         if (closestT < kFltMax)
         {
-            const V3 hn = hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
+            const V3 hn = LDSTRIS ? hit_normal_lds(s_tris + (size_t)(SINGLE ? 0u : triBase)*9, htri, hsign) : hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
             out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
         }
     }

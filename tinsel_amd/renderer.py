@@ -121,7 +121,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_create", "tinsel_hip_destroy", "tinsel_hip_init", "tinsel_hip_init_external", "tinsel_hip_render",
     "tinsel_hip_render_async", "tinsel_hip_accum_device_ptr", "tinsel_hip_read_accum", "tinsel_hip_set_shard",
     "tinsel_hip_set_pipeline", "tinsel_hip_set_pass_index", "tinsel_hip_get_pass_index", "tinsel_hip_stats",
-    "tinsel_hip_reset_stats", "tinsel_hip_stats_detail", "tinsel_hip_set_detail_counters", "tinsel_hip_kernel_times",
+    "tinsel_hip_reset_stats", "tinsel_hip_stats_detail", "tinsel_hip_set_detail_counters", "tinsel_hip_kernel_times", "tinsel_hip_kernel_time_bytes",
     "tinsel_hip_enable_kernel_timing", "tinsel_hip_set_batch_paths", "tinsel_hip_stack_entries",
     "tinsel_hip_nee_per_path", "tinsel_hip_last_error", "tinsel_pack_open", "tinsel_hip_read_batch_radiance", "tinsel_hip_leaf",
     "tinsel_hip_write_accum", "tinsel_hip_reserve", "tinsel_hip_set_russian_roulette", "tinsel_hip_set_mesh_bvh", "tinsel_hip_present", "tinsel_hip_present_async", "tinsel_hip_present_device_ptr", "tinsel_image_quantize_rgb8",
@@ -312,12 +312,15 @@ class HipRenderer:
         _check(self._L.tinsel_hip_enable_kernel_timing(self._h, int(on)), "tinsel_hip_enable_kernel_timing")
 
     def kernel_times(self):
-        arr = (abi.KernelTime * 16)()
-        n = self._L.tinsel_hip_kernel_times(self._h, arr, 16)
+        """{kernel: (launches, sum of their durations in ms, union of their intervals in ms)}; the union is smaller than the sum where a
+        call's chunks overlap on two streams.  A library from before round 4 (TINSEL_HIP_LIB: A/B against an older build) writes 36-byte
+        records without the union: it says so by not exporting tinsel_hip_kernel_time_bytes, and the union is reported as the sum."""
+        old = not hasattr(self._L, "tinsel_hip_kernel_time_bytes") or self._L.tinsel_hip_kernel_time_bytes() != C.sizeof(abi.KernelTime)
+        arr = ((abi.KernelTimeV1 if old else abi.KernelTime) * 16)()
+        n = self._L.tinsel_hip_kernel_times(self._h, C.cast(arr, C.POINTER(abi.KernelTime)), 16)
         if n < 0:
             _check(n, "tinsel_hip_kernel_times")
-        # (launches, sum of their durations, union of their intervals: smaller where a call's chunks overlap on two streams)
-        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms, arr[i].busy_ms) for i in range(n)}
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms, arr[i].total_ms if old else arr[i].busy_ms) for i in range(n)}
 
     def stats(self):
         names = ["rays", "samples", "internal_visits", "tri_tests", "prim_tests", "shadow_rays", "_6", "_7"]
