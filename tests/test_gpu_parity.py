@@ -320,13 +320,13 @@ def test_every_shard_is_bit_identical_to_the_oracle_shard(pipeline, world, tile,
     assert total == 2*opt.width*opt.height
 
 
-@pytest.mark.parametrize("share,waves", [("0", "3"), ("1", "4"), ("0", "4"), ("1", "3")])
+@pytest.mark.parametrize("share,repack", [("0", "0"), ("1", "1"), ("0", "1"), ("1", "0")])
 @pytest.mark.parametrize("name", ["cornell", "veach", "features", "gloss"])
-def test_small_frame_switches_change_no_bit(name, share, waves, monkeypatch):
+def test_small_frame_switches_change_no_bit(name, share, repack, monkeypatch):
     """Two choices the library makes per batch / scene -- k_bounce's waves dealing their workgroup's regions as one stream
-    (TINSEL_HIP_BOUNCE_SHARE) and its three- or four-wave variant (TINSEL_HIP_BOUNCE_WAVES: plan_bounce) -- forced both ways."""
+    (TINSEL_HIP_BOUNCE_SHARE) and closing ranks through the shading pools (TINSEL_HIP_REPACK: plan_bounce) -- forced both ways."""
     monkeypatch.setenv("TINSEL_HIP_BOUNCE_SHARE", share)
-    monkeypatch.setenv("TINSEL_HIP_BOUNCE_WAVES", waves)
+    monkeypatch.setenv("TINSEL_HIP_REPACK", repack)
     scene, cam, opt, g = _load(name)
     passes = int(g["passes"])
     from tinsel_amd import create_gpu_renderer

@@ -15,11 +15,10 @@ SETTINGS = [
     {},                                                     # the defaults, through the same child
     {"TINSEL_HIP_BATCH_PATHS": "65536"},                    # several batches per call
     {"TINSEL_HIP_GRID_MULT": "2"},
-    # k_bounce: its workgroup's regions as one stream or not, the shading pools, three / four waves per SIMD (the host picks per scene: plan_bounce)
+    # k_bounce: its workgroup's regions as one stream or not, the shading pools (the host picks per scene and batch)
     {"TINSEL_HIP_BOUNCE_SHARE": "0"}, {"TINSEL_HIP_BOUNCE_SHARE": "1"},
     {"TINSEL_HIP_REPACK": "0"}, {"TINSEL_HIP_REPACK": "1"}, {"TINSEL_HIP_REPACK": "1", "TINSEL_HIP_BOUNCE_SHARE": "1"},
-    {"TINSEL_HIP_BOUNCE_WAVES": "3"}, {"TINSEL_HIP_BOUNCE_WAVES": "4"}, {"TINSEL_HIP_BOUNCE_WAVES": "4", "TINSEL_HIP_REPACK": "1", "TINSEL_HIP_BOUNCE_SHARE": "1"},
-    {"TINSEL_HIP_BOUNCE_WAVES": "4", "TINSEL_HIP_REPACK": "0", "TINSEL_HIP_BATCH_PATHS": "65536"},
+    {"TINSEL_HIP_REPACK": "0", "TINSEL_HIP_BATCH_PATHS": "65536"},
     {"TINSEL_HIP_SHADE_SORTED": "1"}, {"TINSEL_HIP_SHADE_SORTED": "0"},
     {"TINSEL_HIP_NO_SCENE_WALK": "1"}, {"TINSEL_HIP_SWALK_NO_LDS": "1"},
     {"TINSEL_HIP_NO_LDS_SCENE": "1"}, {"TINSEL_HIP_ARENA_LDS_LIMIT": "1024"},

@@ -28,11 +28,14 @@ namespace tn {
 #ifndef TN_WAVES_FUSED
 #define TN_WAVES_FUSED 2
 #endif
-// k_bounce: its waves per SIMD are a template parameter (3: 168 VGPRs, no scratch; 4: 128 VGPRs, loop invariants spilled in the prologue) that
-// the host picks per scene from the LDS a workgroup needs (plan_bounce, tinsel_hip.hip).  History: the parity arm's k_bounce needed ~250 registers
-// until the SLP vectoriser went (tinsel_amd/build.py); the third wave then paid several times over -- the kernel waits on dependent fp32 / fp64
-// chains, not on issue slots: cornell 2989 -> 3805 Msamples/s, veach 1961 -> 2575 -- and since round 4 took the libm coefficients, a dead double
-// atan2 and the late-read kernel arguments out of its registers the fourth does too where four workgroups fit a CU (cornell 4503 -> 4989).
+// k_bounce: FOUR waves per SIMD (128 VGPRs; 4-9 registers of loop invariants spilled in the prologue).  History: the parity arm's kernel needed
+// ~250 registers until the SLP vectoriser went (tinsel_amd/build.py); the third wave then paid several times over -- the kernel waits on
+// dependent fp32 / fp64 chains, not on issue slots: cornell 2989 -> 3805 Msamples/s -- and so does the fourth since round 5 put the kernel's
+// wave-uniform bookkeeping (region index, base, length, pool pointer: what hangs off threadIdx.x/64) into scalar registers and took slot_pixel's
+// reciprocals from the host: 162 -> 134 VGPRs at three waves, and at four cornell 4455 -> 5267, veach 4K 2923 -> 3489, gloss 11 708 -> 13 115,
+// env_loft 5016 -> 5912, cfg1 2930 -> 3236, features 1025 -> 1070 -- where only three workgroups' LDS fit a CU too
+// (profiles/r05_a_ab_waves4.md, r05_b_ab_bounce_waves.md).
+constexpr int kBounceWaves = 4;
 // k_shade: four since the end of round 4 -- with the libm coefficients out of its registers (K64, tn_math.h) the staged-arena variant needs
 // 133 VGPRs and fits 128 without a byte of scratch (glass k_shade 8.9-9.1 -> 8.7-8.9 ms, motionblur 6.3 -> 5.4, many_spheres +1.7 %:
 // profiles/r04_v_ab_k64.md; at three waves it had been 168 VGPRs + 108 B)
@@ -552,8 +555,8 @@ TN_D void pool_load(const uint32_t* pool, uint32_t e, PathRegs& p, uint32_t& slo
 // and the offsetof() of the late reads below cannot drift from what the launch lays out (the struct used to mirror a parameter
 // list by hand).
 struct BounceKernargs { DevScene scIn; SplitState ss; QueueCtl q; int bounceBegin, bounceEnd, stackEntries; CameraParams cam; FrameParams fp; const uint32_t* passSeeds; };
-template <bool COUNT, bool LDS, bool DEFER, int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void k_bounce(BounceKernargs ka)
+template <bool COUNT, bool LDS, bool DEFER>
+__global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(BounceKernargs ka)
 {
     const DevScene& scIn = ka.scIn;
     const SplitState& ss = ka.ss;

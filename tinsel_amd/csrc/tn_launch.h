@@ -42,7 +42,6 @@ struct LaunchArgs
     int shadeSorted;                // PK_SHADE: k_shade_sorted (paths taken class by class) instead of k_shade
     int lightsInExtend;             // PK_EXTEND, arena staged + meshes in HBM: the variant that draws the light samples too (A/B)
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
-    int bounceWaves;                // PK_BOUNCE: 3 or 4 waves per SIMD (the 168- / 128-VGPR variant; the host's LDS plan decides: plan_bounce)
     int bounce;
     int bounceEnd;                  // PK_BOUNCE: the launch covers the bounces [bounce, bounceEnd)
     int stackEntries;
@@ -112,24 +111,20 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
 #undef TN_LAUNCH_SHADE
         break;
     case PK_BOUNCE:
-#define TN_LAUNCH_BOUNCE(DEFER, WAVES)                                                                                 \
+#define TN_LAUNCH_BOUNCE(DEFER)                                                                                        \
         do {                                                                                                           \
-            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, true, false, 3>), grid, block, a.ldsBytes, st, ka); \
-                         else hipLaunchKernelGGL((k_bounce<true, false, false, 3>), grid, block, a.ldsBytes, st, ka); } \
-            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, true, DEFER, WAVES>), grid, block, a.ldsBytes, st, ka); \
-                         else hipLaunchKernelGGL((k_bounce<false, false, DEFER, WAVES>), grid, block, a.ldsBytes, st, ka); } \
+            if (count) { if (lds) hipLaunchKernelGGL((k_bounce<true, true, false>), grid, block, a.ldsBytes, st, ka); \
+                         else hipLaunchKernelGGL((k_bounce<true, false, false>), grid, block, a.ldsBytes, st, ka); } \
+            else       { if (lds) hipLaunchKernelGGL((k_bounce<false, true, DEFER>), grid, block, a.ldsBytes, st, ka); \
+                         else hipLaunchKernelGGL((k_bounce<false, false, DEFER>), grid, block, a.ldsBytes, st, ka); } \
         } while (0)
         {
             const BounceKernargs ka = { a.scene, a.ss, a.ctl, a.bounce, a.bounceEnd, a.stackEntries, a.cam, a.fp, a.passSeeds };
             // (the detail-counting variants walk the scene BVH: nothing to defer)
             if (a.scene.deferMeshes)
-            {
-                if (a.bounceWaves >= 4) TN_LAUNCH_BOUNCE(true, 4); else TN_LAUNCH_BOUNCE(true, 3);
-            }
+                TN_LAUNCH_BOUNCE(true);
             else
-            {
-                if (a.bounceWaves >= 4) TN_LAUNCH_BOUNCE(false, 4); else TN_LAUNCH_BOUNCE(false, 3);
-            }
+                TN_LAUNCH_BOUNCE(false);
         }
 #undef TN_LAUNCH_BOUNCE
         break;
@@ -202,9 +197,8 @@ inline PrepReport prepare_path_kernels(int sharedMemLimit)
     TN_PREP(k_shade_sorted<true, true>); TN_PREP(k_shade_sorted<true>); TN_PREP(k_shade_sorted<false>);
     TN_PREP(k_swalk<false, 1024, 1>); TN_PREP(k_swalk<false, 1024, 2>); TN_PREP(k_swalk<false, 256, 0>);
     TN_PREP(k_swalk<true, 1024, 1>); TN_PREP(k_swalk<true, 1024, 2>); TN_PREP(k_swalk<true, 256, 0>);
-    TN_PREP(k_bounce<true, true, false, 3>); TN_PREP(k_bounce<true, false, false, 3>);
-    TN_PREP(k_bounce<false, true, false, 3>); TN_PREP(k_bounce<false, false, false, 3>); TN_PREP(k_bounce<false, true, true, 3>); TN_PREP(k_bounce<false, false, true, 3>);
-    TN_PREP(k_bounce<false, true, false, 4>); TN_PREP(k_bounce<false, false, false, 4>); TN_PREP(k_bounce<false, true, true, 4>); TN_PREP(k_bounce<false, false, true, 4>);
+    TN_PREP(k_bounce<true, true, false>); TN_PREP(k_bounce<true, false, false>);
+    TN_PREP(k_bounce<false, true, false>); TN_PREP(k_bounce<false, false, false>); TN_PREP(k_bounce<false, true, true>); TN_PREP(k_bounce<false, false, true>);
 #undef TN_PREP
     return rep;
 }
