@@ -253,6 +253,36 @@ int pick_stack(int need)
     return -1;
 }
 
+// The two-level records of a mesh tree in HBM (Fat128, tn_scene.h; k_build_fat, tn_lbvh.h): k_walk's kWalkFat mode.  `dm.fat` is allocated on
+// first use (owner: the list that frees it) and (re)filled from the tree as it is NOW -- the reference's as converted, a device-built one,
+// either after a refit (the records are copies of the boxes).
+int fill_fat(DevMesh& dm)
+{
+    if (!dm.fat || dm.numInternal <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_build_fat, dim3((unsigned)((dm.numInternal + 255)/256)), dim3(256), 0, nullptr, dm.nodes, dm.numInternal, const_cast<Fat128*>(dm.fat));
+    // (the null stream orders the records before the kernels of the blocking streams; the non-blocking ones are synchronised by the callers:
+    // create / set_mesh_bvh / refit_mesh all end with a device synchronisation)
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)
+        return fail("k_build_fat failed");
+    return 0;
+}
+
+int build_fat(DevMesh& dm, std::vector<void*>& owner)
+{
+    if (dm.inArena || dm.numInternal <= 0 || !dm.nodes || (unsigned)dm.numInternal >= kFatRightBit)
+        return 0;
+    if (!dm.fat)
+    {
+        void* d = nullptr;
+        if (hipMalloc(&d, sizeof(Fat128)*(size_t)dm.numInternal) != hipSuccess)
+            return fail("device allocation failed (two-level node records)");
+        owner.push_back(d);
+        dm.fat = (const Fat128*)d;
+    }
+    return fill_fat(dm);
+}
+
 size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes; }
 
 // The path kernels exist twice (tn_launch.h): this translation unit's, bit-identical to the CPU oracle, and
@@ -380,6 +410,13 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
         const char* singleEnv = getenv("TINSEL_HIP_WALK_SINGLE");
         a.walkSingle = (r->walkPrims.count == 1 && !(singleEnv && atoi(singleEnv) == 0)) ? 1 : 0;
     }
+    // ... and, where its tree has them, two levels per cache line (k_walk's kWalkFat: Fat128 records, nothing staged into LDS).
+    // TINSEL_HIP_WALK_FAT=0: the plain Node64 walk (A/B, tests)
+    bool fatWalk = false;
+    {
+        const char* fatEnv = getenv("TINSEL_HIP_WALK_FAT");
+        fatWalk = a.walkSingle && !(fatEnv && atoi(fatEnv) == 0) && r->meshesNow[(size_t)r->walkPrimMesh[0]].fat != nullptr;
+    }
 
     const size_t ctl = kWalkCtlWords*sizeof(uint32_t);
     // n stack entries per lane in LDS (TINSEL_HIP_WALK_LDS_STACK, default 8; 0: the deepest tree's need, one workgroup per CU), the
@@ -406,6 +443,8 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
                 if (bytes + (size_t)(e + kWalkLaneRows)*1024*sizeof(uint32_t) <= (size_t)r->sharedMemLimit)
                     ldsMeshEntries = e;
     }
+    if (fatWalk)
+        ldsMeshEntries = 0;
     const bool twoPerCU = ldsStackEnv > 0 && !forceBlock && !ldsMeshEntries;
     const int ldsEntries = ldsMeshEntries ? ldsMeshEntries : twoPerCU ? std::min(entries, std::max(1, ldsStackEnv)) : entries;
     job.stackEntries = ldsEntries;
@@ -418,8 +457,8 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     size_t lds = (size_t)(ldsEntries + kWalkLaneRows)*block*sizeof(uint32_t) + ctl;
     if (big)
     {
-        // what is left of the CU's LDS goes to the tree tops, in primitive order
-        size_t room = (ldsBudget - lds)/sizeof(Node64);
+        // what is left of the CU's LDS goes to the tree tops, in primitive order (kWalkFat stages nothing)
+        size_t room = fatWalk ? 0 : (ldsBudget - lds)/sizeof(Node64);
         for (int k = 0; k < r->walkPrims.count && room > 0; ++k)
         {
             const int n = (int)std::min<size_t>(room, (size_t)r->meshesNow[(size_t)r->walkPrimMesh[k]].topCount);
@@ -435,6 +474,7 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
             }
     }
     a.walkLdsMesh = (big && ldsMeshEntries) ? 1 : 0;
+    a.walkFat = (fatWalk && big) ? 1 : 0;
     const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1)*(size_t)r->walkPrims.count;
     const int perCU = big ? gridMult*(twoPerCU ? 2 : 1) : gridMult*4;
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));

@@ -113,8 +113,13 @@ TN_D Node64 load_node_from(Ptr nodes, uint32_t idx)
 //                1024-thread workgroup per CU; glass.tin's 1280-triangle sphere + cube: 126 KB).  No walk step touches memory: node visits are
 //                ds_read_b128, triangle tests read nine floats, only the refill (queue -> ray) and the finished record go to HBM.  The host
 //                chooses it when it fits (launch_walk); otherwise the tree top is staged and the rest comes through L2 as before.
+//   kWalkFat     TWO LEVELS PER CACHE LINE (meshes in HBM whose trees have Fat128 records, tn_scene.h): a node visit pulls ONE 128-B line that
+//                holds the node's two child boxes AND those of its embedded child; when the walk's next stop is that child, its visit is made
+//                at once from the same line.  Same tests, same order, same stack as two turns of the plain loop (closestT cannot change in
+//                between: no triangle is tested between the two visits).  Nothing is staged into LDS in this mode.
 constexpr int kWalkSingle = 2;
 constexpr int kWalkLdsTris = 4;
+constexpr int kWalkFat = 8;
 
 // The closest hit's normal for its record: n*sign with n = Cross(b - a, c - a) as IntersectRayTriTwoSided forms it (intersection.h:122-124),
 // computed again from the triangle where the record is written -- the lane's next refill, whose chain of dependent loads hides the
@@ -143,7 +148,7 @@ constexpr int kWalkLaneRows = 2;
 template <int BLOCK, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 {
-    constexpr bool SINGLE = (MODE & kWalkSingle) != 0, LDSTRIS = (MODE & kWalkLdsTris) != 0;
+    constexpr bool SINGLE = (MODE & kWalkSingle) != 0, LDSTRIS = (MODE & kWalkLdsTris) != 0, FAT = (MODE & kWalkFat) != 0;
     constexpr uint32_t kAtLeaf = kLeafBit;      // refs that wait for the triangle phase
     extern __shared__ __attribute__((aligned(16))) uint32_t s_walk[];
     uint32_t* const stack = s_walk + threadIdx.x;               // this lane's column: entry i at stack[i*BLOCK]
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
         box0a = bp[0]; box0b = bp[1];
     }
     const DevMesh* mesh0p = sc.meshes + prim0.mesh;
-    GlobalF4 mesh0nodes = as_global(mesh0p->nodes), mesh0tris = as_global(mesh0p->tris);
+    GlobalF4 mesh0nodes = as_global(FAT ? (const void*)mesh0p->fat : (const void*)mesh0p->nodes), mesh0tris = as_global(mesh0p->tris);
     const uint32_t mesh0root = mesh0p->root;
     const uint32_t top0N = (uint32_t)job.topCount[0];
     // (kWalkLdsTris) the staged triangles start behind ALL the staged tops
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         else
                         {
                             const DevMesh* m = sc.meshes + p.mesh;
-                            mnodes = as_global(m->nodes);
+                            mnodes = as_global(FAT ? (const void*)m->fat : (const void*)m->nodes);
                             mtris = as_global(m->tris);
                             ref = m->root;
                         }
@@ -420,6 +425,64 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 #endif
 
         // ---- node phase: lanes at an internal node -------------------------------------------------------------
+        if (FAT)
+        {
+            if (active && !(ref & kAtLeaf))
+            {
+                // ONE 128-B line: node `ref`'s two child boxes + refs, and its embedded child's (Fat128, tn_scene.h)
+                GlobalF4 fp = (SINGLE ? mesh0nodes : mnodes) + (size_t)ref*8;
+                const WalkF4 a0 = fp[0], a1 = fp[1], a2 = fp[2], a3 = fp[3], b0 = fp[4], b1 = fp[5], b2 = fp[6];
+                // one visit (intersection.h:696-722): both child boxes against the closest hit so far, the far child of two pushed, the
+                // near one (or the only one) is where the walk goes next; false: no child hit
+                auto visit = [&](const WalkF4& x0, const WalkF4& x1, const WalkF4& x2, uint32_t refL, uint32_t refR, uint32_t& next) -> bool {
+                    float tL, tR;
+                    bool hL, hR;
+                    if (finiteAll)
+                    {
+                        hL = ray_aabb_minmax(o, rcp, x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, tL);
+                        hR = ray_aabb_minmax(o, rcp, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, tR);
+                    }
+                    else
+                    {
+                        tL = tR = 0.0f;
+                        hL = ray_aabb(o, rcp, x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, tL);
+                        hR = ray_aabb(o, rcp, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, tR);
+                    }
+                    hL = hL && tL < closestT;
+                    hR = hR && tR < closestT;
+                    if (hL && hR)
+                    {
+                        const bool leftNear = tL < tR;
+                        const uint32_t far = leftNear ? refR : refL;
+                        if (sp < ldsEntries)
+                            stack[sp*BLOCK] = far;
+                        else
+                            spill[sp - ldsEntries] = far;
+                        ++sp;
+                        next = leftNear ? refL : refR;
+                        return true;
+                    }
+                    next = hL ? refL : refR;
+                    return hL || hR;
+                };
+                const uint32_t refL = __float_as_uint(a3.x), refR = __float_as_uint(a3.y), eL = __float_as_uint(a3.z), eR = __float_as_uint(a3.w);
+                uint32_t next = kNoNode;
+                if (!visit(a0, a1, a2, refL, refR, next))
+                    pop = true;
+                else if (eL != kNoNode && next == ((eL & kFatRightBit) ? refR : refL))
+                {
+                    // the next stop is the embedded child: its visit, now, from the same line
+                    TN_WP_COUNT(14, 1)
+                    if (!visit(b0, b1, b2, eL & ~kFatRightBit, eR, next))
+                        pop = true;
+                    else
+                        ref = next;
+                }
+                else
+                    ref = next;
+            }
+        }
+        else
         if (active && !(ref & kAtLeaf))
         {
             Node64 nd;
