@@ -26,9 +26,6 @@ SETTINGS = [
     {"TINSEL_HIP_NO_WALK": "1"}, {"TINSEL_HIP_WALK_MIN_TRIS": "1"}, {"TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_SMALL_MESH_BYTES": "0"},
     {"TINSEL_HIP_WALK_LDS_STACK": "0"}, {"TINSEL_HIP_WALK_LDS_STACK": "2"}, {"TINSEL_HIP_WALK_BLOCK": "256"}, {"TINSEL_HIP_WALK_SINGLE": "0"},
     {"TINSEL_HIP_WALK_LDS_STACK": "2", "TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_SMALL_MESH_BYTES": "0"},
-    # k_walk's record formats: two levels per cache line (one walked primitive) / the plain Node64 walk; whole small meshes in LDS or not
-    {"TINSEL_HIP_WALK_FAT": "0"}, {"TINSEL_HIP_WALK_FAT": "0", "TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_SMALL_MESH_BYTES": "0"},
-    {"TINSEL_HIP_WALK_LDS_MESH": "0"}, {"TINSEL_HIP_WALK_LDS_MESH": "0", "TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_SMALL_MESH_BYTES": "0"},
     {"TINSEL_HIP_TAIL_SPLIT": "0"}, {"TINSEL_HIP_TAIL_SPLIT": "0.4,8"}, {"TINSEL_HIP_TAIL_SPLIT": "0.05,2"}, {"TINSEL_HIP_TAIL_SPLIT": "0.125,4"},
     # a batch's passes as two overlapped chunks on two streams (render_impl): every fixture, both pipelines; with several batches per call; off
     {"TINSEL_HIP_OVERLAP": "1"}, {"TINSEL_HIP_OVERLAP": "1", "TINSEL_HIP_BATCH_PATHS": "65536"}, {"TINSEL_HIP_OVERLAP": "0"},

@@ -292,9 +292,6 @@ int tinsel_hip_refit_mesh(tinsel_hip* r, int primitive, const float* positions_x
                 }
                 if (!rootGen)
                     rc = fail("refit_mesh: the refit did not reach the root");
-                // the two-level records hold copies of the boxes (tn_scene.h Fat128)
-                if (!rc && tree->fat)
-                    rc = fill_fat(*const_cast<DevMesh*>(tree));
             }
             if (rc)
                 break;

@@ -253,36 +253,6 @@ int pick_stack(int need)
     return -1;
 }
 
-// The two-level records of a mesh tree in HBM (Fat128, tn_scene.h; k_build_fat, tn_lbvh.h): k_walk's kWalkFat mode.  `dm.fat` is allocated on
-// first use (owner: the list that frees it) and (re)filled from the tree as it is NOW -- the reference's as converted, a device-built one,
-// either after a refit (the records are copies of the boxes).
-int fill_fat(DevMesh& dm)
-{
-    if (!dm.fat || dm.numInternal <= 0)
-        return 0;
-    hipLaunchKernelGGL(k_build_fat, dim3((unsigned)((dm.numInternal + 255)/256)), dim3(256), 0, nullptr, dm.nodes, dm.numInternal, const_cast<Fat128*>(dm.fat));
-    // (the null stream orders the records before the kernels of the blocking streams; the non-blocking ones are synchronised by the callers:
-    // create / set_mesh_bvh / refit_mesh all end with a device synchronisation)
-    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess)
-        return fail("k_build_fat failed");
-    return 0;
-}
-
-int build_fat(DevMesh& dm, std::vector<void*>& owner)
-{
-    if (dm.inArena || dm.numInternal <= 0 || !dm.nodes || (unsigned)dm.numInternal >= kFatRightBit)
-        return 0;
-    if (!dm.fat)
-    {
-        void* d = nullptr;
-        if (hipMalloc(&d, sizeof(Fat128)*(size_t)dm.numInternal) != hipSuccess)
-            return fail("device allocation failed (two-level node records)");
-        owner.push_back(d);
-        dm.fat = (const Fat128*)d;
-    }
-    return fill_fat(dm);
-}
-
 size_t stack_bytes(const tinsel_hip* r) { return ((size_t)r->stackNeed*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes; }
 
 // The path kernels exist twice (tn_launch.h): this translation unit's, bit-identical to the CPU oracle, and
@@ -392,7 +362,6 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     {
         job.prim[k] = k < r->walkPrims.count ? r->walkPrims.prim[k] : 0;
         job.topCount[k] = 0;
-        job.triCount[k] = 0;
         if (k < r->walkPrims.count)
             entries = std::max(entries, r->meshesNow[(size_t)r->walkPrimMesh[k]].stackNeed);
     }
@@ -410,13 +379,6 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
         const char* singleEnv = getenv("TINSEL_HIP_WALK_SINGLE");
         a.walkSingle = (r->walkPrims.count == 1 && !(singleEnv && atoi(singleEnv) == 0)) ? 1 : 0;
     }
-    // ... and, where its tree has them, two levels per cache line (k_walk's kWalkFat: Fat128 records, nothing staged into LDS).
-    // TINSEL_HIP_WALK_FAT=0: the plain Node64 walk (A/B, tests)
-    bool fatWalk = false;
-    {
-        const char* fatEnv = getenv("TINSEL_HIP_WALK_FAT");
-        fatWalk = a.walkSingle && !(fatEnv && atoi(fatEnv) == 0) && r->meshesNow[(size_t)r->walkPrimMesh[0]].fat != nullptr;
-    }
 
     const size_t ctl = kWalkCtlWords*sizeof(uint32_t);
     // n stack entries per lane in LDS (TINSEL_HIP_WALK_LDS_STACK, default 8; 0: the deepest tree's need, one workgroup per CU), the
@@ -424,29 +386,8 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     // LDS: the 524k-triangle config's k_walk 19.0 -> 16.6 ms per 32 passes (2042 -> 2199 Msamples/s; 6 entries 17.2, 12 entries 16.7),
     // glass 10.4 -> 9.9; results unchanged (a stack entry is a stack entry wherever it lives)
     static const int ldsStackEnv = getenv("TINSEL_HIP_WALK_LDS_STACK") ? atoi(getenv("TINSEL_HIP_WALK_LDS_STACK")) : 8;
-    // THE WHOLE MESH IN LDS (k_walk's kWalkLdsTris, tn_walk.h) where every walked tree is numbered breadth-first to its last node and all of
-    // them, with their triangles' vertices (36 B each), fit beside the stacks of ONE 1024-thread workgroup per CU with at least four stack
-    // entries per lane in LDS: glass.tin's sphere + cube (1290 nodes, 1292 triangles: 126 KB).  TINSEL_HIP_WALK_LDS_MESH=0: off (A/B, tests).
-    int ldsMeshEntries = 0;
-    {
-        const char* meshEnv = getenv("TINSEL_HIP_WALK_LDS_MESH");
-        size_t bytes = ctl;
-        bool whole = !(meshEnv && atoi(meshEnv) == 0) && !forceBlock && r->walkPrims.count > 0;
-        for (int k = 0; k < r->walkPrims.count && whole; ++k)
-        {
-            const DevMesh& dm = r->meshesNow[(size_t)r->walkPrimMesh[k]];
-            whole = dm.topCount == dm.numInternal && dm.numInternal > 0;
-            bytes += (size_t)dm.numInternal*sizeof(Node64) + (size_t)dm.numTris*36u;
-        }
-        if (whole)
-            for (int e = std::min(entries, 8); e >= std::min(entries, 4) && !ldsMeshEntries; --e)
-                if (bytes + (size_t)(e + kWalkLaneRows)*1024*sizeof(uint32_t) <= (size_t)r->sharedMemLimit)
-                    ldsMeshEntries = e;
-    }
-    if (fatWalk)
-        ldsMeshEntries = 0;
-    const bool twoPerCU = ldsStackEnv > 0 && !forceBlock && !ldsMeshEntries;
-    const int ldsEntries = ldsMeshEntries ? ldsMeshEntries : twoPerCU ? std::min(entries, std::max(1, ldsStackEnv)) : entries;
+    const bool twoPerCU = ldsStackEnv > 0 && !forceBlock;
+    const int ldsEntries = twoPerCU ? std::min(entries, std::max(1, ldsStackEnv)) : entries;
     job.stackEntries = ldsEntries;
     job.overflow = nullptr;
     job.overflowEntries = 0;
@@ -457,8 +398,8 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     size_t lds = (size_t)(ldsEntries + kWalkLaneRows)*block*sizeof(uint32_t) + ctl;
     if (big)
     {
-        // what is left of the CU's LDS goes to the tree tops, in primitive order (kWalkFat stages nothing)
-        size_t room = fatWalk ? 0 : (ldsBudget - lds)/sizeof(Node64);
+        // what is left of the CU's LDS goes to the tree tops, in primitive order
+        size_t room = (ldsBudget - lds)/sizeof(Node64);
         for (int k = 0; k < r->walkPrims.count && room > 0; ++k)
         {
             const int n = (int)std::min<size_t>(room, (size_t)r->meshesNow[(size_t)r->walkPrimMesh[k]].topCount);
@@ -466,15 +407,7 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
             room -= (size_t)n;
             lds += (size_t)n*sizeof(Node64);
         }
-        if (ldsMeshEntries)
-            for (int k = 0; k < r->walkPrims.count; ++k)
-            {
-                job.triCount[k] = r->meshesNow[(size_t)r->walkPrimMesh[k]].numTris;
-                lds += (size_t)job.triCount[k]*36u;
-            }
     }
-    a.walkLdsMesh = (big && ldsMeshEntries) ? 1 : 0;
-    a.walkFat = (fatWalk && big) ? 1 : 0;
     const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1)*(size_t)r->walkPrims.count;
     const int perCU = big ? gridMult*(twoPerCU ? 2 : 1) : gridMult*4;
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));

@@ -151,11 +151,7 @@ int build_device_bvh(tinsel_hip* r, const DevMesh& dm, DevMesh& out, int mode)
     if (rc)
         (void)hipFree(nodes);
     else
-    {
         r->lbvhAllocs.push_back(nodes);
-        out.fat = nullptr;              // this tree's own two-level records (the reference tree keeps its)
-        rc = build_fat(out, r->lbvhAllocs);
-    }
     return rc;
 }
 

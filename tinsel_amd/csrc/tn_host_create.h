@@ -202,7 +202,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                     dm.tris = r->sceneMem.upload(tris.data(), tris.size());
                     dm.normals = r->sceneMem.upload(&g.normals[0].x, (size_t)g.num_vertices*3);
                     dm.cdf = r->sceneMem.upload(g.cdf, (size_t)numTris);
-                    if ((!cb.nodes.empty() && !dm.nodes) || !dm.tris || !dm.normals || !dm.cdf || build_fat(dm, r->sceneMem.allocs))
+                    if ((!cb.nodes.empty() && !dm.nodes) || !dm.tris || !dm.normals || !dm.cdf)
                     {
                         fail("create: device allocation failed (mesh)");
                         ok = false;

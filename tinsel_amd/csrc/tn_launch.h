@@ -38,8 +38,6 @@ struct LaunchArgs
     int swalkMode;                  // PK_SWALK_*: 0 = 256-thread workgroups, generic pointers; 1 / 2 = 1024-thread workgroups, arena in LDS (2: meshes in HBM too)
     int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
     int walkSingle;                 // PK_WALK: ONE walked primitive: the kWalkSingle variant (tn_walk.h)
-    int walkLdsMesh;                // PK_WALK: trees AND triangles staged whole (kWalkLdsTris; 1024-thread workgroups, one per CU)
-    int walkFat;                    // PK_WALK: ONE walked primitive whose tree has Fat128 records: two levels per cache line (kWalkFat; walkBig only)
     int shadeSorted;                // PK_SHADE: k_shade_sorted (paths taken class by class) instead of k_shade
     int lightsInExtend;             // PK_EXTEND, arena staged + meshes in HBM: the variant that draws the light samples too (A/B)
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
@@ -147,16 +145,7 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             else if (a.walkBig) hipLaunchKernelGGL((k_walk<1024, 4, MODE>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk); \
             else hipLaunchKernelGGL((k_walk<256, 5, MODE>), grid, dim3(256), a.ldsBytes, st, a.scene, a.walk);            \
         } while (0)
-        if (a.walkFat && a.walkBig == 2)
-            hipLaunchKernelGGL((k_walk<1024, 8, kWalkSingle | kWalkFat>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
-        else if (a.walkFat && a.walkBig == 1)
-            hipLaunchKernelGGL((k_walk<1024, 4, kWalkSingle | kWalkFat>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
-        else if (a.walkLdsMesh && a.walkBig == 1)
-        {
-            if (a.walkSingle) hipLaunchKernelGGL((k_walk<1024, 4, kWalkSingle | kWalkLdsTris>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
-            else hipLaunchKernelGGL((k_walk<1024, 4, kWalkLdsTris>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk);
-        }
-        else if (a.walkSingle) TN_LAUNCH_WALK(kWalkSingle); else TN_LAUNCH_WALK(0);
+        if (a.walkSingle) TN_LAUNCH_WALK(kWalkSingle); else TN_LAUNCH_WALK(0);
 #undef TN_LAUNCH_WALK
         break;
     default:
@@ -197,8 +186,6 @@ inline PrepReport prepare_path_kernels(int sharedMemLimit)
         if (seg.refused) { rep.refused += 1; rep.first = rep.first ? rep.first : "k_seg_prefix"; }
     }
     TN_PREP(k_walk<1024, 4, 0>); TN_PREP(k_walk<1024, 8, 0>); TN_PREP(k_walk<256, 5, 0>);
-    TN_PREP(k_walk<1024, 4, kWalkLdsTris>); TN_PREP(k_walk<1024, 4, kWalkSingle | kWalkLdsTris>);
-    TN_PREP(k_walk<1024, 8, kWalkSingle | kWalkFat>); TN_PREP(k_walk<1024, 4, kWalkSingle | kWalkFat>);
     TN_PREP(k_walk<1024, 4, kWalkSingle>); TN_PREP(k_walk<1024, 8, kWalkSingle>); TN_PREP(k_walk<256, 5, kWalkSingle>);
     TN_PREP(k_shade_sorted<true, true>); TN_PREP(k_shade_sorted<true>); TN_PREP(k_shade_sorted<false>);
     TN_PREP(k_swalk<false, 1024, 1>); TN_PREP(k_swalk<false, 1024, 2>); TN_PREP(k_swalk<false, 256, 0>);

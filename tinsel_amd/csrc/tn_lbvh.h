@@ -416,50 +416,4 @@ __global__ __launch_bounds__(256) void k_refit_pass(Node64* __restrict__ nodes, 
     gen[k] = pass;
 }
 
-// ---------------------------------------------------------------------------
-// Fat128 records (tn_scene.h) of a Node64 tree: node k's own words followed by those of its embedded child -- of its internal children the
-// one with the larger box surface (the likelier next stop of a ray that enters node k's box); a node without internal children embeds none.
-// Works on any tree (the reference's as converted, a device-built one) and is run again after a refit: the records are COPIES of the boxes.
-__global__ __launch_bounds__(256) void k_build_fat(const Node64* __restrict__ nodes, int numNodes, Fat128* __restrict__ fat)
-{
-    const int k = blockIdx.x*256 + threadIdx.x;
-    if (k >= numNodes)
-        return;
-    const Node64 n = nodes[k];
-    Fat128 f;
-    const float* nb = &n.lminx;
-    for (int c = 0; c < 12; ++c)
-        f.box[c] = nb[c];
-    f.left = n.left; f.right = n.right;
-    auto area = [](float minx, float miny, float minz, float maxx, float maxy, float maxz) {
-        const float dx = maxx - minx, dy = maxy - miny, dz = maxz - minz;
-        return dx*dy + dy*dz + dz*dx;
-    };
-    const bool li = !(n.left & kLeafBit), ri = !(n.right & kLeafBit);
-    int which = -1;
-    if (li && ri)
-        which = area(n.rminx, n.rminy, n.rminz, n.rmaxx, n.rmaxy, n.rmaxz) > area(n.lminx, n.lminy, n.lminz, n.lmaxx, n.lmaxy, n.lmaxz) ? 1 : 0;
-    else if (li)
-        which = 0;
-    else if (ri)
-        which = 1;
-    if (which < 0)
-    {
-        f.embLeft = kNoNode; f.embRight = kNoNode;
-        for (int c = 0; c < 12; ++c)
-            f.embBox[c] = 0.0f;
-    }
-    else
-    {
-        const Node64 e = nodes[which ? n.right : n.left];
-        const float* eb = &e.lminx;
-        for (int c = 0; c < 12; ++c)
-            f.embBox[c] = eb[c];
-        f.embLeft = e.left | (which ? kFatRightBit : 0u);
-        f.embRight = e.right;
-    }
-    f.pad[0] = f.pad[1] = f.pad[2] = f.pad[3] = 0u;
-    fat[k] = f;
-}
-
 } // namespace tn

@@ -34,27 +34,6 @@ struct alignas(64) Node64
 };
 static_assert(sizeof(Node64) == 64, "Node64");
 
-// TWO LEVELS OF A MESH TREE IN ONE 128-B CACHE LINE (k_walk's kWalkFat mode; meshes in HBM).  The walk is bound by the cache lines it pulls
-// from L2 into a CU's L1 -- one 128-B line per visited Node64, of which the record fills half (tn_walk.h).  A Fat128 is node i's Node64 (both
-// children's boxes + refs) FOLLOWED BY the same 56 bytes of ONE of its internal children -- the "embedded" child, the one with the larger box:
-// when the walk's next stop after node i is that child (it is the nearer of two hit children, or the only one hit), its two box tests are
-// made out of the same line and its own record is never fetched.  Boxes and refs are copies of the Node64 words, bit for bit: the tests,
-// their order and the stack discipline are the reference's (intersection.h:696-722) -- only how many lines a ray pulls changes.
-//   q[0..2]  node i: left box, right box (Node64's first 48 bytes)
-//   q[3]     { left ref, right ref, embedded child's left ref | kFatRightBit when the embedded child is the RIGHT one, its right ref };
-//            q[3].z == kNoNode: no internal child to embed
-//   q[4..6]  the embedded child's left box, right box
-//   q[7]     unused
-constexpr uint32_t kFatRightBit = 0x40000000u;
-struct alignas(128) Fat128
-{
-    float box[12];
-    uint32_t left, right, embLeft, embRight;
-    float embBox[12];
-    uint32_t pad[4];
-};
-static_assert(sizeof(Fat128) == 128, "Fat128");
-
 struct alignas(16) Tri48
 {
     float ax, ay, az; int32_t i0;
@@ -145,7 +124,6 @@ struct DevMesh
     int32_t twoLeaves;          // 1: the tree is one internal node over two one-triangle leaves (a quad): ray_mesh_two_leaves
     int32_t numInternal;        // Node64 records of this tree
     int32_t pad0;
-    const Fat128* fat;          // [numInternal] two-level records of the same tree (k_build_fat; null: none -- meshes in the arena, trees of one leaf)
 };
 
 struct DevProbe

@@ -58,7 +58,6 @@ struct WalkJob
     int numPrims;                   // walked primitives (1..7)
     int prim[kWalkMaxPrims];
     int topCount[kWalkMaxPrims];    // Node64 records of each walked primitive's tree staged into LDS (a prefix: breadth-first order)
-    int triCount[kWalkMaxPrims];    // kWalkLdsTris: triangles of each walked primitive's mesh staged into LDS behind the tree tops (all of them)
     int stackEntries;               // LDS stack entries per lane (the deepest walked tree's need, or fewer: see overflow)
     uint32_t* overflow;             // [lane of the grid][overflowEntries]: stack entries beyond the LDS ones (null: the LDS stack holds the deepest tree)
     int overflowEntries;
@@ -109,17 +108,12 @@ TN_D Node64 load_node_from(Ptr nodes, uint32_t idx)
 // (Round 4's kWalkPairs -- a node over two one-triangle leaves fetched as ONE 128-B record in the triangle phase -- was built in three
 // versions, bit-identical, and never paid: 10.8-10.9 ms without, 10.96-11.02 with on the 524k-triangle config, glass 6.5 -> 8.8 ms;
 // profiles/r04_a..c_ab_walk_pairs*.md have the numbers, `git log -- tinsel_amd/csrc/tn_walk.h` the code.)
-//   kWalkLdsTris THE WHOLE MESH IN LDS (small meshes: every walked tree AND its triangles' vertices -- 36 B each -- fit beside the stacks of ONE
-//                1024-thread workgroup per CU; glass.tin's 1280-triangle sphere + cube: 126 KB).  No walk step touches memory: node visits are
-//                ds_read_b128, triangle tests read nine floats, only the refill (queue -> ray) and the finished record go to HBM.  The host
-//                chooses it when it fits (launch_walk); otherwise the tree top is staged and the rest comes through L2 as before.
-//   kWalkFat     TWO LEVELS PER CACHE LINE (meshes in HBM whose trees have Fat128 records, tn_scene.h): a node visit pulls ONE 128-B line that
-//                holds the node's two child boxes AND those of its embedded child; when the walk's next stop is that child, its visit is made
-//                at once from the same line.  Same tests, same order, same stack as two turns of the plain loop (closestT cannot change in
-//                between: no triangle is tested between the two visits).  Nothing is staged into LDS in this mode.
+// (Round 5 built two more modes, both bit-identical under the whole GPU suite, neither kept: the WHOLE of a small mesh in LDS -- glass.tin's
+// sphere + cube, 126 KB, one workgroup per CU: k_walk 6.54 ms against 6.70, 38 % of the lanes active either way: what a ray costs there is its
+// refill and its record, not its node fetches -- and TWO tree levels per 128-B record (a node's child boxes followed by those of its larger
+// internal child: a third fewer visits, each of twice the bytes: 14.0 ms against 10.7 on the 524k-triangle config -- the walk is bound by the
+// BYTES it pulls through a CU's L1, in 64-B sectors, not by lines or round trips).  profiles/r05_b_ab_glass_lds_mesh.md, r05_c_ab_walk_fat.md.)
 constexpr int kWalkSingle = 2;
-constexpr int kWalkLdsTris = 4;
-constexpr int kWalkFat = 8;
 
 // The closest hit's normal for its record: n*sign with n = Cross(b - a, c - a) as IntersectRayTriTwoSided forms it (intersection.h:122-124),
 // computed again from the triangle where the record is written -- the lane's next refill, whose chain of dependent loads hides the
@@ -132,13 +126,6 @@ TN_D V3 hit_normal(GlobalF4 tris, int tri, float sign)
     return cross(b - a, c - a)*sign;
 }
 
-TN_D V3 hit_normal_lds(const float* tris, int tri, float sign)
-{
-    const float* t = tris + (size_t)tri*9;
-    const V3 a(t[0], t[1], t[2]), b(t[3], t[4], t[5]), c(t[6], t[7], t[8]);
-    return cross(b - a, c - a)*sign;
-}
-
 // LDS of one workgroup: [stackEntries][BLOCK] stack words, [kWalkLaneRows][BLOCK] per-lane words that are touched once or twice per
 // RAY and have no business in a register of a 64-VGPR kernel (row 0: the ray's record index, row 1: a shadow ray's stop distance),
 // then 16 control words, then the staged tree tops.
@@ -148,7 +135,7 @@ constexpr int kWalkLaneRows = 2;
 template <int BLOCK, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 {
-    constexpr bool SINGLE = (MODE & kWalkSingle) != 0, LDSTRIS = (MODE & kWalkLdsTris) != 0, FAT = (MODE & kWalkFat) != 0;
+    constexpr bool SINGLE = (MODE & kWalkSingle) != 0;
     constexpr uint32_t kAtLeaf = kLeafBit;      // refs that wait for the triangle phase
     extern __shared__ __attribute__((aligned(16))) uint32_t s_walk[];
     uint32_t* const stack = s_walk + threadIdx.x;               // this lane's column: entry i at stack[i*BLOCK]
@@ -202,28 +189,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                 base += (uint32_t)n;
             }
         }
-        if (LDSTRIS)
-        {
-            // every walked mesh's triangles behind the tops: the three vertices of a Tri48 as nine floats
-            float* dst = reinterpret_cast<float*>(s_top + (size_t)base*4);
-#pragma unroll 1
-            for (int kb = 0; kb < job.numPrims; ++kb)
-            {
-                int primIndex = job.prim[0], n = job.triCount[0];
-#pragma unroll
-                for (int q = 1; q < kWalkMaxPrims; ++q)
-                    if (q == kb) { primIndex = job.prim[q]; n = job.triCount[q]; }
-                const Prim64 p = load_prim(sc.prims, primIndex);
-                GlobalF4 src = as_global(sc.meshes[p.mesh].tris);
-                for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += BLOCK)
-                {
-                    const WalkF4 a = src[(size_t)i*3], b = src[(size_t)i*3 + 1], c = src[(size_t)i*3 + 2];
-                    float* d9 = dst + (size_t)i*9;
-                    d9[0] = a.x; d9[1] = a.y; d9[2] = a.z; d9[3] = b.x; d9[4] = b.y; d9[5] = b.z; d9[6] = c.x; d9[7] = c.y; d9[8] = c.z;
-                }
-                dst += (size_t)n*9;
-            }
-        }
     }
     __syncthreads();
 
@@ -238,18 +203,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
         box0a = bp[0]; box0b = bp[1];
     }
     const DevMesh* mesh0p = sc.meshes + prim0.mesh;
-    GlobalF4 mesh0nodes = as_global(FAT ? (const void*)mesh0p->fat : (const void*)mesh0p->nodes), mesh0tris = as_global(mesh0p->tris);
+    GlobalF4 mesh0nodes = as_global(mesh0p->nodes), mesh0tris = as_global(mesh0p->tris);
     const uint32_t mesh0root = mesh0p->root;
     const uint32_t top0N = (uint32_t)job.topCount[0];
-    // (kWalkLdsTris) the staged triangles start behind ALL the staged tops
-    uint32_t topsAll = 0;
-    if (LDSTRIS)
-    {
-#pragma unroll
-        for (int q = 0; q < kWalkMaxPrims; ++q)
-            topsAll += (uint32_t)job.topCount[q];
-    }
-    const float* const s_tris = reinterpret_cast<const float*>(s_top + (size_t)topsAll*4);
 
     // per-lane walk state
     // (no flags: a lane is ACTIVE iff ref != kNoNode; a finished ray's record is PENDING in its registers iff *s_item != kNoItem)
@@ -265,7 +221,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     GlobalF4 mnodes = nullptr;
     GlobalF4 mtris = nullptr;
     uint32_t topBase = 0, topN = 0;     // this lane's tree: refs < topN are staged at s_top[(topBase + ref)*4 ..]
-    uint32_t triBase = 0;               // (kWalkLdsTris, several primitives) this lane's mesh: its triangles start at s_tris[triBase*9]
     bool finiteAll = true;              // wave-uniform: every active lane's 1/d is finite
     bool exhausted = bbeg >= end;       // wave-uniform: the workgroup's range has been handed out
     TN_WP_DECL
@@ -299,7 +254,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     out[0] = make_float4(closestT, 1.0f - hv - hw, hv, hw);
                     if (closestT < kFltMax)
                     {
-                        const V3 hn = LDSTRIS ? hit_normal_lds(s_tris + (size_t)(SINGLE ? 0u : triBase)*9, htri, hsign) : hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
+                        const V3 hn = hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
                         out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
                     }
                     *s_item = kNoItem;
@@ -333,7 +288,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 
                     int index = job.prim[0];
                     uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
-                    uint32_t trb = 0, trun = (uint32_t)job.triCount[0];
                     if (!SINGLE)
                     {
 #pragma unroll
@@ -344,10 +298,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                                 index = job.prim[q];
                                 tb = run;
                                 tn = (uint32_t)job.topCount[q];
-                                trb = trun;
                             }
                             run += (uint32_t)job.topCount[q];
-                            trun += (uint32_t)job.triCount[q];
                         }
                     }
 
@@ -387,7 +339,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         else
                         {
                             const DevMesh* m = sc.meshes + p.mesh;
-                            mnodes = as_global(FAT ? (const void*)m->fat : (const void*)m->nodes);
+                            mnodes = as_global(m->nodes);
                             mtris = as_global(m->tris);
                             ref = m->root;
                         }
@@ -395,8 +347,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         {
                             topBase = tb;
                             topN = tn;
-                            if (LDSTRIS)
-                                triBase = trb;
                         }
                         sp = 0;
                         closestT = kFltMax;
@@ -425,64 +375,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 #endif
 
         // ---- node phase: lanes at an internal node -------------------------------------------------------------
-        if (FAT)
-        {
-            if (active && !(ref & kAtLeaf))
-            {
-                // ONE 128-B line: node `ref`'s two child boxes + refs, and its embedded child's (Fat128, tn_scene.h)
-                GlobalF4 fp = (SINGLE ? mesh0nodes : mnodes) + (size_t)ref*8;
-                const WalkF4 a0 = fp[0], a1 = fp[1], a2 = fp[2], a3 = fp[3], b0 = fp[4], b1 = fp[5], b2 = fp[6];
-                // one visit (intersection.h:696-722): both child boxes against the closest hit so far, the far child of two pushed, the
-                // near one (or the only one) is where the walk goes next; false: no child hit
-                auto visit = [&](const WalkF4& x0, const WalkF4& x1, const WalkF4& x2, uint32_t refL, uint32_t refR, uint32_t& next) -> bool {
-                    float tL, tR;
-                    bool hL, hR;
-                    if (finiteAll)
-                    {
-                        hL = ray_aabb_minmax(o, rcp, x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, tL);
-                        hR = ray_aabb_minmax(o, rcp, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, tR);
-                    }
-                    else
-                    {
-                        tL = tR = 0.0f;
-                        hL = ray_aabb(o, rcp, x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, tL);
-                        hR = ray_aabb(o, rcp, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, tR);
-                    }
-                    hL = hL && tL < closestT;
-                    hR = hR && tR < closestT;
-                    if (hL && hR)
-                    {
-                        const bool leftNear = tL < tR;
-                        const uint32_t far = leftNear ? refR : refL;
-                        if (sp < ldsEntries)
-                            stack[sp*BLOCK] = far;
-                        else
-                            spill[sp - ldsEntries] = far;
-                        ++sp;
-                        next = leftNear ? refL : refR;
-                        return true;
-                    }
-                    next = hL ? refL : refR;
-                    return hL || hR;
-                };
-                const uint32_t refL = __float_as_uint(a3.x), refR = __float_as_uint(a3.y), eL = __float_as_uint(a3.z), eR = __float_as_uint(a3.w);
-                uint32_t next = kNoNode;
-                if (!visit(a0, a1, a2, refL, refR, next))
-                    pop = true;
-                else if (eL != kNoNode && next == ((eL & kFatRightBit) ? refR : refL))
-                {
-                    // the next stop is the embedded child: its visit, now, from the same line
-                    TN_WP_COUNT(14, 1)
-                    if (!visit(b0, b1, b2, eL & ~kFatRightBit, eR, next))
-                        pop = true;
-                    else
-                        ref = next;
-                }
-                else
-                    ref = next;
-            }
-        }
-        else
         if (active && !(ref & kAtLeaf))
         {
             Node64 nd;
@@ -539,17 +431,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
             {
                 // ONE round trip per phase: every lane requests its leaf's Tri48 before anybody waits
                 const uint32_t idx = ref & ~kLeafBit;
-                WalkF4 q3, q4, q5;
-                if (LDSTRIS)
-                {
-                    const float* t9 = s_tris + ((size_t)(SINGLE ? 0u : triBase) + idx)*9;
-                    q3 = WalkF4{ t9[0], t9[1], t9[2], 0.0f }; q4 = WalkF4{ t9[3], t9[4], t9[5], 0.0f }; q5 = WalkF4{ t9[6], t9[7], t9[8], 0.0f };
-                }
-                else
-                {
-                    GlobalF4 tp = (SINGLE ? mesh0tris : mtris) + (size_t)idx*3;
-                    q3 = tp[0]; q4 = tp[1]; q5 = tp[2];
-                }
+                GlobalF4 tp = (SINGLE ? mesh0tris : mtris) + (size_t)idx*3;
+                const WalkF4 q3 = tp[0], q4 = tp[1], q5 = tp[2];
                 bool any = false;
                 {
                     float t, u, v, w, sign;
@@ -594,7 +477,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
         out[0] = make_float4(closestT, 1.0f - hv - hw, hv, hw);
         if (closestT < kFltMax)
         {
-            const V3 hn = LDSTRIS ? hit_normal_lds(s_tris + (size_t)(SINGLE ? 0u : triBase)*9, htri, hsign) : hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
+            const V3 hn = hit_normal(SINGLE ? mesh0tris : mtris, htri, hsign);
             out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
         }
     }

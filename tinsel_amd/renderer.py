@@ -313,14 +313,24 @@ class HipRenderer:
 
     def kernel_times(self):
         """{kernel: (launches, sum of their durations in ms, union of their intervals in ms)}; the union is smaller than the sum where a
-        call's chunks overlap on two streams.  A library from before round 4 (TINSEL_HIP_LIB: A/B against an older build) writes 36-byte
-        records without the union: it says so by not exporting tinsel_hip_kernel_time_bytes, and the union is reported as the sum."""
-        old = not hasattr(self._L, "tinsel_hip_kernel_time_bytes") or self._L.tinsel_hip_kernel_time_bytes() != C.sizeof(abi.KernelTime)
-        arr = ((abi.KernelTimeV1 if old else abi.KernelTime) * 16)()
-        n = self._L.tinsel_hip_kernel_times(self._h, C.cast(arr, C.POINTER(abi.KernelTime)), 16)
+        call's chunks overlap on two streams.  Another build loaded through TINSEL_HIP_LIB (an A/B against an older library) may write
+        the records of before round 4 -- 36 bytes, no union -- and says nothing about it (tinsel_hip_kernel_time_bytes came later still):
+        then the record stride is READ OFF what the library wrote (every name starts with "k_"), and a 36-byte record's union is its sum."""
+        size = self._L.tinsel_hip_kernel_time_bytes() if hasattr(self._L, "tinsel_hip_kernel_time_bytes") else 0
+        raw = (C.c_ubyte * (16 * C.sizeof(abi.KernelTime)))()
+        n = self._L.tinsel_hip_kernel_times(self._h, C.cast(raw, C.POINTER(abi.KernelTime)), 16)
         if n < 0:
             _check(n, "tinsel_hip_kernel_times")
-        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms, arr[i].total_ms if old else arr[i].busy_ms) for i in range(n)}
+        data = bytes(raw)
+        if size not in (C.sizeof(abi.KernelTime), C.sizeof(abi.KernelTimeV1)):
+            v1 = C.sizeof(abi.KernelTimeV1)
+            size = v1 if (n >= 2 and data[v1:v1 + 2] == b"k_") else C.sizeof(abi.KernelTime)
+        T = abi.KernelTime if size == C.sizeof(abi.KernelTime) else abi.KernelTimeV1
+        out = {}
+        for i in range(n):
+            rec = T.from_buffer_copy(data[i*size:(i + 1)*size])
+            out[rec.name.decode()] = (rec.launches, rec.total_ms, rec.busy_ms if T is abi.KernelTime else rec.total_ms)
+        return out
 
     def stats(self):
         names = ["rays", "samples", "internal_visits", "tri_tests", "prim_tests", "shadow_rays", "_6", "_7"]
