@@ -408,7 +408,10 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
             lds += (size_t)n*sizeof(Node64);
         }
     }
-    const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1)*(size_t)r->walkPrims.count;
+    // (a work item is a ray; with several walked primitives a lane keeps its ray as position | k << 27 while primitives are left: tn_walk.h)
+    if (r->walkPrims.count > 1 && (ss.capacity >= (1u << 27) || r->neePerPath >= 32))
+        return fail("k_walk: batch too large or too many shadow rays per path for several walked primitives");
+    const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1);
     const int perCU = big ? gridMult*(twoPerCU ? 2 : 1) : gridMult*4;
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
     a.walkBig = big ? (twoPerCU ? 2 : 1) : 0;

@@ -306,10 +306,21 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         const size_t offLights = arena.add(lights.data(), lights.size());
         const size_t offMeshes = arena.add(meshes.data(), meshes.size());
 
-        // the always-hit planes once more, four by four, for the flat scan (trace_flat; TINSEL_HIP_NO_PLANE_TABLE: A/B)
+        // The always-hit planes once more, four by four, for the flat scan (trace_flat): four IntersectRayPlane calls in a block are four
+        // independent IEEE-division chains.  Where: scenes with a mesh in HBM (the split pipeline's kernels: glass k_extend -6 %, k_shadow
+        // -5 %, round 4) and -- since k_bounce has the registers for it, round 5 -- fused scenes with at least one full block of four
+        // (cornell 5283 -> 5450 Msamples/s, cfg1 +2.5 %); with fewer planes the table's remainder code only costs (gloss, env_loft -1 %:
+        // profiles/r05_d_ab_plane_table_fused.md), so those keep the loop.
         std::vector<float> planeEq;
         std::vector<int32_t> planeIdx;
-        if (flatScan)
+        int alwaysHitPlanes = 0;
+        bool anyMeshInHbm = false;
+        for (int k = 0; k < P; ++k)
+        {
+            alwaysHitPlanes += (prims[(size_t)k].type == kPrimPlane && boxes[(size_t)k].alwaysHit) ? 1 : 0;
+            anyMeshInHbm = anyMeshInHbm || (prims[(size_t)k].type == kPrimMesh && !meshes[prims[(size_t)k].mesh].inArena);
+        }
+        if (flatScan && (alwaysHitPlanes >= 4 || anyMeshInHbm))
         {
             for (int k = 0; k < P; ++k)
                 if (prims[(size_t)k].type == kPrimPlane && boxes[(size_t)k].alwaysHit)

@@ -525,7 +525,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
     // meets; their boxes say 2 and the loop below passes them by).  Every lane is at the same primitive in this scan, so one
     // IntersectRayPlane after the other is one IEEE division's dependent chain after the other; four in one block are four independent
     // chains the scheduler interleaves (then two, then one: what is left).  The order of the accept() calls does not matter (above).
-    const int numPlanes = SC::kPlaneTable ? sc.numPlanes : 0;
+    const int numPlanes = sc.numPlanes;
     int pk = 0;
     for (; pk + 4 <= numPlanes; pk += 4)
     {
@@ -567,7 +567,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
     {
         TN_TTICK(ctr, 4)
         const ConstF4V b0 = sc.kBoxes[i*2], b1 = sc.kBoxes[i*2 + 1];
-        if (SC::kPlaneTable && __float_as_uint(b1.z) == 2u)
+        if (__float_as_uint(b1.z) == 2u)
             continue;
         if (__float_as_uint(b1.z) == 0u)
         {

@@ -189,9 +189,6 @@ typedef const __attribute__((address_space(4))) ConstF4V* ConstF4;
 // MIXED (with LDS): the arena is staged whole and every scene record resolves to LDS at compile time, but some meshes live in
 // HBM -- the split pipeline's scenes (glass, the 524k-triangle config).  Only the mesh accessors below then choose per mesh;
 // without it those kernels reach everything through generic pointers (flat loads, which wait on both memory counters).
-#ifndef TN_PLANE_TABLE_ALL
-#define TN_PLANE_TABLE_ALL 0          // -DTN_PLANE_TABLE_ALL=1: the fused kernel too (A/B)
-#endif
 template <bool LDS, bool WALKED_ONLY = false, int DEFER = 2, bool MIXED = false>
 struct SceneT : DevScene
 {
@@ -199,10 +196,6 @@ struct SceneT : DevScene
     static constexpr bool kMixed = MIXED;
     static constexpr bool kWalkedOnly = WALKED_ONLY;
     static constexpr int kDefer = DEFER;
-    // trace_flat tests the always-hit planes four at a time from DevScene::planeEq: in the split pipeline's kernels and the one-lane-per-path
-    // ones; not in the fused kernel (k_bounce: DEFER 0 / 1), where the extra blocks cost more than the interleaved divisions give back
-    // (glass k_extend 7.2 -> 6.8 ms, k_shadow 4.05 -> 3.87; fused: veach -1.1 %, gloss -2.7 %, env_loft -2.5 %, cornell +-0: profiles/r04_o_ab_plane_table.md)
-    static constexpr bool kPlaneTable = TN_PLANE_TABLE_ALL || DEFER == 2;
     const unsigned char* ldsBase;
     // The flat scan reads primitive records and leaf boxes at a wave-uniform index: through these pointers (the arena's copy
     // in HBM, constant address space) they are scalar loads into SGPRs instead of 64 lanes reading the same LDS words

@@ -127,10 +127,11 @@ TN_D V3 hit_normal(GlobalF4 tris, int tri, float sign)
 }
 
 // LDS of one workgroup: [stackEntries][BLOCK] stack words, [kWalkLaneRows][BLOCK] per-lane words that are touched once or twice per
-// RAY and have no business in a register of a 64-VGPR kernel (row 0: the ray's record index, row 1: a shadow ray's stop distance),
+// RAY and have no business in a register of a 64-VGPR kernel (row 0: the ray's record index, row 1: a shadow ray's stop distance, row 2 --
+// several walked primitives -- the ray itself as slot | k << 27, for the primitives it still has to visit),
 // then 16 control words, then the staged tree tops.
 constexpr int kWalkCtlWords = 16;
-constexpr int kWalkLaneRows = 2;
+constexpr int kWalkLaneRows = 3;
 
 template <int BLOCK, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
@@ -145,19 +146,23 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     const int ldsEntries = job.stackEntries;
     uint32_t* const s_item = s_walk + job.stackEntries*BLOCK + threadIdx.x;                 // kNoItem: no finished ray's record waits in this lane's registers
     float* const s_stop = reinterpret_cast<float*>(s_walk + (job.stackEntries + 1)*BLOCK + threadIdx.x);    // shadow rays: an accepted hit closer than this ends the walk
+    uint32_t* const s_ray = s_walk + (job.stackEntries + 2)*BLOCK + threadIdx.x;            // several walked primitives: the lane's ray (slot | k << 27: the host checks the ranges) while primitives are left
     uint32_t* const s_ctl = s_walk + (job.stackEntries + kWalkLaneRows)*BLOCK;              // [0] the workgroup's cursor
     WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_ctl + kWalkCtlWords);
 
     const int lane = (int)__lane_id();
     const uint32_t Kx = job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
     const uint32_t Kb = (uint32_t)job.numPrims;
-    const uint32_t per = Kx*Kb;                                 // work items per queued slot
+    // A work item is a RAY (slot, k).  With several walked primitives the lane that takes it tests all their leaf boxes once -- the records
+    // are wave-uniform -- and walks the ones the ray enters one after the other (`pend`: a bit per primitive still to visit).  (Until round 5
+    // an item was a (ray, primitive) pair: glass fetched every ray twice, the reference's table.tin -- seven walked meshes -- seven times,
+    // to find five or six of the seven boxes missed.)
+    const uint32_t per = Kx;                                    // work items per queued slot
     const uint32_t total = (*job.frontCount)*per;
     // my/per and rem/Kb below: both divisors are wave-uniform, so the reciprocals live in SGPRs (the compiler's own expansion kept two
     // VGPR reciprocals across the loop, spilled them, and reloaded them in every refill behind an s_waitcnt vmcnt(0) -- i.e. behind the
     // finished rays' record stores).  q' = mulhi(n, floor((2^32-1)/d)) is q or q - 1 for n < 2^32: one correction.
     const uint32_t perM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xffffffffu/per));
-    const uint32_t KbM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xffffffffu/Kb));
 
     // static ranges: workgroup b -> the b-th contiguous piece of the items; its waves share it through an LDS cursor
     const uint32_t chunk = (total + gridDim.x - 1u)/gridDim.x;
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     GlobalF4 mnodes = nullptr;
     GlobalF4 mtris = nullptr;
     uint32_t topBase = 0, topN = 0;     // this lane's tree: refs < topN are staged at s_top[(topBase + ref)*4 ..]
+    uint32_t pend = 0;                  // (several walked primitives) bit kb: this lane's ray enters walked primitive kb's box and has not walked it yet
     bool finiteAll = true;              // wave-uniform: every active lane's 1/d is finite
     bool exhausted = bbeg >= end;       // wave-uniform: the workgroup's range has been handed out
     TN_WP_DECL
@@ -232,15 +238,23 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
         // ---- refill: idle lanes take the next items of the workgroup's range ---------------------------------
         const unsigned long long idleMask = __ballot(!active);
         const int nIdle = __popcll(idleMask);
-        if (!exhausted && nIdle >= job.refillMin)
+        // idle lanes whose ray has primitives left go on with it; the others take new items
+        const unsigned long long newMask = SINGLE ? idleMask : __ballot(!active && pend == 0u);
+        const bool anyCont = !SINGLE && newMask != idleMask;
+        if ((!exhausted || anyCont) && nIdle >= job.refillMin)
         {
             TN_WP_COUNT(6, 1)
             TN_WP_COUNT(11, nIdle)
-            uint32_t cur = 0;
-            if (lane == 0)
-                cur = atomicAdd(&s_ctl[0], (uint32_t)nIdle);        // LDS atomic: one per refill
-            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-            exhausted = cur + (uint32_t)nIdle >= end;
+            const int nNew = __popcll(newMask);
+            uint32_t cur = end;
+            if (!exhausted)
+            {
+                cur = 0;
+                if (lane == 0)
+                    cur = atomicAdd(&s_ctl[0], (uint32_t)nNew);         // LDS atomic: one per refill
+                cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                exhausted = cur + (uint32_t)nNew >= end;
+            }
             if (!active)
             {
                 // A finished ray's record is written HERE, next to the loads of the lane's next ray, not where the ray
@@ -259,17 +273,33 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     }
                     *s_item = kNoItem;
                 }
-                // (set bits of the idle mask below this lane: v_mbcnt, no per-lane 64-bit mask kept in registers)
-                const uint32_t my = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
-                if (my < end)
+                // the lane's ray: the one it still has primitives for, or the next item of the range
+                // (set bits of the mask below this lane: v_mbcnt, no per-lane 64-bit mask kept in registers)
+                const bool cont = !SINGLE && pend != 0u;
+                uint32_t slot = 0, k = 0;
+                bool have = cont;
+                if (cont)
                 {
-                    uint32_t qi = __umulhi(my, perM), rem = my - qi*per;
-                    if (rem >= per) { ++qi; rem -= per; }
-                    uint32_t k = __umulhi(rem, KbM), kb = rem - k*Kb;
-                    if (kb >= Kb) { ++k; kb -= Kb; }
-                    const uint32_t slot = job.queue[qi];
-                    const uint32_t recAt = slot*per + rem;      // records are indexed by position, like everything the scan kernels read
-
+                    const uint32_t sk = *s_ray;
+                    slot = sk & 0x07ffffffu;
+                    k = sk >> 27;
+                }
+                else
+                {
+                    const uint32_t my = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(newMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)newMask, 0u));
+                    if (my < end)
+                    {
+                        uint32_t qi = __umulhi(my, perM);
+                        k = my - qi*per;
+                        if (k >= per) { ++qi; k -= per; }
+                        slot = job.queue[qi];
+                        have = true;
+                        if (!SINGLE)
+                            *s_ray = slot | (k << 27);
+                    }
+                }
+                if (have)
+                {
                     float4 ro, rd;
                     float time;
                     if (job.neePerPath > 0)
@@ -285,43 +315,67 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         time = ro.w;
                     }
                     const V3 wo(ro.x, ro.y, ro.z), wd(rd.x, rd.y, rd.z);
-
-                    int index = job.prim[0];
-                    uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
-                    if (!SINGLE)
-                    {
-#pragma unroll
-                        for (int q = 1; q < kWalkMaxPrims; ++q)
-                        {
-                            if ((uint32_t)q == kb)
-                            {
-                                index = job.prim[q];
-                                tb = run;
-                                tn = (uint32_t)job.topCount[q];
-                            }
-                            run += (uint32_t)job.topCount[q];
-                        }
-                    }
-
-                    // the leaf-box test of the scan (trace_flat / the scene BVH walk): same function, same operands
-                    float4 b0 = box0a, b1 = box0b;
-                    if (!single)
-                    {
-                        const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + index);
-                        b0 = bp[0]; b1 = bp[1];
-                    }
                     const V3 wrcp = rcp3_cr(wd);
-                    float tbox;
-                    bool enters = true;         // rays the scan does not box-test (ray_sane) are walked unconditionally
-                    if (__float_as_uint(b1.z) == 0u && ray_sane(wo))
-                        enters = ray_aabb(wo, wrcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tbox);
 
-                    if (!enters)
+                    // which walked primitives does the ray enter?  The leaf-box test of the scan (trace_flat / the scene BVH walk): same
+                    // function, same operands; rays the scan does not box-test (ray_sane) are walked unconditionally.  A primitive whose
+                    // box the ray misses gets no record: the scan kernels read one only behind the same test.
+                    bool enters = true;
+                    if (SINGLE)
                     {
-                        job.rec[(size_t)recAt*2] = make_float4(kFltMax, 0.0f, 0.0f, 0.0f);
+                        float tbox;
+                        if (__float_as_uint(box0b.z) == 0u && ray_sane(wo))
+                            enters = ray_aabb(wo, wrcp, box0a.x, box0a.y, box0a.z, box0a.w, box0b.x, box0b.y, tbox);
                     }
                     else
                     {
+                        if (!cont)
+                        {
+                            const bool sane = ray_sane(wo);
+                            pend = 0u;
+#pragma unroll
+                            for (int q = 0; q < kWalkMaxPrims; ++q)
+                            {
+                                if (q < job.numPrims)
+                                {
+                                    const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + job.prim[q]);     // (wave-uniform)
+                                    const float4 b0 = bp[0], b1 = bp[1];
+                                    float tbox;
+                                    bool in = true;
+                                    if (__float_as_uint(b1.z) == 0u && sane)
+                                        in = ray_aabb(wo, wrcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tbox);
+                                    pend |= in ? (1u << q) : 0u;
+                                }
+                            }
+                        }
+                        enters = pend != 0u;
+                    }
+
+                    if (enters)
+                    {
+                        // the primitive to walk now: the lowest one left
+                        uint32_t kb = 0;
+                        if (!SINGLE)
+                        {
+                            kb = (uint32_t)__builtin_ctz(pend);
+                            pend &= pend - 1u;
+                        }
+                        int index = job.prim[0];
+                        uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
+                        if (!SINGLE)
+                        {
+#pragma unroll
+                            for (int q = 1; q < kWalkMaxPrims; ++q)
+                            {
+                                if ((uint32_t)q == kb)
+                                {
+                                    index = job.prim[q];
+                                    tb = run;
+                                    tn = (uint32_t)job.topCount[q];
+                                }
+                                run += (uint32_t)job.topCount[q];
+                            }
+                        }
                         // PrimitiveIntersect's mesh branch up to IntersectRayMesh (intersection.h:977-990)
                         Prim64 p = prim0;
                         if (!single)
@@ -351,7 +405,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         sp = 0;
                         closestT = kFltMax;
                         htri = -1;
-                        *s_item = recAt;
+                        *s_item = (slot*per + k)*Kb + kb;       // records are indexed by position, like everything the scan kernels read
                     }
                 }
             }
@@ -362,7 +416,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 
         if (__ballot(active) == 0ull)
         {
-            if (exhausted)
+            // nobody walks: done when the range is handed out and no lane has a primitive left; else the idle lanes refill at the next turn
+            if (exhausted && (SINGLE || __ballot(pend != 0u) == 0ull))
                 break;
             continue;
         }
