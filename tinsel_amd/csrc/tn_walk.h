@@ -131,7 +131,8 @@ TN_D V3 hit_normal(GlobalF4 tris, int tri, float sign)
 // several walked primitives -- the ray itself as slot | k << 27, for the primitives it still has to visit),
 // then 16 control words, then the staged tree tops.
 constexpr int kWalkCtlWords = 16;
-constexpr int kWalkLaneRows = 3;
+constexpr int kWalkLaneRows = 3;        // (two where ONE primitive is walked: kWalkSingle has no use for row 2)
+constexpr int walk_lane_rows(bool single) { return single ? 2 : kWalkLaneRows; }
 
 template <int BLOCK, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     uint32_t* const s_item = s_walk + job.stackEntries*BLOCK + threadIdx.x;                 // kNoItem: no finished ray's record waits in this lane's registers
     float* const s_stop = reinterpret_cast<float*>(s_walk + (job.stackEntries + 1)*BLOCK + threadIdx.x);    // shadow rays: an accepted hit closer than this ends the walk
     uint32_t* const s_ray = s_walk + (job.stackEntries + 2)*BLOCK + threadIdx.x;            // several walked primitives: the lane's ray (slot | k << 27: the host checks the ranges) while primitives are left
-    uint32_t* const s_ctl = s_walk + (job.stackEntries + kWalkLaneRows)*BLOCK;              // [0] the workgroup's cursor
+    uint32_t* const s_ctl = s_walk + (job.stackEntries + walk_lane_rows(SINGLE))*BLOCK;     // [0] the workgroup's cursor
     WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_ctl + kWalkCtlWords);
 
     const int lane = (int)__lane_id();
