@@ -164,6 +164,8 @@ def _kernel_key(name):
         return "k_accumulate"
     if k in ("k_seg_prefix", "k_seg_expand", "k_seg_expand_all", "k_region_order"):
         return "k_seg"
+    if k == "k_walk_rays":                  # several walked primitives: the same timer
+        return "k_walk"
     if k == "k_swalk":                      # the scene-level walk stands in for k_extend / k_shadow (its first template argument: shadow rays)
         return "k_shadow" if targs.startswith("<true") else "k_extend"
     if k == "k_shade_sorted":

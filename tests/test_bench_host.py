@@ -37,6 +37,7 @@ def test_profiler_kernel_names_map_to_the_timers_names():
     import bench
     K = bench._kernel_key
     assert K("void tn::k_walk<1024, 8, 2>(tn::DevScene, tn::WalkJob)") == "k_walk"
+    assert K("void tn::k_walk_rays<1024, 8>(tn::DevScene, tn::WalkJob)") == "k_walk"
     assert K("void tn::k_accumulate_tiled<4, 256>(tn::PathState, ...)") == "k_accumulate"
     assert K("tn::k_seg_prefix(unsigned int const*, ...)") == "k_seg" and K("tn::k_seg_expand_all(...)") == "k_seg" and K("tn::k_region_order(...)") == "k_seg"
     assert K("void tn::k_swalk<false, 1024, 1>(...)") == "k_extend" and K("void tn::k_swalk<true, 1024, 1>(...)") == "k_shadow"

@@ -58,7 +58,7 @@ def test_the_library_carries_no_foreign_kernels():
 
 def test_the_walk_kernels_keep_eight_waves_per_simd():
     k = _resources()
-    for n in ("k_walk<1024,8,2>", "k_walk<1024,8,0>"):                  # one walked primitive / several (the defaults)
+    for n in ("k_walk<1024,8,2>", "k_walk_rays<1024,8>"):               # one walked primitive / several (the defaults)
         assert k[n]["waves_per_simd"] == 8 and k[n]["vgprs"] <= 64 and k[n]["scratch_bytes"] == 0, (n, k[n])
     for n in (m for m in k if m.startswith("k_swalk<")):
         assert k[n]["scratch_bytes"] == 0 and k[n]["waves_per_simd"] >= 5, (n, k[n])

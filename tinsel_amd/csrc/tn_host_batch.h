@@ -391,11 +391,11 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     job.stackEntries = ldsEntries;
     job.overflow = nullptr;
     job.overflowEntries = 0;
-    const size_t stackBig = (size_t)(ldsEntries + walk_lane_rows(a.walkSingle != 0))*1024*sizeof(uint32_t);     // (+ the per-lane rows, tn_walk.h)
+    const size_t stackBig = (size_t)(ldsEntries + (a.walkSingle ? kWalkLaneRows : kWalkRayRows))*1024*sizeof(uint32_t);     // (+ the per-lane rows, tn_walk.h)
     const size_t ldsBudget = twoPerCU ? (size_t)r->sharedMemLimit/2 : (size_t)r->sharedMemLimit;
     const bool big = forceBlock ? forceBlock == 1024 : stackBig + ctl + 16384 <= ldsBudget;
     const int block = big ? 1024 : 256;
-    size_t lds = (size_t)(ldsEntries + walk_lane_rows(a.walkSingle != 0))*block*sizeof(uint32_t) + ctl;
+    size_t lds = (size_t)(ldsEntries + (a.walkSingle ? kWalkLaneRows : kWalkRayRows))*block*sizeof(uint32_t) + ctl;
     if (big)
     {
         // what is left of the CU's LDS goes to the tree tops, in primitive order

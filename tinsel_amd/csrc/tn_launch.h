@@ -37,7 +37,7 @@ struct LaunchArgs
     SwalkJob swalk;                 // PK_SWALK_*
     int swalkMode;                  // PK_SWALK_*: 0 = 256-thread workgroups, generic pointers; 1 / 2 = 1024-thread workgroups, arena in LDS (2: meshes in HBM too)
     int walkBig;                    // PK_WALK: 1 = 1024-thread workgroups with an LDS-resident tree top (2: two of them per CU, short LDS stacks), 0 = 256-thread ones
-    int walkSingle;                 // PK_WALK: ONE walked primitive: the kWalkSingle variant (tn_walk.h)
+    int walkSingle;                 // PK_WALK: ONE walked primitive: k_walk<.., kWalkSingle>; else k_walk_rays (tn_walk.h)
     int shadeSorted;                // PK_SHADE: k_shade_sorted (paths taken class by class) instead of k_shade
     int lightsInExtend;             // PK_EXTEND, arena staged + meshes in HBM: the variant that draws the light samples too (A/B)
     int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
@@ -139,13 +139,16 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
 #undef TN_LAUNCH_SWALK
         break;
     case PK_WALK:
-#define TN_LAUNCH_WALK(MODE)                                                                                           \
+        // ONE walked primitive: k_walk (its tree as kernel-argument scalars); several: k_walk_rays (a work item is a ray)
+#define TN_LAUNCH_WALK(KERNEL, ...)                                                                                    \
         do {                                                                                                           \
-            if (a.walkBig == 2) hipLaunchKernelGGL((k_walk<1024, 8, MODE>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk); \
-            else if (a.walkBig) hipLaunchKernelGGL((k_walk<1024, 4, MODE>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk); \
-            else hipLaunchKernelGGL((k_walk<256, 5, MODE>), grid, dim3(256), a.ldsBytes, st, a.scene, a.walk);            \
+            if (a.walkBig == 2) hipLaunchKernelGGL((KERNEL<1024, 8 __VA_ARGS__>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk); \
+            else if (a.walkBig) hipLaunchKernelGGL((KERNEL<1024, 4 __VA_ARGS__>), grid, dim3(1024), a.ldsBytes, st, a.scene, a.walk); \
+            else hipLaunchKernelGGL((KERNEL<256, 5 __VA_ARGS__>), grid, dim3(256), a.ldsBytes, st, a.scene, a.walk);      \
         } while (0)
-        if (a.walkSingle) TN_LAUNCH_WALK(kWalkSingle); else TN_LAUNCH_WALK(0);
+#define TN_COMMA ,
+        if (a.walkSingle) TN_LAUNCH_WALK(k_walk, TN_COMMA kWalkSingle); else TN_LAUNCH_WALK(k_walk_rays, );
+#undef TN_COMMA
 #undef TN_LAUNCH_WALK
         break;
     default:
@@ -185,7 +188,7 @@ inline PrepReport prepare_path_kernels(int sharedMemLimit)
         rep.segPrefixLds = seg.refused ? (sharedMemLimit < 65536 ? sharedMemLimit : 65536) - 1024 : sharedMemLimit - 1024;
         if (seg.refused) { rep.refused += 1; rep.first = rep.first ? rep.first : "k_seg_prefix"; }
     }
-    TN_PREP(k_walk<1024, 4, 0>); TN_PREP(k_walk<1024, 8, 0>); TN_PREP(k_walk<256, 5, 0>);
+    TN_PREP(k_walk_rays<1024, 4>); TN_PREP(k_walk_rays<1024, 8>); TN_PREP(k_walk_rays<256, 5>);
     TN_PREP(k_walk<1024, 4, kWalkSingle>); TN_PREP(k_walk<1024, 8, kWalkSingle>); TN_PREP(k_walk<256, 5, kWalkSingle>);
     TN_PREP(k_shade_sorted<true, true>); TN_PREP(k_shade_sorted<true>); TN_PREP(k_shade_sorted<false>);
     TN_PREP(k_swalk<false, 1024, 1>); TN_PREP(k_swalk<false, 1024, 2>); TN_PREP(k_swalk<false, 256, 0>);

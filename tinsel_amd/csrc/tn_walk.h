@@ -1,4 +1,5 @@
-// tn_walk.h -- k_walk: the closest-hit walk of meshes that live in HBM, as its own lean streaming kernel.
+// tn_walk.h -- k_walk / k_walk_rays: the closest-hit walk of meshes that live in HBM, as its own lean streaming kernel (k_walk: ONE walked
+// primitive, its tree as kernel-argument scalars; k_walk_rays, at the end of the file: several, a work item is a ray).
 //
 // Why a kernel of its own.  The scan kernels (k_extend / k_shadow, tn_kernels.h) carry the whole scene-level
 // state of Trace() (render.cpp:17-62) around the mesh walk of IntersectRayMesh (intersection.h:661-749): 128
@@ -127,17 +128,16 @@ TN_D V3 hit_normal(GlobalF4 tris, int tri, float sign)
 }
 
 // LDS of one workgroup: [stackEntries][BLOCK] stack words, [kWalkLaneRows][BLOCK] per-lane words that are touched once or twice per
-// RAY and have no business in a register of a 64-VGPR kernel (row 0: the ray's record index, row 1: a shadow ray's stop distance, row 2 --
-// several walked primitives -- the ray itself as slot | k << 27, for the primitives it still has to visit),
+// RAY and have no business in a register of a 64-VGPR kernel (row 0: the ray's record index, row 1: a shadow ray's stop distance),
 // then 16 control words, then the staged tree tops.
 constexpr int kWalkCtlWords = 16;
-constexpr int kWalkLaneRows = 3;        // (two where ONE primitive is walked: kWalkSingle has no use for row 2)
-constexpr int walk_lane_rows(bool single) { return single ? 2 : kWalkLaneRows; }
+constexpr int kWalkLaneRows = 2;
 
 template <int BLOCK, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 {
     constexpr bool SINGLE = (MODE & kWalkSingle) != 0;
+    static_assert(SINGLE, "k_walk is instantiated for ONE walked primitive only: several go through k_walk_rays (below)");
     constexpr uint32_t kAtLeaf = kLeafBit;      // refs that wait for the triangle phase
     extern __shared__ __attribute__((aligned(16))) uint32_t s_walk[];
     uint32_t* const stack = s_walk + threadIdx.x;               // this lane's column: entry i at stack[i*BLOCK]
@@ -147,23 +147,19 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     const int ldsEntries = job.stackEntries;
     uint32_t* const s_item = s_walk + job.stackEntries*BLOCK + threadIdx.x;                 // kNoItem: no finished ray's record waits in this lane's registers
     float* const s_stop = reinterpret_cast<float*>(s_walk + (job.stackEntries + 1)*BLOCK + threadIdx.x);    // shadow rays: an accepted hit closer than this ends the walk
-    uint32_t* const s_ray = s_walk + (job.stackEntries + 2)*BLOCK + threadIdx.x;            // several walked primitives: the lane's ray (slot | k << 27: the host checks the ranges) while primitives are left
-    uint32_t* const s_ctl = s_walk + (job.stackEntries + walk_lane_rows(SINGLE))*BLOCK;     // [0] the workgroup's cursor
+    uint32_t* const s_ctl = s_walk + (job.stackEntries + kWalkLaneRows)*BLOCK;              // [0] the workgroup's cursor
     WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_ctl + kWalkCtlWords);
 
     const int lane = (int)__lane_id();
     const uint32_t Kx = job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
     const uint32_t Kb = (uint32_t)job.numPrims;
-    // A work item is a RAY (slot, k).  With several walked primitives the lane that takes it tests all their leaf boxes once -- the records
-    // are wave-uniform -- and walks the ones the ray enters one after the other (`pend`: a bit per primitive still to visit).  (Until round 5
-    // an item was a (ray, primitive) pair: glass fetched every ray twice, the reference's table.tin -- seven walked meshes -- seven times,
-    // to find five or six of the seven boxes missed.)
-    const uint32_t per = Kx;                                    // work items per queued slot
+    const uint32_t per = Kx*Kb;                                 // work items per queued slot
     const uint32_t total = (*job.frontCount)*per;
     // my/per and rem/Kb below: both divisors are wave-uniform, so the reciprocals live in SGPRs (the compiler's own expansion kept two
     // VGPR reciprocals across the loop, spilled them, and reloaded them in every refill behind an s_waitcnt vmcnt(0) -- i.e. behind the
     // finished rays' record stores).  q' = mulhi(n, floor((2^32-1)/d)) is q or q - 1 for n < 2^32: one correction.
     const uint32_t perM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xffffffffu/per));
+    const uint32_t KbM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xffffffffu/Kb));
 
     // static ranges: workgroup b -> the b-th contiguous piece of the items; its waves share it through an LDS cursor
     const uint32_t chunk = (total + gridDim.x - 1u)/gridDim.x;
@@ -227,7 +223,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     GlobalF4 mnodes = nullptr;
     GlobalF4 mtris = nullptr;
     uint32_t topBase = 0, topN = 0;     // this lane's tree: refs < topN are staged at s_top[(topBase + ref)*4 ..]
-    uint32_t pend = 0;                  // (several walked primitives) bit kb: this lane's ray enters walked primitive kb's box and has not walked it yet
     bool finiteAll = true;              // wave-uniform: every active lane's 1/d is finite
     bool exhausted = bbeg >= end;       // wave-uniform: the workgroup's range has been handed out
     TN_WP_DECL
@@ -239,23 +234,15 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
         // ---- refill: idle lanes take the next items of the workgroup's range ---------------------------------
         const unsigned long long idleMask = __ballot(!active);
         const int nIdle = __popcll(idleMask);
-        // idle lanes whose ray has primitives left go on with it; the others take new items
-        const unsigned long long newMask = SINGLE ? idleMask : __ballot(!active && pend == 0u);
-        const bool anyCont = !SINGLE && newMask != idleMask;
-        if ((!exhausted || anyCont) && nIdle >= job.refillMin)
+        if (!exhausted && nIdle >= job.refillMin)
         {
             TN_WP_COUNT(6, 1)
             TN_WP_COUNT(11, nIdle)
-            const int nNew = __popcll(newMask);
-            uint32_t cur = end;
-            if (!exhausted)
-            {
-                cur = 0;
-                if (lane == 0)
-                    cur = atomicAdd(&s_ctl[0], (uint32_t)nNew);         // LDS atomic: one per refill
-                cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-                exhausted = cur + (uint32_t)nNew >= end;
-            }
+            uint32_t cur = 0;
+            if (lane == 0)
+                cur = atomicAdd(&s_ctl[0], (uint32_t)nIdle);        // LDS atomic: one per refill
+            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+            exhausted = cur + (uint32_t)nIdle >= end;
             if (!active)
             {
                 // A finished ray's record is written HERE, next to the loads of the lane's next ray, not where the ray
@@ -274,33 +261,17 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     }
                     *s_item = kNoItem;
                 }
-                // the lane's ray: the one it still has primitives for, or the next item of the range
-                // (set bits of the mask below this lane: v_mbcnt, no per-lane 64-bit mask kept in registers)
-                const bool cont = !SINGLE && pend != 0u;
-                uint32_t slot = 0, k = 0;
-                bool have = cont;
-                if (cont)
+                // (set bits of the idle mask below this lane: v_mbcnt, no per-lane 64-bit mask kept in registers)
+                const uint32_t my = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+                if (my < end)
                 {
-                    const uint32_t sk = *s_ray;
-                    slot = sk & 0x07ffffffu;
-                    k = sk >> 27;
-                }
-                else
-                {
-                    const uint32_t my = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(newMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)newMask, 0u));
-                    if (my < end)
-                    {
-                        uint32_t qi = __umulhi(my, perM);
-                        k = my - qi*per;
-                        if (k >= per) { ++qi; k -= per; }
-                        slot = job.queue[qi];
-                        have = true;
-                        if (!SINGLE)
-                            *s_ray = slot | (k << 27);
-                    }
-                }
-                if (have)
-                {
+                    uint32_t qi = __umulhi(my, perM), rem = my - qi*per;
+                    if (rem >= per) { ++qi; rem -= per; }
+                    uint32_t k = __umulhi(rem, KbM), kb = rem - k*Kb;
+                    if (kb >= Kb) { ++k; kb -= Kb; }
+                    const uint32_t slot = job.queue[qi];
+                    const uint32_t recAt = slot*per + rem;      // records are indexed by position, like everything the scan kernels read
+
                     float4 ro, rd;
                     float time;
                     if (job.neePerPath > 0)
@@ -316,67 +287,43 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         time = ro.w;
                     }
                     const V3 wo(ro.x, ro.y, ro.z), wd(rd.x, rd.y, rd.z);
-                    const V3 wrcp = rcp3_cr(wd);
 
-                    // which walked primitives does the ray enter?  The leaf-box test of the scan (trace_flat / the scene BVH walk): same
-                    // function, same operands; rays the scan does not box-test (ray_sane) are walked unconditionally.  A primitive whose
-                    // box the ray misses gets no record: the scan kernels read one only behind the same test.
-                    bool enters = true;
-                    if (SINGLE)
+                    int index = job.prim[0];
+                    uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
+                    if (!SINGLE)
                     {
-                        float tbox;
-                        if (__float_as_uint(box0b.z) == 0u && ray_sane(wo))
-                            enters = ray_aabb(wo, wrcp, box0a.x, box0a.y, box0a.z, box0a.w, box0b.x, box0b.y, tbox);
+#pragma unroll
+                        for (int q = 1; q < kWalkMaxPrims; ++q)
+                        {
+                            if ((uint32_t)q == kb)
+                            {
+                                index = job.prim[q];
+                                tb = run;
+                                tn = (uint32_t)job.topCount[q];
+                            }
+                            run += (uint32_t)job.topCount[q];
+                        }
+                    }
+
+                    // the leaf-box test of the scan (trace_flat / the scene BVH walk): same function, same operands
+                    float4 b0 = box0a, b1 = box0b;
+                    if (!single)
+                    {
+                        const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + index);
+                        b0 = bp[0]; b1 = bp[1];
+                    }
+                    const V3 wrcp = rcp3_cr(wd);
+                    float tbox;
+                    bool enters = true;         // rays the scan does not box-test (ray_sane) are walked unconditionally
+                    if (__float_as_uint(b1.z) == 0u && ray_sane(wo))
+                        enters = ray_aabb(wo, wrcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tbox);
+
+                    if (!enters)
+                    {
+                        job.rec[(size_t)recAt*2] = make_float4(kFltMax, 0.0f, 0.0f, 0.0f);
                     }
                     else
                     {
-                        if (!cont)
-                        {
-                            const bool sane = ray_sane(wo);
-                            pend = 0u;
-#pragma unroll
-                            for (int q = 0; q < kWalkMaxPrims; ++q)
-                            {
-                                if (q < job.numPrims)
-                                {
-                                    const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + job.prim[q]);     // (wave-uniform)
-                                    const float4 b0 = bp[0], b1 = bp[1];
-                                    float tbox;
-                                    bool in = true;
-                                    if (__float_as_uint(b1.z) == 0u && sane)
-                                        in = ray_aabb(wo, wrcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tbox);
-                                    pend |= in ? (1u << q) : 0u;
-                                }
-                            }
-                        }
-                        enters = pend != 0u;
-                    }
-
-                    if (enters)
-                    {
-                        // the primitive to walk now: the lowest one left
-                        uint32_t kb = 0;
-                        if (!SINGLE)
-                        {
-                            kb = (uint32_t)__builtin_ctz(pend);
-                            pend &= pend - 1u;
-                        }
-                        int index = job.prim[0];
-                        uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
-                        if (!SINGLE)
-                        {
-#pragma unroll
-                            for (int q = 1; q < kWalkMaxPrims; ++q)
-                            {
-                                if ((uint32_t)q == kb)
-                                {
-                                    index = job.prim[q];
-                                    tb = run;
-                                    tn = (uint32_t)job.topCount[q];
-                                }
-                                run += (uint32_t)job.topCount[q];
-                            }
-                        }
                         // PrimitiveIntersect's mesh branch up to IntersectRayMesh (intersection.h:977-990)
                         Prim64 p = prim0;
                         if (!single)
@@ -406,7 +353,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         sp = 0;
                         closestT = kFltMax;
                         htri = -1;
-                        *s_item = (slot*per + k)*Kb + kb;       // records are indexed by position, like everything the scan kernels read
+                        *s_item = recAt;
                     }
                 }
             }
@@ -417,8 +364,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 
         if (__ballot(active) == 0ull)
         {
-            // nobody walks: done when the range is handed out and no lane has a primitive left; else the idle lanes refill at the next turn
-            if (exhausted && (SINGLE || __ballot(pend != 0u) == 0ull))
+            if (exhausted)
                 break;
             continue;
         }
@@ -540,5 +486,378 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     TN_WP_FLUSH
 #undef active
 }
+
+// ---------------------------------------------------------------------------
+// k_walk_rays: SEVERAL walked primitives.  The same walk; a work item is a RAY (slot, k): the lane that takes it tests all walked primitives'
+// leaf boxes once -- the records are wave-uniform -- and walks the ones the ray enters one after the other (`pend`: a bit per primitive still
+// to visit; the ray itself parked in an LDS row as position | k << 27).  Until round 5 an item was a (ray, primitive) pair through k_walk's
+// MODE 0: glass fetched every ray twice, the reference's table.tin -- seven walked meshes -- seven times, to find most of the boxes missed
+// (table.tin 690 -> 896 Msamples/s, transmission.tin 654 -> 815, glass k_walk 6.67 -> 5.91 ms: profiles/r05_e_ab_walk_by_ray.md).  A kernel of
+// its own, not a mode of k_walk: written as one template, the one-primitive kernel of the 524k-triangle config came out 4-8 % slower with an
+// identical node phase (profiles/r05_g_ab_walk_single_refill.md) -- its source is left exactly as rounds 3-4 tuned it.
+constexpr int kWalkRayRows = 3;         // k_walk's two per-lane LDS rows + the ray
+
+template <int BLOCK, int WAVES>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob job)
+{
+    constexpr uint32_t kAtLeaf = kLeafBit;      // refs that wait for the triangle phase
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_walk[];
+    uint32_t* const stack = s_walk + threadIdx.x;               // this lane's column: entry i at stack[i*BLOCK]
+    // a SHORT LDS stack leaves room for a second workgroup per CU (8 waves per SIMD at 64 VGPRs): the rare entries beyond it
+    // live in HBM, a column per lane of the grid
+    uint32_t* const spill = job.overflow ? job.overflow + ((size_t)blockIdx.x*BLOCK + threadIdx.x)*(size_t)job.overflowEntries : nullptr;
+    const int ldsEntries = job.stackEntries;
+    uint32_t* const s_item = s_walk + job.stackEntries*BLOCK + threadIdx.x;                 // kNoItem: no finished ray's record waits in this lane's registers
+    float* const s_stop = reinterpret_cast<float*>(s_walk + (job.stackEntries + 1)*BLOCK + threadIdx.x);    // shadow rays: an accepted hit closer than this ends the walk
+    uint32_t* const s_ray = s_walk + (job.stackEntries + 2)*BLOCK + threadIdx.x;            // several walked primitives: the lane's ray (slot | k << 27: the host checks the ranges) while primitives are left
+    uint32_t* const s_ctl = s_walk + (job.stackEntries + kWalkRayRows)*BLOCK;               // [0] the workgroup's cursor
+    WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_ctl + kWalkCtlWords);
+
+    const int lane = (int)__lane_id();
+    const uint32_t Kx = job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
+    const uint32_t Kb = (uint32_t)job.numPrims;
+    // A work item is a RAY (slot, k).  With several walked primitives the lane that takes it tests all their leaf boxes once -- the records
+    // are wave-uniform -- and walks the ones the ray enters one after the other (`pend`: a bit per primitive still to visit).  (Until round 5
+    // an item was a (ray, primitive) pair: glass fetched every ray twice, the reference's table.tin -- seven walked meshes -- seven times,
+    // to find five or six of the seven boxes missed.)
+    const uint32_t per = Kx;                                    // work items per queued slot
+    const uint32_t total = (*job.frontCount)*per;
+    // my/per and rem/Kb below: both divisors are wave-uniform, so the reciprocals live in SGPRs (the compiler's own expansion kept two
+    // VGPR reciprocals across the loop, spilled them, and reloaded them in every refill behind an s_waitcnt vmcnt(0) -- i.e. behind the
+    // finished rays' record stores).  q' = mulhi(n, floor((2^32-1)/d)) is q or q - 1 for n < 2^32: one correction.
+    const uint32_t perM = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xffffffffu/per));
+
+    // static ranges: workgroup b -> the b-th contiguous piece of the items; its waves share it through an LDS cursor
+    const uint32_t chunk = (total + gridDim.x - 1u)/gridDim.x;
+    const uint32_t bbeg = blockIdx.x*chunk < total ? blockIdx.x*chunk : total;
+    const uint32_t end = (bbeg + chunk) < total ? (bbeg + chunk) : total;
+    if (threadIdx.x == 0)
+        s_ctl[0] = bbeg;
+    *s_item = 0xffffffffu;
+    *s_stop = -kFltMax;                 // (never, for extension rays)
+
+    // stage the tops of the walked trees (a workgroup with nothing to do skips it)
+    if (bbeg < end)
+    {
+        uint32_t base = 0;
+#pragma unroll 1
+        for (int kb = 0; kb < job.numPrims; ++kb)
+        {
+            int primIndex = job.prim[0], n = job.topCount[0];
+#pragma unroll
+            for (int q = 1; q < kWalkMaxPrims; ++q)
+                if (q == kb) { primIndex = job.prim[q]; n = job.topCount[q]; }
+            if (n > 0)
+            {
+                const Prim64 p = load_prim(sc.prims, primIndex);
+                GlobalF4 src = as_global(sc.meshes[p.mesh].nodes);
+                WalkF4* dst = s_top + (size_t)base*4;
+                for (uint32_t i = threadIdx.x; i < (uint32_t)n*4u; i += BLOCK)
+                    dst[i] = src[i];
+                base += (uint32_t)n;
+            }
+        }
+    }
+    __syncthreads();
+
+    // per-lane walk state
+    // (no flags: a lane is ACTIVE iff ref != kNoNode; a finished ray's record is PENDING in its registers iff *s_item != kNoItem)
+    constexpr uint32_t kNoItem = 0xffffffffu;
+    uint32_t ref = kNoNode;
+#define active (ref != kNoNode)
+    int sp = 0;
+    V3 o, d, rcp;
+    float closestT = kFltMax;
+    float hv = 0.0f, hw = 0.0f;         // (u = 1 - v - w is recomputed where the record is written: IntersectRayTriTwoSided's own expression)
+    int htri = -1;
+    float hsign = 0.0f;                 // the hit's `sign` (IntersectRayTriTwoSided's d): its normal n*sign is formed where the record is written
+    GlobalF4 mnodes = nullptr;
+    GlobalF4 mtris = nullptr;
+    uint32_t topBase = 0, topN = 0;     // this lane's tree: refs < topN are staged at s_top[(topBase + ref)*4 ..]
+    uint32_t pend = 0;                  // (several walked primitives) bit kb: this lane's ray enters walked primitive kb's box and has not walked it yet
+    bool finiteAll = true;              // wave-uniform: every active lane's 1/d is finite
+    bool exhausted = bbeg >= end;       // wave-uniform: the workgroup's range has been handed out
+    TN_WP_DECL
+
+    for (;;)
+    {
+        TN_WP_TICK(4)
+        TN_WP_COUNT(5, 1)
+        // ---- refill: idle lanes take the next items of the workgroup's range ---------------------------------
+        const unsigned long long idleMask = __ballot(!active);
+        const int nIdle = __popcll(idleMask);
+        // idle lanes whose ray has primitives left go on with it; the others take new items
+        const unsigned long long newMask = __ballot(!active && pend == 0u);
+        const bool anyCont = newMask != idleMask;
+        if ((!exhausted || anyCont) && nIdle >= job.refillMin)
+        {
+            TN_WP_COUNT(6, 1)
+            TN_WP_COUNT(11, nIdle)
+            const int nNew = __popcll(newMask);
+            uint32_t cur = end;
+            if (!exhausted)
+            {
+                cur = 0;
+                if (lane == 0)
+                    cur = atomicAdd(&s_ctl[0], (uint32_t)nNew);         // LDS atomic: one per refill
+                cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                exhausted = cur + (uint32_t)nNew >= end;
+            }
+            if (!active)
+            {
+                // A finished ray's record is written HERE, next to the loads of the lane's next ray, not where the ray
+                // ends: stores count against vmcnt like loads on gfx950, so a 32-B record on its way to HBM would sit in
+                // front of every node fetch the wave waits for (measured: node phases of 1900-2800 cycles, 780 when
+                // nothing but LDS reads was outstanding).
+                const uint32_t item = *s_item;
+                if (item != kNoItem)
+                {
+                    float4* out = job.rec + (size_t)item*2;
+                    out[0] = make_float4(closestT, 1.0f - hv - hw, hv, hw);
+                    if (closestT < kFltMax)
+                    {
+                        const V3 hn = hit_normal(mtris, htri, hsign);
+                        out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
+                    }
+                    *s_item = kNoItem;
+                }
+                // the lane's ray: the one it still has primitives for, or the next item of the range
+                // (set bits of the mask below this lane: v_mbcnt, no per-lane 64-bit mask kept in registers)
+                const bool cont = pend != 0u;
+                uint32_t slot = 0, k = 0;
+                bool have = cont;
+                if (cont)
+                {
+                    const uint32_t sk = *s_ray;
+                    slot = sk & 0x07ffffffu;
+                    k = sk >> 27;
+                }
+                else
+                {
+                    const uint32_t my = cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(newMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)newMask, 0u));
+                    if (my < end)
+                    {
+                        uint32_t qi = __umulhi(my, perM);
+                        k = my - qi*per;
+                        if (k >= per) { ++qi; k -= per; }
+                        slot = job.queue[qi];
+                        have = true;
+                        *s_ray = slot | (k << 27);
+                    }
+                }
+                if (have)
+                {
+                    float4 ro, rd;
+                    float time;
+                    if (job.neePerPath > 0)
+                    {
+                        const float4* np = job.nee + (size_t)(k*2u)*job.neeStride + slot;
+                        ro = np[0]; rd = np[job.neeStride];
+                        time = job.neeTime[slot];
+                        *s_stop = shadow_stop(ro.w);    // the record's .w is the sample's distance (< 0: probe sample)
+                    }
+                    else
+                    {
+                        ro = job.rayO[slot]; rd = job.rayD[slot];
+                        time = ro.w;
+                    }
+                    const V3 wo(ro.x, ro.y, ro.z), wd(rd.x, rd.y, rd.z);
+                    const V3 wrcp = rcp3_cr(wd);
+
+                    // which walked primitives does the ray enter?  The leaf-box test of the scan (trace_flat / the scene BVH walk): same
+                    // function, same operands; rays the scan does not box-test (ray_sane) are walked unconditionally.  A primitive whose
+                    // box the ray misses gets no record: the scan kernels read one only behind the same test.
+                    {
+                        if (!cont)
+                        {
+                            const bool sane = ray_sane(wo);
+                            pend = 0u;
+#pragma unroll
+                            for (int q = 0; q < kWalkMaxPrims; ++q)
+                            {
+                                if (q < job.numPrims)
+                                {
+                                    const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + job.prim[q]);     // (wave-uniform)
+                                    const float4 b0 = bp[0], b1 = bp[1];
+                                    float tbox;
+                                    bool in = true;
+                                    if (__float_as_uint(b1.z) == 0u && sane)
+                                        in = ray_aabb(wo, wrcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tbox);
+                                    pend |= in ? (1u << q) : 0u;
+                                }
+                            }
+                        }
+                    }
+
+                    if (pend != 0u)
+                    {
+                        // the primitive to walk now: the lowest one left
+                        const uint32_t kb = (uint32_t)__builtin_ctz(pend);
+                        pend &= pend - 1u;
+                        int index = job.prim[0];
+                        uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
+                        {
+#pragma unroll
+                            for (int q = 1; q < kWalkMaxPrims; ++q)
+                            {
+                                if ((uint32_t)q == kb)
+                                {
+                                    index = job.prim[q];
+                                    tb = run;
+                                    tn = (uint32_t)job.topCount[q];
+                                }
+                                run += (uint32_t)job.topCount[q];
+                            }
+                        }
+                        // PrimitiveIntersect's mesh branch up to IntersectRayMesh (intersection.h:977-990)
+                        const Prim64 p = load_prim(sc.prims, index);
+                        const Xform x = prim_pose(sc, p, time);
+                        pose_inv_ray(p, x, wo, wd, o, d, rcp, &wrcp);
+                        {
+                            const DevMesh* m = sc.meshes + p.mesh;
+                            mnodes = as_global(m->nodes);
+                            mtris = as_global(m->tris);
+                            ref = m->root;
+                        }
+                        topBase = tb;
+                        topN = tn;
+                        sp = 0;
+                        closestT = kFltMax;
+                        htri = -1;
+                        *s_item = (slot*per + k)*Kb + kb;       // records are indexed by position, like everything the scan kernels read
+                    }
+                }
+            }
+            finiteAll = __all(!active || (finite_bits(rcp.x) && finite_bits(rcp.y) && finite_bits(rcp.z) &&
+                                          finite_bits(o.x) && finite_bits(o.y) && finite_bits(o.z)));
+            TN_WP_TICK(0)
+        }
+
+        if (__ballot(active) == 0ull)
+        {
+            // nobody walks: done when the range is handed out and no lane has a primitive left; else the idle lanes refill at the next turn
+            if (exhausted && __ballot(pend != 0u) == 0ull)
+                break;
+            continue;
+        }
+
+        bool pop = false;
+#ifdef TN_WALK_PROF
+        { const unsigned long long nm = __ballot(active && !(ref & kAtLeaf)); if (nm) { TN_WP_COUNT(7, 1) TN_WP_COUNT(9, __popcll(nm)) }
+          TN_WP_COUNT(14, __popcll(__ballot(active && !(ref & kAtLeaf) && ref < topN))) }
+        TN_WP_TICK(4)
+#endif
+
+        // ---- node phase: lanes at an internal node -------------------------------------------------------------
+        if (active && !(ref & kAtLeaf))
+        {
+            Node64 nd;
+            if (ref < topN)
+                nd = load_node_from((const WalkF4*)s_top, topBase + ref);    // 4 x ds_read_b128
+            else
+                nd = load_node_from(mnodes, ref);                     // 4 x global_load_dwordx4
+            float tL, tR;
+            bool hL, hR;
+            if (finiteAll)
+            {
+                hL = ray_aabb_minmax(o, rcp, nd.lminx, nd.lminy, nd.lminz, nd.lmaxx, nd.lmaxy, nd.lmaxz, tL);
+                hR = ray_aabb_minmax(o, rcp, nd.rminx, nd.rminy, nd.rminz, nd.rmaxx, nd.rmaxy, nd.rmaxz, tR);
+            }
+            else
+            {
+                tL = tR = 0.0f;
+                hL = ray_aabb(o, rcp, nd.lminx, nd.lminy, nd.lminz, nd.lmaxx, nd.lmaxy, nd.lmaxz, tL);
+                hR = ray_aabb(o, rcp, nd.rminx, nd.rminy, nd.rminz, nd.rmaxx, nd.rmaxy, nd.rmaxz, tR);
+            }
+            hL = hL && tL < closestT;       // `tLeft < tmax`, tmax == closestT after every leaf (intersection.h:701-702)
+            hR = hR && tR < closestT;
+            const uint32_t refL = nd.left, refR = nd.right;
+
+            if (hL && hR)
+            {
+                // the reference pushes far then near and pops near: the near child continues in a register
+                const bool leftNear = tL < tR;
+                const uint32_t far = leftNear ? refR : refL;
+                if (sp < ldsEntries)
+                    stack[sp*BLOCK] = far;
+                else
+                    spill[sp - ldsEntries] = far;
+                ++sp;
+                ref = leftNear ? refL : refR;
+            }
+            else if (hL)
+                ref = refL;
+            else if (hR)
+                ref = refR;
+            else
+                pop = true;
+        }
+
+        TN_WP_TICK(1)
+        // ---- triangle phase: once enough lanes wait at a leaf (or nobody has a node to visit) -----------------
+        const bool atLeaf = active && !pop && (ref & kAtLeaf);
+        const unsigned long long leafMask = __ballot(atLeaf);
+        if (leafMask != 0ull && (__popcll(leafMask) >= job.leafMin || __ballot(active && !pop && !atLeaf) == 0ull))
+        {
+            TN_WP_COUNT(8, 1)
+            TN_WP_COUNT(10, __popcll(leafMask))
+            if (atLeaf)
+            {
+                // ONE round trip per phase: every lane requests its leaf's Tri48 before anybody waits
+                const uint32_t idx = ref & ~kLeafBit;
+                GlobalF4 tp = mtris + (size_t)idx*3;
+                const WalkF4 q3 = tp[0], q4 = tp[1], q5 = tp[2];
+                bool any = false;
+                {
+                    float t, u, v, w, sign;
+                    V3 n;
+                    if (ray_tri(o, d, V3(q3.x, q3.y, q3.z), V3(q4.x, q4.y, q4.z), V3(q5.x, q5.y, q5.z), t, u, v, w, sign, n))
+                    {
+                        if (t > 0.0f && t < closestT)
+                        {
+                            any = true;
+                            closestT = t;
+                            hv = v; hw = w;
+                            htri = (int)idx;
+                            hsign = sign;
+                        }
+                    }
+                }
+                if (any && closestT < *s_stop)
+                    sp = 0;             // shadow ray decided (shadow_stop, tn_isect.h): drop what is left on the stack
+                pop = true;
+            }
+        }
+
+        TN_WP_TICK(2)
+        // ---- next entry, or the ray is done ---------------------------------------------------------------------
+        if (pop)
+        {
+            if (sp > 0)
+            {
+                --sp;
+                ref = sp < ldsEntries ? stack[sp*BLOCK] : spill[sp - ldsEntries];
+            }
+            else
+            {
+                ref = kNoNode;          // done; the record stays in registers until the lane's next refill (*s_item says which)
+            }
+        }
+        TN_WP_TICK(3)
+    }
+    if (const uint32_t item = *s_item; item != kNoItem)
+    {
+        float4* out = job.rec + (size_t)item*2;
+        out[0] = make_float4(closestT, 1.0f - hv - hw, hv, hw);
+        if (closestT < kFltMax)
+        {
+            const V3 hn = hit_normal(mtris, htri, hsign);
+            out[1] = make_float4(hn.x, hn.y, hn.z, __int_as_float(htri));
+        }
+    }
+    TN_WP_FLUSH
+#undef active
+}
+
 
 } // namespace tn
