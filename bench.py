@@ -355,12 +355,14 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     first_timed_pass = None
     blocks, stats_blocks, ktimes = [], None, {}
     total = 0.0
-    # the kernels' HIP events (two records per launch, on the launch stream) ride in the FIRST timed block only: every record is a barrier
-    # packet of a few microseconds, which a small batch (cfg1: 0.34 ms of kernels) feels -- the median block does not carry them
+    # The kernels' HIP events (two records per launch, on the launch stream) ride in ONE timed block, the LAST: every record is a barrier
+    # packet of a few microseconds, which a small batch (cfg1: 0.32 ms of kernels) feels in every block -- and the first block after the
+    # warm-up runs 10-15 % below the others (clocks), which made its kernel times disagree with rocprofv3's averages of the same command.
     while True:
+        last = total >= MIN_TIMED_S or len(blocks) >= 1000          # (the block after the time is up: the one with the events)
         accum.zero_()
         r.reset_stats()
-        r.enable_kernel_timing(not blocks)
+        r.enable_kernel_timing(last)
         sync()
         if first_timed_pass is None:
             first_timed_pass = r.get_pass_index()
@@ -377,8 +379,8 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         total += elapsed
         if stats_blocks is None:
             stats_blocks = r.stats()
-            ktimes = r.kernel_times()           # of the first timed block's render call
-        if total >= MIN_TIMED_S or len(blocks) >= 1000:
+        if last:
+            ktimes = r.kernel_times()           # of the last timed block's render call
             break
     r.enable_kernel_timing(False)
     elapsed = statistics.median(blocks)
