@@ -772,7 +772,7 @@ int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t ma
 // per CU (kBounceWaves), which is what the grid and the region cut are sized by, also where LDS leaves three (measured: features, above).
 bool plan_bounce(tinsel_hip* r)
 {
-    static const char* repackEnv = getenv("TINSEL_HIP_REPACK");          // 0 / 1: never / always (A/B, tests); default: open scenes
+    const char* repackEnv = getenv("TINSEL_HIP_REPACK");                 // 0 / 1: never / always (A/B, tests: read per call); default: open scenes
     const size_t perCU = 160u*1024u;
     const size_t lds = stack_bytes(r), withPool = lds + kPoolWords*sizeof(uint32_t);
     const bool want = repackEnv ? atoi(repackEnv) != 0 : !r->sceneEnclosed;
