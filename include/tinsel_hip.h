@@ -445,6 +445,11 @@ int tinsel_hip_plan_regions(unsigned long long slots, int num_cus, int nee_per_p
  * out_first_bad: the smallest mismatching bit pattern (0xffffffff when none).  No reference counterpart (test infrastructure
  * of this library: the reference divides with the host FPU / nvcc's IEEE division, render.cpp / maths.h throughout). */
 int tinsel_hip_selftest_arith(int device_index, int op, int variant, unsigned long long* out_counts, unsigned int* out_first_bad);
+/* The library's own stable radix sort and exclusive scan (the device BVH builder's, tinsel_amd/csrc/tn_sort.h) on caller data, for tests:
+ * keys[0, n) sorted in place by their bits [begin_bit, end_bit) (multiples of 8; keys with equal bits keep their order);
+ * out[i] = in[0] + .. + in[i - 1]. */
+int tinsel_hip_selftest_sort(int device_index, unsigned long long* keys, unsigned long long n, int begin_bit, int end_bit);
+int tinsel_hip_selftest_scan(int device_index, const int* in, int* out, unsigned long long n);
 
 /* Yard-sticks measured on the GPU itself, for bench.py's roofline (not part of the render path): kind 0 = a float4 stream
  * copy of `bytes` bytes (*out_units = bytes read + written); kinds 1..3 = dependent chases through a table of 64-B records

@@ -169,3 +169,21 @@ def test_region_cut_invariants_over_the_whole_range_of_batch_sizes():
                         assert big == n, what                       # the split pipeline keeps all regions alike
                     if n > big:                                     # short regions exist: the long ones alone do not cover the batch
                         assert big*L < slots, what
+
+
+def test_division_by_host_reciprocal_is_exact():
+    """tn_kernels.h div_magic (slot_pixel: a path slot -> pass, pixel): n / d as mulhi(n, floor((2^32 - 1) / d)) plus ONE correction, for every
+    n < 2^32 and d >= 1.  The host puts the reciprocals into FrameParams; the kernels never divide.  Checked here on the edges and on two
+    million random pairs (numpy: the same 32-bit arithmetic)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    d = np.concatenate([np.array([1, 2, 3, 7, 64, 4096, 1920, 1080, 1920*1080, 3840*2160, 1 << 20, (1 << 32) - 1], np.uint64),
+                        rng.integers(1, 1 << 32, 200000, dtype=np.uint64), rng.integers(1, 1 << 16, 200000, dtype=np.uint64)])
+    for n in (np.zeros_like(d), d - np.uint64(1), d, np.minimum(d*np.uint64(3) + np.uint64(1), np.uint64((1 << 32) - 1)), np.full_like(d, (1 << 32) - 1),
+              rng.integers(0, 1 << 32, d.size, dtype=np.uint64)):
+        m = np.uint64((1 << 32) - 1)//d
+        q = (n*m) >> np.uint64(32)
+        rem = n - q*d
+        fix = rem >= d
+        q, rem = q + fix.astype(np.uint64), rem - d*fix.astype(np.uint64)
+        assert np.array_equal(q, n//d) and np.array_equal(rem, n % d)

@@ -1060,6 +1060,52 @@ int tinsel_hip_selftest_arith(int device_index, int op, int variant, unsigned lo
     return rc;
 }
 
+// The library's own sort and scan (tn_sort.h: the device BVH builder's) on caller data: keys[0, n) sorted in place by their bits
+// [begin_bit, end_bit) (multiples of 8), keys with equal bits keeping their order; out[i] = in[0] + .. + in[i - 1].
+int tinsel_hip_selftest_sort(int device_index, unsigned long long* keys, unsigned long long n, int begin_bit, int end_bit)
+{
+    if (!keys || n == 0 || n >= (1ull << 31) || begin_bit < 0 || end_bit > 64 || begin_bit >= end_bit || (begin_bit & 7) || (end_bit & 7))
+        return fail("selftest_sort: bad arguments");
+    HIP_TRY(hipSetDevice(device_index));
+    unsigned long long *a = nullptr, *b = nullptr;
+    int* scratch = nullptr;
+    int rc = 0;
+    if (hipMalloc((void**)&a, n*8) != hipSuccess || hipMalloc((void**)&b, n*8) != hipSuccess ||
+        hipMalloc((void**)&scratch, sort_scratch_ints((size_t)n)*sizeof(int)) != hipSuccess)
+        rc = fail("selftest_sort: allocation failed");
+    else if (hipMemcpy(a, keys, n*8, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail("selftest_sort: upload failed");
+    else
+    {
+        radix_sort_keys(a, b, (size_t)n, begin_bit, end_bit, scratch, nullptr);
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess || hipMemcpy(keys, b, n*8, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail("selftest_sort: kernels failed");
+    }
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(scratch);
+    return rc;
+}
+
+int tinsel_hip_selftest_scan(int device_index, const int* in, int* out, unsigned long long n)
+{
+    if (!in || !out || n == 0 || n >= (1ull << 31))
+        return fail("selftest_scan: bad arguments");
+    HIP_TRY(hipSetDevice(device_index));
+    int *a = nullptr, *scratch = nullptr;
+    int rc = 0;
+    if (hipMalloc((void**)&a, n*sizeof(int)) != hipSuccess || hipMalloc((void**)&scratch, scan_scratch_ints((size_t)n)*sizeof(int)) != hipSuccess)
+        rc = fail("selftest_scan: allocation failed");
+    else if (hipMemcpy(a, in, n*sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail("selftest_scan: upload failed");
+    else
+    {
+        exclusive_scan(a, a, (size_t)n, scratch, nullptr);         // (in place, as the builder's radix passes use it)
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess || hipMemcpy(out, a, n*sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail("selftest_scan: kernels failed");
+    }
+    (void)hipFree(a); (void)hipFree(scratch);
+    return rc;
+}
+
 int tinsel_hip_ubench(int device_index, int kind, unsigned long long bytes, int steps, double* out_ms, double* out_units)
 {
     if (kind < 0 || kind > 3 || bytes < 4096 || !out_ms || !out_units)

@@ -110,6 +110,9 @@ def load_library():
     L.tinsel_hip_group_set_lookahead.argtypes = [vp, ci]
     L.tinsel_hip_ubench.argtypes = [ci, ci, C.c_ulonglong, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tinsel_hip_selftest_arith.argtypes = [ci, ci, ci, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
+    if hasattr(L, "tinsel_hip_selftest_sort"):          # (absent from libraries built before round 5: TINSEL_HIP_LIB)
+        L.tinsel_hip_selftest_sort.argtypes = [ci, vp, C.c_ulonglong, ci, ci]
+        L.tinsel_hip_selftest_scan.argtypes = [ci, vp, vp, C.c_ulonglong]
     L.tinsel_hip_plan_regions.argtypes = [C.c_ulonglong, ci, ci, ci, C.POINTER(C.c_uint)]
     L.tinsel_hip_last_error.restype = C.c_char_p
     L.tinsel_pack_open.argtypes = [vp, C.c_size_t, C.POINTER(abi.SceneDesc), C.POINTER(abi.Camera), C.POINTER(abi.Options)]
@@ -129,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_set_primitive_transform", "tinsel_hip_rebuild_scene",
     "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
     "tinsel_hip_group_size", "tinsel_hip_group_member", "tinsel_hip_group_set_lookahead", "tinsel_hip_ubench",
-    "tinsel_hip_selftest_arith", "tinsel_hip_plan_regions",
+    "tinsel_hip_selftest_arith", "tinsel_hip_selftest_sort", "tinsel_hip_selftest_scan", "tinsel_hip_plan_regions",
 ]
 
 
@@ -475,6 +478,23 @@ def plan_regions(slots, num_cus=256, nee_per_path=1, fused=True):
     out = (C.c_uint*6)()
     _check(L.tinsel_hip_plan_regions(int(slots), int(num_cus), int(nee_per_path), 1 if fused else 0, out), "tinsel_hip_plan_regions")
     return dict(zip(("num_regions", "region_len", "big_regions", "short_len", "grid", "max_regions"), (int(v) for v in out)))
+
+
+def selftest_sort(keys, begin_bit=0, end_bit=64, device=0):
+    """tinsel_hip_selftest_sort: the library's stable LSD radix sort of uint64 keys by their bits [begin_bit, end_bit); returns the sorted copy"""
+    L = load_library()
+    out = np.ascontiguousarray(keys, np.uint64).copy()
+    _check(L.tinsel_hip_selftest_sort(int(device), out.ctypes.data_as(C.c_void_p), out.size, int(begin_bit), int(end_bit)), "tinsel_hip_selftest_sort")
+    return out
+
+
+def selftest_scan(values, device=0):
+    """tinsel_hip_selftest_scan: the library's exclusive prefix sum of int32 values"""
+    L = load_library()
+    a = np.ascontiguousarray(values, np.int32)
+    out = np.empty_like(a)
+    _check(L.tinsel_hip_selftest_scan(int(device), a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), a.size), "tinsel_hip_selftest_scan")
+    return out
 
 
 def selftest_arith(op, variant=-1, device=0):
