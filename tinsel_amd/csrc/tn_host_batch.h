@@ -515,7 +515,7 @@ int accumulate_tile_list(tinsel_hip* r, const FrameParams& fp)
         return 0;
     const int tilesX = (fp.width + kAccTile - 1)/kAccTile, tilesY = (fp.height + kAccTile - 1)/kAccTile;
     const int shardX = (fp.width + fp.shardTile - 1)/fp.shardTile;
-    std::vector<int> list;
+    std::vector<std::pair<long long, int>> weighted;
     for (int ty = 0; ty < tilesY; ++ty)
     {
         for (int tx = 0; tx < tilesX; ++tx)
@@ -523,14 +523,23 @@ int accumulate_tile_list(tinsel_hip* r, const FrameParams& fp)
             // candidate paths of this tile are generated at pixels [x0, x1] x [y0, y1]
             const int x0 = std::max(0, tx*kAccTile - reachLo), x1 = std::min(fp.width - 1, tx*kAccTile + kAccTile - 1 + reachHi);
             const int y0 = std::max(0, ty*kAccTile - reachLo), y1 = std::min(fp.height - 1, ty*kAccTile + kAccTile - 1 + reachHi);
-            bool mine = false;
-            for (int sy = y0/fp.shardTile; sy <= y1/fp.shardTile && !mine; ++sy)
-                for (int sx = x0/fp.shardTile; sx <= x1/fp.shardTile && !mine; ++sx)
-                    mine = ((sy*shardX + sx) % fp.shardWorld) == fp.shardRank;
-            if (mine)
-                list.push_back(ty*tilesX + tx);
+            // ... of which this shard's: the rectangle cut with every shard tile it touches
+            long long owned = 0;
+            for (int sy = y0/fp.shardTile; sy <= y1/fp.shardTile; ++sy)
+                for (int sx = x0/fp.shardTile; sx <= x1/fp.shardTile; ++sx)
+                    if (((sy*shardX + sx) % fp.shardWorld) == fp.shardRank)
+                        owned += (long long)(std::min(x1, sx*fp.shardTile + fp.shardTile - 1) - std::max(x0, sx*fp.shardTile) + 1)*
+                                 (std::min(y1, sy*fp.shardTile + fp.shardTile - 1) - std::max(y0, sy*fp.shardTile) + 1);
+            if (owned > 0)
+                weighted.push_back({ -owned, ty*tilesX + tx });
         }
     }
+    // the tiles with the most candidates first: a halo tile (a strip of a neighbouring shard tile's pixels) is a fraction of an inner
+    // tile's work per pass (k_accumulate_tiled), and the launch ends in whatever was handed out last
+    std::stable_sort(weighted.begin(), weighted.end(), [](const std::pair<long long, int>& a, const std::pair<long long, int>& b) { return a.first < b.first; });
+    std::vector<int> list;
+    for (const auto& w : weighted)
+        list.push_back(w.second);
     if (r->accTilesDev)
     {
         HIP_TRY(hipDeviceSynchronize());

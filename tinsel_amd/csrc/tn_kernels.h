@@ -1807,9 +1807,6 @@ __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumula
     const int tilesX = (fp.width + kAccTile - 1)/kAccTile;
     const int tile = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;
     const int tx = tile % tilesX, ty = tile/tilesX;
-    const int lx = threadIdx.x % kAccTile, ly = (threadIdx.x/kAccTile) % kAccTile;
-    const int px = tx*kAccTile + lx, py = ty*kAccTile + ly;
-    const bool inside = threadIdx.x < kBlock && px < fp.width && py < fp.height;
 
     const float fw = fp.filterWidth;
     const int reachLo = 1 + (int)floorf(fw);
@@ -1818,6 +1815,110 @@ __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumula
     const int ox = tx*kAccTile - reachLo, oy = ty*kAccTile - reachLo;     // frame coordinates of LDS entry (0,0)
     const bool gauss = fp.filterType != 0;
 
+    // The (at most two) candidate entries this thread stages every pass: which path, where in LDS, whether the path
+    // is this shard's.  The radiance of the NEXT pass is requested before the current pass is processed.
+    int entLe[kEnt], entGx[kEnt], entGy[kEnt];
+    bool entLive[kEnt], entStage[kEnt];
+    float4 nextRa[kEnt];
+    auto set_entry = [&](int k, int e) {
+        const int ex = e % side, ey = e/side;
+        entGx[k] = ox + ex; entGy[k] = oy + ey;
+        entLe[k] = ey*kAccSide + ex;
+        entLive[k] = e < side*side && entGx[k] >= 0 && entGy[k] >= 0 && entGx[k] < fp.width && entGy[k] < fp.height &&
+                     pixel_owned(fp, entGx[k], entGy[k]);
+    };
+#pragma unroll
+    for (int k = 0; k < kEnt; ++k)
+    {
+        set_entry(k, threadIdx.x + k*THREADS);
+        entStage[k] = threadIdx.x + k*THREADS < side*side;       // (entries outside the frame are staged as "covers nothing", every pass)
+    }
+
+    // Which pixel is this thread's, which entries does it stage?  Pixel by pixel, row by row (a wave = 4 rows of the tile) and entry
+    // t, t + THREADS -- unless the tile is one of a shard's HALO tiles: its candidate window reaches an owned shard tile by a pixel or
+    // two, so only a strip of its entries (or a corner) is this shard's and only a strip of its pixels has any candidate of this shard,
+    // in every pass (ownership is a function of the pixel).  Spread over the workgroup as above that is a lane or two of EVERY wave
+    // staging and gathering: a halo tile cost 0.7 of an inner one, and with 8 shards of 64-pixel tiles 20 of a shard tile's 36
+    // accumulate tiles are halo while the pass loop is 8 x as long (profiles/r05_n_shard_tile.md).  So for a shard:
+    //   - the shard's own entries are handed out DENSELY (the t-th live entry to thread t): a strip is staged by one wave, and
+    //     the entries that are not the shard's are marked "covers nothing" once, here;
+    //   - pixels without a candidate of this shard are left alone altogether -- no gather, no load, no store -- and the tile's
+    //     pixels are dealt to the threads row by row or column by column, whichever leaves fewer waves with a pixel to do.
+    // A pixel's adds are its own thread's, in pass and raster order, whichever thread that is.
+    int lx = threadIdx.x % kAccTile, ly = (threadIdx.x/kAccTile) % kAccTile;
+    bool mine = true;
+    if (tileList)
+    {
+        __shared__ int s_count[3];                      // waves with a pixel to do (by rows, by columns); live entries
+        int* s_list = reinterpret_cast<int*>(&s_wx[0][0]);      // (the weights are written by the passes: free until then)
+        if (threadIdx.x < 3)
+            s_count[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kEnt; ++k)
+        {
+            const int e = threadIdx.x + k*THREADS;
+            if (e < side*side)
+            {
+                s_y[entLe[k]] = entLive[k] ? 1u : 0u;
+                s_c[entLe[k]] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            const unsigned long long live = __ballot(entLive[k]);
+            int base = 0;
+            if ((threadIdx.x & 63) == 0 && live != 0ull)
+                base = atomicAdd(&s_count[2], __popcll(live));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (entLive[k])
+                s_list[base + (int)bits_below(live)] = e;
+        }
+        __syncthreads();
+        auto window_live = [&](int wx, int wy) {
+            const int qx = tx*kAccTile + wx, qy = ty*kAccTile + wy;
+            if (qx >= fp.width || qy >= fp.height)
+                return false;
+            const int a0 = maxI(0, qx - reachLo) - ox, a1 = minI(fp.width - 1, qx + reachHi) - ox;
+            const int b0 = maxI(0, qy - reachLo) - oy, b1 = minI(fp.height - 1, qy + reachHi) - oy;
+            uint32_t any = 0u;
+            for (int j = b0; j <= b1; ++j)
+                for (int i = a0; i <= a1; ++i)
+                    any |= s_y[j*kAccSide + i];
+            return any != 0u;
+        };
+        const int cx = ly, cy = lx;                     // the same thread, column by column
+        const bool byRow = threadIdx.x < kBlock && window_live(lx, ly);
+        const bool byCol = threadIdx.x < kBlock && window_live(cx, cy);
+        const bool waveRow = __ballot(byRow) != 0ull, waveCol = __ballot(byCol) != 0ull;
+        if ((threadIdx.x & 63) == 0)
+        {
+            if (waveRow) atomicAdd(&s_count[0], 1);
+            if (waveCol) atomicAdd(&s_count[1], 1);
+        }
+        __syncthreads();
+        const bool columns = s_count[1] < s_count[0];
+        if (columns) { lx = cx; ly = cy; }
+        mine = columns ? byCol : byRow;
+        const int nLive = s_count[2];
+#pragma unroll
+        for (int k = 0; k < kEnt; ++k)
+        {
+            const int t = threadIdx.x + k*THREADS;
+            entStage[k] = t < nLive;
+            entLive[k] = false;
+            if (entStage[k])
+                set_entry(k, s_list[t]);
+        }
+        __syncthreads();                                // (the flags and the list are staged over by the first pass)
+    }
+#pragma unroll
+    for (int k = 0; k < kEnt; ++k)
+    {
+        nextRa[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (entLive[k] && fp.accBegin < fp.accEnd)
+            nextRa[k] = ps.rad[slot_of(fp, fp.accBegin, entGx[k], entGy[k])];
+    }
+    const int px = tx*kAccTile + lx, py = ty*kAccTile + ly;
+    const bool inside = threadIdx.x < kBlock && px < fp.width && py < fp.height && mine;
+
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (inside)
         acc = accum[py*fp.width + px];
@@ -1825,25 +1926,6 @@ __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumula
     // this pixel's candidate window, in LDS coordinates (clipped to the frame like the reference's loops)
     const int i0 = maxI(0, px - reachLo) - ox, i1 = minI(fp.width - 1, px + reachHi) - ox;
     const int j0 = maxI(0, py - reachLo) - oy, j1 = minI(fp.height - 1, py + reachHi) - oy;
-
-    // The (at most two) candidate entries this thread stages every pass: which path, where in LDS, whether the path
-    // is this shard's.  The radiance of the NEXT pass is requested before the current pass is processed.
-    int entLe[kEnt], entGx[kEnt], entGy[kEnt];
-    bool entLive[kEnt];
-    float4 nextRa[kEnt];
-#pragma unroll
-    for (int k = 0; k < kEnt; ++k)
-    {
-        const int e = threadIdx.x + k*THREADS;
-        const int ex = e % side, ey = e/side;
-        entGx[k] = ox + ex; entGy[k] = oy + ey;
-        entLe[k] = ey*kAccSide + ex;
-        entLive[k] = e < side*side && entGx[k] >= 0 && entGy[k] >= 0 && entGx[k] < fp.width && entGy[k] < fp.height &&
-                     pixel_owned(fp, entGx[k], entGy[k]);
-        nextRa[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (entLive[k] && fp.accBegin < fp.accEnd)
-            nextRa[k] = ps.rad[slot_of(fp, fp.accBegin, entGx[k], entGy[k])];
-    }
 
     for (int s = fp.accBegin; s < fp.accEnd; ++s)
     {
@@ -1860,7 +1942,7 @@ __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumula
 #pragma unroll
         for (int k = 0; k < kEnt; ++k)
         {
-            if (threadIdx.x + k*THREADS >= side*side)
+            if (!entStage[k])
                 continue;
             const int gx = entGx[k], gy = entGy[k], le = entLe[k];
             float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // nX == 0: covers nothing
