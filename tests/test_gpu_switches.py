@@ -30,6 +30,9 @@ SETTINGS = [
     # a batch's passes as two overlapped chunks on two streams (render_impl): every fixture, both pipelines; with several batches per call; off
     {"TINSEL_HIP_OVERLAP": "1"}, {"TINSEL_HIP_OVERLAP": "1", "TINSEL_HIP_BATCH_PATHS": "65536"}, {"TINSEL_HIP_OVERLAP": "0"},
     {"TINSEL_HIP_OVERLAP": "1", "TINSEL_HIP_WALK_MIN_TRIS": "1", "TINSEL_HIP_SMALL_MESH_BYTES": "0"},
+    # the accumulate kernel for filter widths up to 1: 256-thread workgroups, 512 (second half stages), staging and gathering overlapped
+    {"TINSEL_HIP_ACCUMULATE": "tiled"}, {"TINSEL_HIP_ACCUMULATE": "wide"}, {"TINSEL_HIP_ACCUMULATE": "piped"},
+    {"TINSEL_HIP_ACCUMULATE": "piped", "TINSEL_HIP_BATCH_PATHS": "65536"},
 ]
 
 

@@ -70,6 +70,8 @@ def test_the_scan_kernels_spill_nothing():
         # (k_shadow with inline mesh walks parks 20 B of plane equations; k_extend's staged-arena variant with light sampling trades 36 B
         # for its fifth wave per SIMD: glass, profiles/r04_w_ab_extend5.md)
         assert k[n]["scratch_bytes"] <= (40 if n == "k_extend<0,1,0,1,1>" else 20), (n, k[n])
+    for n in ("k_accumulate_piped<3>", "k_accumulate_piped<4>"):       # ten waves a tile: three tiles a CU need 7.5 waves per SIMD
+        assert k[n]["waves_per_simd"] == 8 and k[n]["scratch_bytes"] == 0, (n, k[n])
     assert k["k_extend<0,1,0,1,1>"]["waves_per_simd"] >= 5
     assert k["k_extend<0,1,1,1,1>"]["waves_per_simd"] >= 6              # lean scan + light sampling (the 524k-triangle config)
     assert k["k_shadow<0,1,1,1>"]["waves_per_simd"] >= 7

@@ -598,9 +598,24 @@ int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, floa
         if (tiles > 0)
         {
             const int span = 1 + (int)floorf(fp.filterWidth) + (int)ceilf(fp.filterWidth) + 1;     // reachLo + reachHi + 1
-            // few tiles (a wave per SIMD or less): 512-thread workgroups, the second half only stages (tn_kernels.h; profiles/r03_y_ab_acc_wide.md)
-            const bool wide = tiles <= r->numCUs*4;
-            if (span == 3 && wide)
+            // Which kernel (the same adds in the same order, tests/test_gpu_switches.py):
+            //   a block per CU or less: staging of pass s + 1 overlapped with the gather of pass s (k_accumulate_piped: the launch is as long as
+            //     one tile's pass loop; cornell 256^2 x 16 passes 0.053 -> 0.037 ms, profiles/r05_q_ab_acc_piped.md; at 1024 tiles 0.100 -> 0.107,
+            //     one shard of 8 of cornell 1024^2 0.565 -> 0.525 at 64-pixel tiles but 0.563 -> 0.613 at 32: not used there);
+            //   up to a wave per SIMD: 512-thread workgroups, the second half only stages (profiles/r03_y_ab_acc_wide.md);
+            //   else 256-thread workgroups.
+            bool piped = tiles <= r->numCUs;
+            bool wide = tiles <= r->numCUs*4;
+            if (const char* e = getenv("TINSEL_HIP_ACCUMULATE"))        // (read per call: tests switch it)
+            {
+                piped = !strcmp(e, "piped");
+                wide = !strcmp(e, "wide");
+            }
+            if (span == 3 && piped)
+                hipLaunchKernelGGL((k_accumulate_piped<3>), dim3(tiles), dim3(kAccPipeThreads), 0, st, r->ps, fp, target, r->passSeeds, tileList);
+            else if (span == 4 && piped)
+                hipLaunchKernelGGL((k_accumulate_piped<4>), dim3(tiles), dim3(kAccPipeThreads), 0, st, r->ps, fp, target, r->passSeeds, tileList);
+            else if (span == 3 && wide)
                 hipLaunchKernelGGL((k_accumulate_tiled<3, 2*kBlock>), dim3(tiles), dim3(2*kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);
             else if (span == 4 && wide)
                 hipLaunchKernelGGL((k_accumulate_tiled<4, 2*kBlock>), dim3(tiles), dim3(2*kBlock), 0, st, r->ps, fp, target, r->passSeeds, tileList);

@@ -2022,6 +2022,237 @@ __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumula
         accum[py*fp.width + px] = acc;
 }
 
+// k_accumulate_piped: the same adds for launches of FEW tiles, where a tile's pass loop -- stage the pass's candidates, barrier, gather,
+// barrier, one pass after the other -- is what the launch lasts: a small frame (a wave per SIMD or less), or a shard of N, whose pass
+// loop is N x as long over 1/N of the tiles (8 shards of cornell 1024^2: 160 passes x 3.5 us whatever else was changed; calls o-p).
+// Ten waves per tile: waves 4-9 stage pass s + 1 into one half of a double buffer while waves 0-3 gather pass s from the other; one
+// barrier per pass, and a pass lasts as long as the longer of the two instead of their sum.  A pixel's adds are still one thread's, in
+// pass and raster order.  Entries that cover nothing in any pass (outside the frame, another shard's) are marked so once, in both
+// halves; a shard's halo tiles are handled as in k_accumulate_tiled (own entries dense, pixels without a candidate left alone, rows or
+// columns).
+constexpr int kAccPipeStagers = 384;        // >= 19 x 19 entries (filter widths up to 1): one entry per staging thread
+constexpr int kAccPipeThreads = kBlock + kAccPipeStagers;
+
+template <int SPAN>
+__global__ __launch_bounds__(kAccPipeThreads, 2) void k_accumulate_piped(PathState ps, FrameParams fp, float4* __restrict__ accum,
+                                                                     const uint32_t* __restrict__ passSeeds, const int* __restrict__ tileList)
+{
+    constexpr int kEnt = (kAccEntries + kAccPipeStagers - 1)/kAccPipeStagers;
+    // footprint columns / rows a path can have: int(r + fw) - int(r - fw) + 1 <= 3 for the filter widths of SPAN 3 and 4 (fw <= 1)
+    constexpr int kFoot = SPAN > 0 ? 3 : kAccMaxFoot;
+    __shared__ float4 s_c[2][kAccEntries];              // rgb, .w = bits(startX | nX << 16)
+    __shared__ uint32_t s_y[2][kAccEntries];            // startY | nY << 16
+    __shared__ float s_wx[2][kFoot][kAccEntries];
+    __shared__ float s_wy[2][kFoot][kAccEntries];
+    __shared__ unsigned long long s_exp[32];
+    __shared__ int s_count[3];                          // waves with a pixel to do (by rows, by columns); live entries
+    if (threadIdx.x < 32)
+        s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
+    if (threadIdx.x < 3)
+        s_count[threadIdx.x] = 0;
+
+    const int tilesX = (fp.width + kAccTile - 1)/kAccTile;
+    const int tile = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;
+    const int tx = tile % tilesX, ty = tile/tilesX;
+    const float fw = fp.filterWidth;
+    const int reachLo = 1 + (int)floorf(fw);
+    const int reachHi = (int)ceilf(fw);
+    const int side = kAccTile + reachLo + reachHi;
+    const int ox = tx*kAccTile - reachLo, oy = ty*kAccTile - reachLo;     // frame coordinates of LDS entry (0,0)
+    const bool gauss = fp.filterType != 0;
+    const bool stager = threadIdx.x >= kBlock;
+    const int sid = (int)threadIdx.x - kBlock;          // stagers: 0 .. kAccPipeStagers - 1
+
+    // every thread marks entries "cover nothing" in both halves and flags the live ones; the live entries are listed densely
+    int* s_list = reinterpret_cast<int*>(&s_wx[1][0][0]);      // (free until the second pass is staged)
+    for (int e = threadIdx.x; e < kAccEntries; e += kAccPipeThreads)
+    {
+        s_c[0][e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_c[1][e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_y[0][e] = 0u;
+        s_y[1][e] = 0u;
+    }
+    __syncthreads();
+    for (int e0 = 0; e0 < side*side; e0 += kAccPipeThreads)
+    {
+        const int e = e0 + (int)threadIdx.x;
+        const int ex = e % side, ey = e/side;
+        const int gx = ox + ex, gy = oy + ey;
+        const bool live = e < side*side && gx >= 0 && gy >= 0 && gx < fp.width && gy < fp.height && pixel_owned(fp, gx, gy);
+        const unsigned long long m = __ballot(live);
+        int base = 0;
+        if ((threadIdx.x & 63) == 0 && m != 0ull)
+            base = atomicAdd(&s_count[2], __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (live)
+        {
+            s_list[base + (int)bits_below(m)] = e;
+            s_y[1][ey*kAccSide + ex] = 1u;              // (the flag: read below, staged over by the second pass)
+        }
+    }
+    __syncthreads();
+    const int nLive = s_count[2];
+
+    // gatherers: which pixel (k_accumulate_tiled: rows or columns, whichever leaves fewer waves with a pixel that has a candidate)
+    int lx = threadIdx.x % kAccTile, ly = (threadIdx.x/kAccTile) % kAccTile;
+    bool mine = false;
+    {
+        auto window_live = [&](int wx, int wy) {
+            const int qx = tx*kAccTile + wx, qy = ty*kAccTile + wy;
+            if (qx >= fp.width || qy >= fp.height)
+                return false;
+            const int a0 = maxI(0, qx - reachLo) - ox, a1 = minI(fp.width - 1, qx + reachHi) - ox;
+            const int b0 = maxI(0, qy - reachLo) - oy, b1 = minI(fp.height - 1, qy + reachHi) - oy;
+            uint32_t any = 0u;
+            for (int j = b0; j <= b1; ++j)
+                for (int i = a0; i <= a1; ++i)
+                    any |= s_y[1][j*kAccSide + i];
+            return any != 0u;
+        };
+        const int cx = ly, cy = lx;
+        const bool byRow = !stager && window_live(lx, ly);
+        const bool byCol = !stager && window_live(cx, cy);
+        const bool waveRow = __ballot(byRow) != 0ull, waveCol = __ballot(byCol) != 0ull;
+        if ((threadIdx.x & 63) == 0)
+        {
+            if (waveRow) atomicAdd(&s_count[0], 1);
+            if (waveCol) atomicAdd(&s_count[1], 1);
+        }
+        __syncthreads();
+        const bool columns = s_count[1] < s_count[0];
+        if (columns) { lx = cx; ly = cy; }
+        mine = columns ? byCol : byRow;
+    }
+    // stagers: which entries
+    int entLe[kEnt], entGx[kEnt], entGy[kEnt];
+    bool entLive[kEnt];
+    float4 nextRa[kEnt];
+#pragma unroll
+    for (int k = 0; k < kEnt; ++k)
+    {
+        const int t = sid + k*kAccPipeStagers;
+        entLive[k] = stager && t < nLive;
+        entLe[k] = 0; entGx[k] = 0; entGy[k] = 0;
+        if (entLive[k])
+        {
+            const int e = s_list[t];
+            const int ex = e % side, ey = e/side;
+            entGx[k] = ox + ex; entGy[k] = oy + ey;
+            entLe[k] = ey*kAccSide + ex;
+        }
+        nextRa[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (entLive[k] && fp.accBegin < fp.accEnd)
+            nextRa[k] = ps.rad[slot_of(fp, fp.accBegin, entGx[k], entGy[k])];
+    }
+    __syncthreads();                                    // (flags and list read by everyone)
+    for (int e = threadIdx.x; e < kAccEntries; e += kAccPipeThreads)
+        s_y[1][e] = 0u;                                 // the flags go; the barrier of the first staging orders this before any write of half 1
+
+    const int px = tx*kAccTile + lx, py = ty*kAccTile + ly;
+    const bool inside = !stager && mine;                // (window_live: inside the frame)
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (inside)
+        acc = accum[py*fp.width + px];
+    const int i0 = maxI(0, px - reachLo) - ox, i1 = minI(fp.width - 1, px + reachHi) - ox;
+    const int j0 = maxI(0, py - reachLo) - oy, j1 = minI(fp.height - 1, py + reachHi) - oy;
+
+    // stage pass s into half h (stagers)
+    auto stage = [&](int s, int h) {
+        float4 curRa[kEnt];
+#pragma unroll
+        for (int k = 0; k < kEnt; ++k)
+            curRa[k] = nextRa[k];
+        if (s + 1 < fp.accEnd)
+#pragma unroll
+            for (int k = 0; k < kEnt; ++k)
+                if (entLive[k])
+                    nextRa[k] = ps.rad[slot_of(fp, s + 1, entGx[k], entGy[k])];
+#pragma unroll
+        for (int k = 0; k < kEnt; ++k)
+        {
+            if (!entLive[k])
+                continue;
+            const int gx = entGx[k], gy = entGy[k], le = entLe[k];
+            // (k_accumulate_tiled's staging, expression for expression)
+            Rng rng = Rng::seeded((uint32_t)gx + (uint32_t)gy*(uint32_t)fp.width + passSeeds[fp.passBase + s]);
+            const float x = rng.randf();
+            const float y = rng.randf();
+            const float rx = x + gx, ry = y + gy;
+            const float4 ra = curRa[k];
+            const V3 cl = clamp_length(V3(ra.x, ra.y, ra.z), fp.clampLen);
+            const int startX = maxI(0, int(rx - fw));
+            const int startY = maxI(0, int(ry - fw));
+            const int endX = minI(int(rx + fw), fp.width - 1);
+            const int endY = minI(int(ry + fw), fp.height - 1);
+            const int nX = maxI(0, endX - startX + 1), nY = maxI(0, endY - startY + 1);
+            if (gauss)
+            {
+                for (int kk = 0; kk < kFoot; ++kk)
+                {
+                    if (kk < nX)
+                        s_wx[h][kk][le] = filter_gauss_tab((startX + kk) - rx, fp.filterFalloff, fp.filterOffset, s_exp);
+                    if (kk < nY)
+                        s_wy[h][kk][le] = filter_gauss_tab((startY + kk) - ry, fp.filterFalloff, fp.filterOffset, s_exp);
+                }
+            }
+            s_c[h][le] = make_float4(cl.x, cl.y, cl.z, __uint_as_float((uint32_t)startX | (uint32_t)nX << 16));
+            s_y[h][le] = (uint32_t)startY | (uint32_t)nY << 16;
+        }
+    };
+
+    __syncthreads();
+    if (stager && fp.accBegin < fp.accEnd)
+        stage(fp.accBegin, 0);
+    __syncthreads();
+
+    for (int s = fp.accBegin; s < fp.accEnd; ++s)
+    {
+        const int h = (s - fp.accBegin) & 1;
+        if (stager)
+        {
+            if (s + 1 < fp.accEnd)
+                stage(s + 1, h ^ 1);
+        }
+        else if (inside)
+        {
+            auto add = [&](int le) {
+                const float4 c = s_c[h][le];
+                const uint32_t xm = __float_as_uint(c.w), ym = s_y[h][le];
+                const uint32_t kx = (uint32_t)(px - (int)(xm & 0xffffu)), ky = (uint32_t)(py - (int)(ym & 0xffffu));
+                if (kx >= (xm >> 16) || ky >= (ym >> 16))
+                    return;
+                if (!gauss)
+                {
+                    acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
+                }
+                else
+                {
+                    const float w = s_wx[h][kx][le]*s_wy[h][ky][le];
+                    acc.x += c.x*w; acc.y += c.y*w; acc.z += c.z*w; acc.w += w;
+                }
+            };
+            if (SPAN > 0)
+            {
+#pragma unroll
+                for (int dj = 0; dj < SPAN; ++dj)
+#pragma unroll
+                    for (int di = 0; di < SPAN; ++di)
+                        add((ly + dj)*kAccSide + lx + di);
+            }
+            else
+            {
+                for (int j = j0; j <= j1; ++j)
+                    for (int i = i0; i <= i1; ++i)
+                        add(j*kAccSide + i);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (inside)
+        accum[py*fp.width + px] = acc;
+}
+
 // ---------------------------------------------------------------------------
 // k_pass_seeds: passSeed[s] = the (first + s + 1)-th output of Random(1).Rand() (render.cu:1050-1052, 1099), continued on
 // the device from the generator state the host keeps for the next pass: one thread, a few thousand integer steps at
