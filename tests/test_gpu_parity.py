@@ -287,6 +287,44 @@ def test_malformed_bvhs_are_refused():
             tinsel_amd.create_gpu_renderer(scene)
 
 
+@pytest.mark.parametrize("kernel", ["tiled", "wide", "piped"])
+@pytest.mark.parametrize("ftype,width,falloff", [(0, 1.0, 2.0), (1, 0.5, 2.0), (1, 0.75, 2.0), (1, 1.0, 2.0)], ids=["box1", "gauss0.5", "gauss0.75", "gauss1"])
+@pytest.mark.parametrize("W,H", [(70, 37), (129, 65)])
+def test_every_accumulate_kernel_adds_the_same(kernel, ftype, width, falloff, W, H, monkeypatch):
+    """The three accumulate kernels for filter widths up to 1 -- 256-thread workgroups, 512 with a staging half, 640 with staging and gathering
+    overlapped (k_accumulate_piped) -- each FORCED (the library picks by the number of tiles), frames that are not multiples of the tile:
+    AddSample's framebuffer (render.cpp:401-445) bit for bit, whole frame and every rank of a 3-shard split (a shard's halo tiles take the
+    dense-entry path of each kernel)."""
+    from tests.oracle_api import RefOracle
+    from tests import oracle_api as oa
+    from tinsel_amd import create_gpu_renderer
+    monkeypatch.setenv("TINSEL_HIP_ACCUMULATE", kernel)
+    R = RefOracle()
+    scene, cam, opt, g = _load("cornell")
+    opt.width, opt.height = W, H
+    opt.filter = R.make_filter(ftype, width, falloff)
+    h = R.load_pack(os.path.join(GOLDEN, "cornell.pack"))
+    ref, _, _ = R.render_seeded(h, cam, opt, 0, 5)
+    R.free(h)
+    out, _ = _render(scene, cam, opt, 5, abi.PIPELINE_WAVEFRONT)
+    assert np.array_equal(out, ref)
+    if not oa.have_port():
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(oa.ROOT, "oracle"), "port"], check=True)
+    P = oa.PortOracle()
+    hp = P.load_pack(os.path.join(GOLDEN, "cornell.pack"))
+    for rank in range(3):
+        sref, nref = P.render_sharded(hp, cam, opt, rank, 3, tile=16, passes=5)
+        r = create_gpu_renderer(scene)
+        r.set_pipeline(abi.PIPELINE_WAVEFRONT)
+        r.set_shard(rank, 3, 16)
+        r.init(W, H)
+        sout = r.render(cam, opt, passes=5)
+        r.close()
+        assert np.array_equal(sout, sref), "rank %d of 3" % rank
+    P.free(hp)
+
+
 @pytest.mark.parametrize("pipeline", [abi.PIPELINE_WAVEFRONT, abi.PIPELINE_WAVEFRONT_SPLIT, abi.PIPELINE_MEGAKERNEL], ids=["wavefront", "split", "mega"])
 @pytest.mark.parametrize("world,tile,fwidth", [(4, 8, 1.0), (3, 20, 1.0), (8, 32, 0.75), (2, 32, 3.0), (5, 64, 1.0)])
 def test_every_shard_is_bit_identical_to_the_oracle_shard(pipeline, world, tile, fwidth):
