@@ -1789,13 +1789,19 @@ template <int SPAN, int THREADS = kBlock>
 __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumulate_tiled(PathState ps, FrameParams fp, float4* __restrict__ accum,
                                                                 const uint32_t* __restrict__ passSeeds, const int* __restrict__ tileList)
 {
-    constexpr int kEnt = (kAccEntries + THREADS - 1)/THREADS;       // candidate entries a thread stages per pass
+    // LDS sized by what the window can hold: for the compile-time windows (filter widths up to 1) an edge of 16 + SPAN - 1 entries and at most
+    // three footprint columns / rows per path (int(r + fw) - int(r - fw) + 1 <= 3) -- 14-16 KB a workgroup instead of 26.7, so the registers
+    // (six waves per SIMD) and not the LDS (five workgroups per CU) set the occupancy of a kernel that waits half of its cycles
+    constexpr int kSide = SPAN > 0 ? kAccTile + SPAN - 1 : kAccSide;
+    constexpr int kEntries = kSide*kSide;
+    constexpr int kFoot = SPAN > 0 ? 3 : kAccMaxFoot;
+    constexpr int kEnt = (kEntries + THREADS - 1)/THREADS;          // candidate entries a thread stages per pass
     // per candidate path of the tile: clamped sample, footprint [startX, startX+nX) x [startY, startY+nY)
     // and the separable Gaussian weights of its footprint columns / rows (each shared by up to 5 pixels)
-    __shared__ float4 s_c[kAccEntries];                 // rgb, .w = bits(startX | nX << 16)
-    __shared__ uint32_t s_y[kAccEntries];               // startY | nY << 16
-    __shared__ float s_wx[kAccMaxFoot][kAccEntries];
-    __shared__ float s_wy[kAccMaxFoot][kAccEntries];
+    __shared__ float4 s_c[kEntries];                 // rgb, .w = bits(startX | nX << 16)
+    __shared__ uint32_t s_y[kEntries];               // startY | nY << 16
+    __shared__ float s_wx[kFoot][kEntries];
+    __shared__ float s_wy[kFoot][kEntries];
     __shared__ unsigned long long s_exp[32];            // expf's table: six data-dependent reads per staged path
     if (threadIdx.x < 32)
         s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
@@ -1823,7 +1829,7 @@ __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumula
     auto set_entry = [&](int k, int e) {
         const int ex = e % side, ey = e/side;
         entGx[k] = ox + ex; entGy[k] = oy + ey;
-        entLe[k] = ey*kAccSide + ex;
+        entLe[k] = ey*kSide + ex;
         entLive[k] = e < side*side && entGx[k] >= 0 && entGy[k] >= 0 && entGx[k] < fp.width && entGy[k] < fp.height &&
                      pixel_owned(fp, entGx[k], entGy[k]);
     };
@@ -1881,7 +1887,7 @@ __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumula
             uint32_t any = 0u;
             for (int j = b0; j <= b1; ++j)
                 for (int i = a0; i <= a1; ++i)
-                    any |= s_y[j*kAccSide + i];
+                    any |= s_y[j*kSide + i];
             return any != 0u;
         };
         const int cx = ly, cy = lx;                     // the same thread, column by column
@@ -1967,7 +1973,7 @@ __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumula
                 ym = (uint32_t)startY | (uint32_t)nY << 16;
                 if (gauss)
                 {
-                    for (int kk = 0; kk < kAccMaxFoot; ++kk)
+                    for (int kk = 0; kk < kFoot; ++kk)
                     {
                         if (kk < nX)
                             s_wx[kk][le] = filter_gauss_tab((startX + kk) - rx, fp.filterFalloff, fp.filterOffset, s_exp);
@@ -2006,13 +2012,13 @@ __global__ __launch_bounds__(THREADS, THREADS == kBlock ? 4 : 2) void k_accumula
                 for (int dj = 0; dj < SPAN; ++dj)
 #pragma unroll
                     for (int di = 0; di < SPAN; ++di)
-                        add((ly + dj)*kAccSide + lx + di);
+                        add((ly + dj)*kSide + lx + di);
             }
             else
             {
                 for (int j = j0; j <= j1; ++j)
                     for (int i = i0; i <= i1; ++i)
-                        add(j*kAccSide + i);
+                        add(j*kSide + i);
             }
         }
         __syncthreads();
