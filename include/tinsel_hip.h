@@ -176,6 +176,53 @@ enum { TINSEL_PIPELINE_WAVEFRONT = 0, TINSEL_PIPELINE_MEGAKERNEL = 1, TINSEL_PIP
  * points to may be freed once this returns. */
 tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* scene, int device_index);
 
+/* Tuning: every choice between two code paths of the library that a scene or a batch size normally decides, as ONE plain
+ * struct (no reference counterpart: the reference has one kernel and no choices).  Nothing here changes a result -- every
+ * setting renders the same image bit for bit (tests/test_gpu_switches.py drives all of them) -- and nothing is read from the
+ * caller's ENVIRONMENT: a production caller gets the defaults (tinsel_hip_create), a test or an A/B run fills the struct.
+ * Convention: -1 (or 0 where stated) = "the library decides"; struct_bytes = sizeof(tinsel_hip_tuning) as the CALLER compiled
+ * it (a library built against a longer struct takes the defaults for the fields the caller does not have). */
+typedef struct tinsel_hip_tuning {
+    uint32_t struct_bytes;
+    /* ---- where the scene's data lives and how its scene level is scanned: read by tinsel_hip_create_tuned only ---- */
+    int32_t flat_scan;          /* -1 auto | 0: scene level by BVH walk even where the flat scan could take it (<= 64 primitives) */
+    int32_t lds_scene;          /* -1 auto | 0: the scene arena stays in HBM (never staged into LDS) */
+    int32_t walk;               /* -1 auto | 0: meshes in HBM are walked inline by k_extend / k_shadow, no k_walk */
+    int32_t inline_max_tris;    /* -1 default | triangles up to which a mesh rides in the arena beside a mesh in HBM */
+    int32_t walk_min_tris;      /* -1 default | triangle count from which k_walk takes a mesh in HBM */
+    int64_t small_mesh_bytes;   /* -1 default | size up to which a mesh rides in the arena (0: every mesh lives in HBM) */
+    int64_t arena_lds_limit;    /* -1 default | arena size up to which it is staged into LDS */
+    /* ---- per render: tinsel_hip_set_tuning changes them at any time between two renders ---- */
+    int64_t batch_paths;        /* 0 default | path slots resident per batch (>= 65536; tinsel_hip_set_batch_paths sets the same field) */
+    int32_t grid_mult;          /* 0 default (32) | upper bound of the streaming grid in workgroups per CU */
+    int32_t bounce_share;       /* -1 auto | 0 / 1: k_bounce deals its workgroup's four regions to its waves as one stream: never / always */
+    int32_t repack;             /* -1 auto | 0 / 1: k_bounce's per-wave shading pools: never / always (where the LDS allows) */
+    int32_t tail_split;         /* -1 auto | 0 off | 1: the last tail_share of a batch in regions 1/tail_divide as long */
+    float tail_share;
+    int32_t tail_divide;
+    int32_t shade_sorted;       /* -1 auto | 0 / 1: k_shade / k_shade_sorted */
+    int32_t overlap;            /* -1 auto | 0 / 1: a batch's passes as two overlapped chunks on two streams: never / wherever it has two passes */
+    int32_t scene_walk;         /* -1 auto | 0: scenes beyond the flat scan through k_extend / k_shadow instead of k_swalk */
+    int32_t swalk_lds;          /* -1 auto | 0: k_swalk's 256-thread generic-pointer variant */
+    int32_t accumulate;         /* 0 auto | TINSEL_ACCUMULATE_TILED / _WIDE / _PIPED (filter widths up to 1) */
+    int32_t walk_block;         /* 0 auto | 256 / 1024: k_walk's workgroup size */
+    int32_t walk_single;        /* -1 auto | 0: per-lane tree pointers (k_walk_rays) also for ONE walked primitive */
+    int32_t walk_lds_stack;     /* -1 default (8) | stack entries per lane kept in LDS (0: all of them, one workgroup per CU) */
+    int32_t walk_refill_min;    /* 0 default (24) | idle lanes of a wave that trigger k_walk's refill */
+    int32_t walk_leaf_min;      /* 0 default (8) | lanes waiting at a leaf that trigger k_walk's triangle phase */
+} tinsel_hip_tuning;
+enum { TINSEL_ACCUMULATE_AUTO = 0, TINSEL_ACCUMULATE_TILED = 1, TINSEL_ACCUMULATE_WIDE = 2, TINSEL_ACCUMULATE_PIPED = 3 };
+
+/* Fills `t` with the defaults ("the library decides" everywhere). */
+void tinsel_hip_tuning_init(tinsel_hip_tuning* t);
+/* tinsel_hip_create with a tuning (NULL: the defaults, i.e. exactly tinsel_hip_create). */
+tinsel_hip* tinsel_hip_create_tuned(const tinsel_scene_desc* scene, int device_index, const tinsel_hip_tuning* tuning);
+/* The per-render fields of `tuning` from the next render on (the create-time fields are ignored: they are baked into the
+ * uploaded scene).  Frees the path buffers (they are sized by grid_mult), drops any look-ahead. */
+int tinsel_hip_set_tuning(tinsel_hip* r, const tinsel_hip_tuning* tuning);
+/* The tuning in force (create-time fields as given to create, per-render fields as last set). */
+int tinsel_hip_get_tuning(tinsel_hip* r, tinsel_hip_tuning* out);
+
 /* Replaces GpuRenderer::~GpuRenderer (render.cu:1055-1068). */
 void tinsel_hip_destroy(tinsel_hip* r);
 
@@ -359,8 +406,8 @@ int tinsel_hip_set_detail_counters(tinsel_hip* r, int enable);
  * such call does not pay for hipMalloc (tinsel_hip_render* allocate on demand otherwise). */
 int tinsel_hip_reserve(tinsel_hip* r, int passes, int max_depth);
 
-/* Upper bound on path slots resident per batch (default 8 Mi, 64 Mi for scenes with meshes in HBM; or env
- * TINSEL_HIP_BATCH_PATHS). */
+/* Upper bound on path slots resident per batch (default 64 Mi for the wavefront pipelines, 8 Mi for the megakernel arm); the
+ * same field as tinsel_hip_tuning::batch_paths. */
 int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths);
 
 /* Per-path radiance of the most recent batch (test hook): copies min(max_paths, paths in batch)
@@ -411,6 +458,8 @@ typedef struct tinsel_hip_group tinsel_hip_group;      /* opaque */
  * under TINSEL_HIP_GROUP_ONE_DEVICE=1, a VALIDATION switch for single-GPU boxes: all members share device 0 and the
  * reduce is a device-local sum in rank order instead of the RCCL call (threads, shards, slots and read-back as real). */
 tinsel_hip_group* tinsel_hip_group_create(const tinsel_scene_desc* scene, int num_gpus, int tile);
+/* The same with a tuning for every member (NULL: the defaults). */
+tinsel_hip_group* tinsel_hip_group_create_tuned(const tinsel_scene_desc* scene, int num_gpus, int tile, const tinsel_hip_tuning* tuning);
 void tinsel_hip_group_destroy(tinsel_hip_group* g);
 /* Renderer::Init on every member (+ the reduce target on member 0). */
 int tinsel_hip_group_init(tinsel_hip_group* g, int width, int height);
@@ -520,6 +569,7 @@ static_assert(sizeof(tinsel_filter) == 16, "Filter");
 static_assert(sizeof(tinsel_options) == 48, "Options");
 static_assert(offsetof(tinsel_options, max_depth) == 40, "Options.maxDepth");
 static_assert(sizeof(tinsel_pack_header) == 256, "pack header");
+static_assert(sizeof(tinsel_hip_tuning) == 112, "tuning");
 #endif
 
 #endif /* TINSEL_HIP_H */

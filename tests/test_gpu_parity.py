@@ -298,7 +298,8 @@ def test_every_accumulate_kernel_adds_the_same(kernel, ftype, width, falloff, W,
     from tests.oracle_api import RefOracle
     from tests import oracle_api as oa
     from tinsel_amd import create_gpu_renderer
-    monkeypatch.setenv("TINSEL_HIP_ACCUMULATE", kernel)
+    from tinsel_amd import renderer
+    monkeypatch.setattr(renderer, "DEFAULT_TUNING", abi.Tuning(accumulate={"tiled": abi.ACCUMULATE_TILED, "wide": abi.ACCUMULATE_WIDE, "piped": abi.ACCUMULATE_PIPED}[kernel]))
     R = RefOracle()
     scene, cam, opt, g = _load("cornell")
     opt.width, opt.height = W, H
@@ -362,9 +363,9 @@ def test_every_shard_is_bit_identical_to_the_oracle_shard(pipeline, world, tile,
 @pytest.mark.parametrize("name", ["cornell", "veach", "features", "gloss"])
 def test_small_frame_switches_change_no_bit(name, share, repack, monkeypatch):
     """Two choices the library makes per batch / scene -- k_bounce's waves dealing their workgroup's regions as one stream
-    (TINSEL_HIP_BOUNCE_SHARE) and closing ranks through the shading pools (TINSEL_HIP_REPACK: plan_bounce) -- forced both ways."""
-    monkeypatch.setenv("TINSEL_HIP_BOUNCE_SHARE", share)
-    monkeypatch.setenv("TINSEL_HIP_REPACK", repack)
+    (tinsel_hip_tuning::bounce_share) and closing ranks through the shading pools (tinsel_hip_tuning::repack: plan_bounce) -- forced both ways."""
+    from tinsel_amd import renderer
+    monkeypatch.setattr(renderer, "DEFAULT_TUNING", abi.Tuning(bounce_share=int(share), repack=int(repack)))
     scene, cam, opt, g = _load(name)
     passes = int(g["passes"])
     from tinsel_amd import create_gpu_renderer

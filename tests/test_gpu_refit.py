@@ -167,10 +167,11 @@ def test_refit_after_displacement_matches_the_oracle_on_the_refitted_pack(bvh):
 
 
 def test_refit_of_a_light_mesh_updates_cdf_and_area(monkeypatch):
-    """cornell's quad light as a mesh in HBM (TINSEL_HIP_SMALL_MESH_BYTES=0): moving its vertices changes the light's area
+    """cornell's quad light as a mesh in HBM (tinsel_hip_tuning::small_mesh_bytes = 0): moving its vertices changes the light's area
     (PrimitiveArea -> the light pdf) and its sampling CDF; the oracle renders the refitted pack."""
     import tinsel_amd
-    monkeypatch.setenv("TINSEL_HIP_SMALL_MESH_BYTES", "0")
+    from tinsel_amd import renderer
+    monkeypatch.setattr(renderer, "DEFAULT_TUNING", abi.Tuning(small_mesh_bytes=0))
     scene, cam, opt, g = _load("cornell")
     blob = bytearray(open(os.path.join(oa.GOLDEN, "cornell.pack"), "rb").read())
     prim = _mesh_prim(scene)

@@ -1,6 +1,6 @@
 """k_swalk (tinsel_amd/csrc/tn_swalk.h): the scene-level walk with ray replacement (QueryBVH under Trace, reference
 intersection.h:751-799 / render.cpp:17-62), which replaces k_extend / k_shadow where the scene does not fit the wave-uniform flat
-scan.  By default that is many_spheres (203 primitives) only; with the flat scan switched off (TINSEL_HIP_NO_FLAT_SCAN, the
+scan.  By default that is many_spheres (203 primitives) only; with the flat scan switched off (tinsel_hip_tuning::flat_scan = 0, the
 library's A/B knob) EVERY fixture and the 32-scene fuzz corpus go through it in the split pipeline: planes, spheres, meshes
 walked inline on the stack above the scene level, moving primitives, several shadow rays per bounce, probes, one-primitive
 scenes whose root is a leaf.  Per-path radiance and framebuffer must be the reference's bit for bit."""
@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def no_flat_scan(monkeypatch):
-    monkeypatch.setenv("TINSEL_HIP_NO_FLAT_SCAN", "1")
+    from tinsel_amd import renderer
+    monkeypatch.setattr(renderer, "DEFAULT_TUNING", abi.Tuning(flat_scan=0))
 
 
 def _render_split(scene, cam, opt, passes, first_pass=0):
@@ -46,10 +47,11 @@ def test_every_fixture_through_the_scene_walk_matches_the_reference(name, no_fla
 
 
 def test_scene_walk_counts_the_rays_of_the_inline_kernels(monkeypatch):
-    """many_spheres as shipped: k_swalk (default) against k_extend / k_shadow (TINSEL_HIP_NO_SCENE_WALK) -- same image, same rays."""
+    """many_spheres as shipped: k_swalk (default) against k_extend / k_shadow (tinsel_hip_tuning::scene_walk = 0) -- same image, same rays."""
     scene, cam, opt, g = _load("many_spheres")
     out_a, rad_a, st_a = _render_split(scene, cam, opt, 3)
-    monkeypatch.setenv("TINSEL_HIP_NO_SCENE_WALK", "1")
+    from tinsel_amd import renderer
+    monkeypatch.setattr(renderer, "DEFAULT_TUNING", abi.Tuning(scene_walk=0))
     out_b, rad_b, st_b = _render_split(scene, cam, opt, 3)
     assert np.array_equal(out_a, out_b) and np.array_equal(rad_a, rad_b)
     assert st_a["rays"] == st_b["rays"] and st_a["shadow_rays"] == st_b["shadow_rays"]

@@ -2,7 +2,7 @@
 closest hits of the inline IntersectRayMesh walk (reference intersection.h:661-749) -- i.e. the reference's radiance.
 
 By default, in a scene that has a mesh too large for the LDS arena, every mesh of 8 triangles or more lives in HBM and is
-handed to k_walk, which the committed fixtures exercise with one or two meshes and one NEE ray per bounce.  Here the thresholds are lowered through the library's A/B knobs so that
+handed to k_walk, which the committed fixtures exercise with one or two meshes and one NEE ray per bounce.  Here the thresholds are lowered through tinsel_hip_tuning (walk_min_tris, small_mesh_bytes) so that
 EVERY mesh of EVERY fixture and of the 32-scene fuzz corpus goes through it: several walked primitives per scene,
 several shadow rays per bounce, moving meshes, one-triangle trees, rays that miss the leaf box."""
 import os
@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def walk_everything(monkeypatch):
-    monkeypatch.setenv("TINSEL_HIP_WALK_MIN_TRIS", "0")
-    monkeypatch.setenv("TINSEL_HIP_SMALL_MESH_BYTES", "0")
+    from tinsel_amd import renderer
+    monkeypatch.setattr(renderer, "DEFAULT_TUNING", abi.Tuning(walk_min_tris=0, small_mesh_bytes=0))
 
 
 def _render_split(scene, cam, opt, passes, first_pass=0):

@@ -116,6 +116,46 @@ class KernelTimeV1(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint32), ("total_ms", C.c_float)]
 
 
+class Tuning(C.Structure):
+    """tinsel_hip_tuning (include/tinsel_hip.h): every choice between two code paths of the library as one plain struct.  Tuning() holds
+    the defaults ("the library decides"); Tuning(walk_min_tris=0, small_mesh_bytes=0) overrides fields.  Nothing is read from the
+    environment."""
+    _fields_ = [("struct_bytes", C.c_uint32),
+                ("flat_scan", C.c_int32), ("lds_scene", C.c_int32), ("walk", C.c_int32), ("inline_max_tris", C.c_int32), ("walk_min_tris", C.c_int32),
+                ("small_mesh_bytes", C.c_int64), ("arena_lds_limit", C.c_int64),
+                ("batch_paths", C.c_int64), ("grid_mult", C.c_int32), ("bounce_share", C.c_int32), ("repack", C.c_int32),
+                ("tail_split", C.c_int32), ("tail_share", C.c_float), ("tail_divide", C.c_int32),
+                ("shade_sorted", C.c_int32), ("overlap", C.c_int32), ("scene_walk", C.c_int32), ("swalk_lds", C.c_int32), ("accumulate", C.c_int32),
+                ("walk_block", C.c_int32), ("walk_single", C.c_int32), ("walk_lds_stack", C.c_int32), ("walk_refill_min", C.c_int32), ("walk_leaf_min", C.c_int32)]
+    CREATE_FIELDS = ("flat_scan", "lds_scene", "walk", "inline_max_tris", "walk_min_tris", "small_mesh_bytes", "arena_lds_limit")
+    _DEFAULTS = dict(flat_scan=-1, lds_scene=-1, walk=-1, inline_max_tris=-1, walk_min_tris=-1, small_mesh_bytes=-1, arena_lds_limit=-1,
+                     batch_paths=0, grid_mult=0, bounce_share=-1, repack=-1, tail_split=-1, tail_share=0.0, tail_divide=4,
+                     shade_sorted=-1, overlap=-1, scene_walk=-1, swalk_lds=-1, accumulate=0,
+                     walk_block=0, walk_single=-1, walk_lds_stack=-1, walk_refill_min=0, walk_leaf_min=0)
+
+    def __init__(self, **over):
+        super().__init__()
+        self.struct_bytes = C.sizeof(Tuning)
+        for k, v in self._DEFAULTS.items():
+            setattr(self, k, v)
+        for k, v in over.items():
+            if k not in self._DEFAULTS:
+                raise TypeError("tinsel_hip_tuning has no field %r" % k)
+            setattr(self, k, v)
+
+    def replace(self, **over):
+        t = Tuning(**{k: getattr(self, k) for k in self._DEFAULTS})
+        for k, v in over.items():
+            if k not in self._DEFAULTS:
+                raise TypeError("tinsel_hip_tuning has no field %r" % k)
+            setattr(t, k, v)
+        return t
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in self._DEFAULTS}
+
+
+ACCUMULATE_AUTO, ACCUMULATE_TILED, ACCUMULATE_WIDE, ACCUMULATE_PIPED = 0, 1, 2, 3
 MODE_NORMALS, MODE_COMPLEXITY, MODE_PATHTRACE = 0, 1, 2
 BVH_REFERENCE, BVH_LBVH, BVH_PLOC = 0, 1, 2
 SCENE_BVH_NODES, SCENE_BVH_DEVICE = 0, 1

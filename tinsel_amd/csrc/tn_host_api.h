@@ -892,6 +892,46 @@ int tinsel_hip_set_batch_paths(tinsel_hip* r, unsigned long long max_paths)
         return fail("set_batch_paths: bad arguments");
     r->maxBatchSlots = (size_t)max_paths;
     r->batchSlotsExplicit = true;
+    r->tune.batch_paths = (int64_t)max_paths;
+    return 0;
+}
+
+// The per-render fields of the tuning (include/tinsel_hip.h): the create-time ones are baked into the uploaded scene and stay as created.
+int tinsel_hip_set_tuning(tinsel_hip* r, const tinsel_hip_tuning* tuning)
+{
+    if (!r || !tuning)
+        return fail("set_tuning: null argument");
+    lookahead_cancel(r);
+    tinsel_hip_tuning t = tuning_from_caller(tuning);
+    if (t.grid_mult < 0 || t.grid_mult > 256 || (t.walk_block != 0 && t.walk_block != 256 && t.walk_block != 1024) ||
+        t.accumulate < TINSEL_ACCUMULATE_AUTO || t.accumulate > TINSEL_ACCUMULATE_PIPED || t.walk_refill_min > 64 || t.walk_leaf_min > 64 ||
+        (t.tail_split > 0 && (!(t.tail_share >= 0.0f) || t.tail_divide < 1)) || (t.batch_paths != 0 && t.batch_paths < 1024))
+        return fail("set_tuning: a field is out of range");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipDeviceSynchronize());        // (launches in flight use the path buffers free_batch gives back)
+    const tinsel_hip_tuning was = r->tune;
+    t.flat_scan = was.flat_scan; t.lds_scene = was.lds_scene; t.walk = was.walk; t.inline_max_tris = was.inline_max_tris;
+    t.walk_min_tris = was.walk_min_tris; t.small_mesh_bytes = was.small_mesh_bytes; t.arena_lds_limit = was.arena_lds_limit;
+    r->tune = t;
+    if (t.batch_paths > 0)
+    {
+        r->maxBatchSlots = (size_t)t.batch_paths;
+        r->batchSlotsExplicit = true;
+    }
+    else
+    {
+        r->maxBatchSlots = 8u << 20;
+        r->batchSlotsExplicit = false;
+    }
+    free_batch(r);          // (the region arrays are sized by grid_mult)
+    return 0;
+}
+
+int tinsel_hip_get_tuning(tinsel_hip* r, tinsel_hip_tuning* out)
+{
+    if (!r || !out)
+        return fail("get_tuning: null argument");
+    *out = r->tune;
     return 0;
 }
 
@@ -1003,7 +1043,7 @@ int tinsel_hip_plan_regions(unsigned long long slots, int num_cus, int nee_per_p
     r->numCUs = num_cus;
     r->neePerPath = nee_per_path;
     // (alloc_dense's capacities)
-    const size_t maxRegions = (size_t)num_cus*(size_t)grid_mult()*(kBlock/kWave)*3/2;
+    const size_t maxRegions = (size_t)num_cus*(size_t)grid_mult(r)*(kBlock/kWave)*3/2;
     r->splitMaxRegions = (uint32_t)maxRegions;
     r->splitCap = (size_t)slots + maxRegions*kWave;
     LaunchArgs a = {};

@@ -36,11 +36,8 @@ int batch_alloc(tinsel_hip* r, T** out, size_t count)
 
 // blocks per CU of the streaming kernels' fixed grid.  Swept 4..256 on every config: 32 is best everywhere (finer static
 // ranges even out the tail; beyond 64 the per-block staging and the shorter ranges cost more than they give)
-int grid_mult()
-{
-    static const int m = getenv("TINSEL_HIP_GRID_MULT") ? std::max(1, atoi(getenv("TINSEL_HIP_GRID_MULT"))) : 32;
-    return m;
-}
+constexpr int kGridMultDefault = 32;
+int grid_mult(const tinsel_hip* r) { return r->tune.grid_mult > 0 ? r->tune.grid_mult : kGridMultDefault; }
 
 int resolve_pipeline(const tinsel_hip* r)
 {
@@ -59,7 +56,7 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
 {
     const size_t K = split ? (size_t)r->neePerPath : 0;
     // (half as many again as the widest grid: the short regions at the end of a batch, split_tail_regions)
-    const size_t maxRegions = (size_t)r->numCUs*(size_t)grid_mult()*(kBlock/kWave)*3/2;
+    const size_t maxRegions = (size_t)r->numCUs*(size_t)grid_mult(r)*(kBlock/kWave)*3/2;
     const size_t cap = slots + maxRegions*kWave;        // a region is a whole number of waves long
     SplitState& ss = r->ss;
     memset(&ss, 0, sizeof(ss));
@@ -262,7 +259,7 @@ extern "C" int tinsel_fast_prepare_path_kernels(int sharedMemLimit, const char**
 extern "C" unsigned tinsel_fast_launch_args_size(void);
 
 // Raises the dynamic-LDS limit of every kernel that needs more than the default launch limit, for both arithmetic arms (tn_launch.h).  Called by
-// tinsel_hip_create, which refuses the device when the runtime refuses a kernel (r->prepRefused: "kernel name (arm)").
+// tinsel_hip_create, which falls back to planning within 64 KB per workgroup when the runtime refuses a kernel (r->prepRefused: "kernel name (arm)").
 void prepare_kernels_once(tinsel_hip* r)
 {
     if (r->pathKernelsPrepared)
@@ -325,12 +322,12 @@ uint32_t seg_prefix_max_regions(tinsel_hip* r)
 int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* regionCounts, bool shadowRays)
 {
     // (measured and settled, profiles/EXPERIMENTS.md: one resident set of workgroups; a refill once 24 lanes idle; a triangle phase once 8 wait)
-    const int gridMult = 1, refillMin = 24, leafMin = 8;
-    static const int forceBlock = getenv("TINSEL_HIP_WALK_BLOCK") ? atoi(getenv("TINSEL_HIP_WALK_BLOCK")) : 0;
+    const int gridMult = 1, refillMin = r->tune.walk_refill_min > 0 ? r->tune.walk_refill_min : 24, leafMin = r->tune.walk_leaf_min > 0 ? r->tune.walk_leaf_min : 8;
+    const int forceBlock = r->tune.walk_block;
     prepare_kernels_once(r);
     // the work list: the front entries of every region (paths / shadow-ray bundles whose ray enters a walked mesh's box)
     const SplitState& ss = a.ss;
-    // the list visits the regions a golden-section step apart (TINSEL_HIP_WALK_LIST_STEP=1: in order)
+    // the list visits the regions a golden-section step apart
     uint32_t step = (uint32_t)(ss.numRegions*0.6180339887) | 1u;
     {
         auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
@@ -342,7 +339,7 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     {
         ScopedTimer t(r, KN_SEG, st);
         if (ss.numRegions > seg_prefix_max_regions(r))
-            return fail("k_seg_prefix: " + std::to_string(ss.numRegions) + " regions do not fit its LDS (TINSEL_HIP_GRID_MULT too large for this device)");
+            return fail("k_seg_prefix: " + std::to_string(ss.numRegions) + " regions do not fit its LDS (tinsel_hip_tuning::grid_mult too large for this device)");
         hipLaunchKernelGGL(k_seg_prefix, dim3(1), dim3(kSegBlock), ss.numRegions*sizeof(uint32_t), st, regionCounts, (const uint32_t*)nullptr, ss.numRegions, step, r->segPrefix);
         hipLaunchKernelGGL(k_seg_expand, dim3((unsigned)std::max(1, a.grid)), dim3(kBlock), 0, st, regionCounts, (const uint32_t*)r->segPrefix, ss, r->walkList);
     }
@@ -369,23 +366,15 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     job.prof = r->walkProf;
     job.refillMin = std::min(64, std::max(1, refillMin));
     job.leafMin = std::min(64, std::max(1, leafMin));
-#ifdef TN_TUNE_ENV
-    // (developer builds only -- scratch/build_variant.sh NAME -DTN_TUNE_ENV: the two thresholds from the environment for a sweep)
-    if (getenv("TN_TUNE_WALK_REFILL")) job.refillMin = std::min(64, std::max(1, atoi(getenv("TN_TUNE_WALK_REFILL"))));
-    if (getenv("TN_TUNE_WALK_LEAFMIN")) job.leafMin = std::min(64, std::max(1, atoi(getenv("TN_TUNE_WALK_LEAFMIN"))));
-#endif
-    // ONE walked primitive: its tree as kernel-argument scalars (TINSEL_HIP_WALK_SINGLE=0: per-lane pointers as for several; tests)
-    {
-        const char* singleEnv = getenv("TINSEL_HIP_WALK_SINGLE");
-        a.walkSingle = (r->walkPrims.count == 1 && !(singleEnv && atoi(singleEnv) == 0)) ? 1 : 0;
-    }
+    // ONE walked primitive: its tree as kernel-argument scalars (tinsel_hip_tuning::walk_single = 0: per-lane pointers as for several; tests)
+    a.walkSingle = (r->walkPrims.count == 1 && r->tune.walk_single != 0) ? 1 : 0;
 
     const size_t ctl = kWalkCtlWords*sizeof(uint32_t);
-    // n stack entries per lane in LDS (TINSEL_HIP_WALK_LDS_STACK, default 8; 0: the deepest tree's need, one workgroup per CU), the
+    // n stack entries per lane in LDS (tinsel_hip_tuning::walk_lds_stack, default 8; 0: the deepest tree's need, one workgroup per CU), the
     // rest of the deepest tree's need in HBM, and TWO 1024-thread workgroups per CU (8 waves per SIMD at 64 VGPRs) sharing the CU's
     // LDS: the 524k-triangle config's k_walk 19.0 -> 16.6 ms per 32 passes (2042 -> 2199 Msamples/s; 6 entries 17.2, 12 entries 16.7),
     // glass 10.4 -> 9.9; results unchanged (a stack entry is a stack entry wherever it lives)
-    static const int ldsStackEnv = getenv("TINSEL_HIP_WALK_LDS_STACK") ? atoi(getenv("TINSEL_HIP_WALK_LDS_STACK")) : 8;
+    const int ldsStackEnv = r->tune.walk_lds_stack >= 0 ? r->tune.walk_lds_stack : 8;
     const bool twoPerCU = ldsStackEnv > 0 && !forceBlock;
     const int ldsEntries = twoPerCU ? std::min(entries, std::max(1, ldsStackEnv)) : entries;
     job.stackEntries = ldsEntries;
@@ -409,8 +398,9 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
         }
     }
     // (a work item is a ray; with several walked primitives a lane keeps its ray as position | k << 27 while primitives are left: tn_walk.h)
-    if (r->walkPrims.count > 1 && (ss.capacity >= (1u << 27) || r->neePerPath >= 32))
-        return fail("k_walk: batch too large or too many shadow rays per path for several walked primitives");
+    // (k_walk_rays, whatever the number of walked primitives: ADVICE r05)
+    if (!a.walkSingle && (ss.capacity >= (1u << 27) || r->neePerPath >= 32))
+        return fail("k_walk_rays: batch too large (>= 2^27 positions) or too many shadow rays per path (>= 32): lower tinsel_hip_tuning::batch_paths");
     const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1);
     const int perCU = big ? gridMult*(twoPerCU ? 2 : 1) : gridMult*4;
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
@@ -448,7 +438,7 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
 int launch_swalk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* front, const uint32_t* back, bool shadowRays)
 {
     const int refillMin = 32, leafMin = 16;         // (settled: profiles/r03_d_ab_swalk.txt, r03_e_ab_swalk.txt)
-    static const bool noLds = getenv("TINSEL_HIP_SWALK_NO_LDS") != nullptr;
+    const bool noLds = r->tune.swalk_lds == 0;
     const SplitState& ss = a.ss;
     // the list visits the regions a golden-section step apart: every workgroup's static range gets the same mix of rays
     // (k_walk's lesson; in index order a 256-thread grid of 8 workgroups per CU took 14.4 ms where 32 per CU took 9.2)
@@ -606,10 +596,10 @@ int launch_accumulate(tinsel_hip* r, hipStream_t st, const FrameParams& fp, floa
             //   else 256-thread workgroups.
             bool piped = tiles <= r->numCUs;
             bool wide = tiles <= r->numCUs*4;
-            if (const char* e = getenv("TINSEL_HIP_ACCUMULATE"))        // (read per call: tests switch it)
+            if (r->tune.accumulate != TINSEL_ACCUMULATE_AUTO)
             {
-                piped = !strcmp(e, "piped");
-                wide = !strcmp(e, "wide");
+                piped = r->tune.accumulate == TINSEL_ACCUMULATE_PIPED;
+                wide = r->tune.accumulate == TINSEL_ACCUMULATE_WIDE;
             }
             if (span == 3 && piped)
                 hipLaunchKernelGGL((k_accumulate_piped<3>), dim3(tiles), dim3(kAccPipeThreads), 0, st, r->ps, fp, target, r->passSeeds, tileList);
@@ -649,15 +639,15 @@ int streaming_grid(const tinsel_hip* r, size_t slots, int pipeline)
     const size_t regionTarget = (pipeline == TINSEL_PIPELINE_WAVEFRONT && r->neePerPath >= 3) ? 2048 : 1024;
     const size_t perBlock = regionTarget*(kBlock/kWave);
     const size_t blocks = (slots + perBlock - 1)/perBlock;
-    // (at least as many workgroups as the chip holds at once -- TINSEL_HIP_GRID_MIN per CU, default 3: k_bounce and k_shade run three
-    // waves per SIMD -- where the batch has that many 256-path pieces: a 1 M-path batch would otherwise leave the third wave slot empty)
+    // (at least as many workgroups as the chip holds at once -- k_bounce's resident workgroups per CU, three for the split pipeline's kernels --
+    // where the batch has that many 256-path pieces: a 1 M-path batch would otherwise leave the last wave slot empty)
     const int gridMin = pipeline == TINSEL_PIPELINE_WAVEFRONT ? r->bounceWaves : 3;
-    const size_t lo = std::min<size_t>((size_t)r->numCUs*(size_t)gridMin, (slots + kBlock - 1)/kBlock), hi = (size_t)r->numCUs*(size_t)grid_mult();
+    const size_t lo = std::min<size_t>((size_t)r->numCUs*(size_t)gridMin, (slots + kBlock - 1)/kBlock), hi = (size_t)r->numCUs*(size_t)grid_mult(r);
     size_t grid = std::max<size_t>(1, std::min(hi, std::max(lo, blocks)));
     // The workgroups that HAVE work (regions are a whole number of waves long, so fewer than the grid may) as close to a whole number
     // of resident sets (gridMin per CU) as the region length allows within +-25 %: the last set of a launch is then full instead
     // of, say, two thirds empty.  Glass at 20 passes per batch 1262 -> 1291 Msamples/s, the 524k-triangle config 2024 -> 2034, the
-    // fused configs +-0 (profiles/r03_s_ab_grid_round.txt); TINSEL_HIP_GRID_ROUND=0: off (A/B)
+    // fused configs +-0 (profiles/r03_s_ab_grid_round.txt)
     const size_t resident = (size_t)r->numCUs*(size_t)gridMin;
     if (grid > 2*resident)
     {
@@ -736,6 +726,8 @@ bool split_one_set(tinsel_hip* r, LaunchArgs& a, size_t slots)
     const size_t cus = (size_t)r->numCUs;
     // (W workgroups resident per CU: W - 1 long groups per CU hold W/(W + 1) of the batch -- three waves: two groups, three quarters)
     const size_t W = (size_t)r->bounceWaves;
+    if (W < 2)
+        return false;
     const uint32_t L = (uint32_t)((slots*W/(W + 1))/((W - 1)*cus*per)/kWave*kWave);
     if (L < 3u*kWave)
         return false;
@@ -758,18 +750,22 @@ bool split_one_set(tinsel_hip* r, LaunchArgs& a, size_t slots)
 // set_regions + the short regions at the end.  The last eighth or so of the positions in regions a quarter as long: a workgroup's region group
 // is 0.75 ms of a 5 ms launch (cornell, 20 passes) and a launch ends when its last workgroup does.  k_bounce alone (round 3, call Z5):
 // cornell 1024^2 x 20 passes 3878 -> 4012 Msamples/s, x 8 3539 -> 3685, 512^2 x 16 2812 -> 3021, features 1183 -> 1292, veach 1080p
-// 2414 -> 2610 (profiles/r03_z5_ab_tail_split.md).  TINSEL_HIP_TAIL_SPLIT="share,divide" (A/B; "0": off).  On return *grid is the number
+// 2414 -> 2610 (profiles/r03_z5_ab_tail_split.md).  tinsel_hip_tuning::tail_split / tail_share / tail_divide (A/B).  On return *grid is the number
 // of region groups = the workgroups of a launch that gives every group its own.
 int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t maxRegions)
 {
     if (set_regions(r, a, slots, *grid))
         return -1;
-    const char* tailEnv = getenv("TINSEL_HIP_TAIL_SPLIT");
     double share = -0.5;
     int divide = 4;
-    if (tailEnv)
-        sscanf(tailEnv, "%lf,%d", &share, &divide);
-    // (three workgroups per CU are resident: k_bounce)
+    if (r->tune.tail_split == 0)
+        share = 0.0;
+    else if (r->tune.tail_split > 0)
+    {
+        share = (double)r->tune.tail_share;
+        divide = r->tune.tail_divide;
+    }
+    // (r->bounceWaves workgroups per CU are resident: plan_bounce)
     if (share < 0.0 && maxRegions > 0 && (size_t)*grid <= (size_t)r->numCUs*r->bounceWaves && (size_t)*grid > (size_t)r->numCUs*(r->bounceWaves - 1) && split_one_set(r, a, slots))
     {
         *grid = (int)(a.ss.numRegions/(kBlock/kWave));
@@ -777,7 +773,7 @@ int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t ma
     }
     if (share < 0.0)
     {
-        // a negative share: that multiple of ONE resident set's part of the batch (three workgroups per CU: k_bounce).  The default, half a
+        // a negative share: that multiple of ONE resident set's part of the batch (r->bounceWaves workgroups per CU).  The default, half a
         // set's part, against a fixed eighth: cornell x 20 passes 4036 -> 4059, x 64 4203 -> 4221, features 1289 -> 1298, veach 1080p
         // 2610 -> 2621, gloss 10570 -> 10530 (call Z8)
         const double sets = (double)*grid/(double)(r->bounceWaves*r->numCUs);
@@ -793,15 +789,18 @@ int cut_regions(tinsel_hip* r, LaunchArgs& a, size_t slots, int* grid, size_t ma
 // where rays can LEAVE the scene -- veach 1515 -> 1866 Msamples/s, features 755 -> 865, env_loft 3598 -> 3793, gloss 7584 -> 7934 when they
 // were introduced; between two facing planes every ray hits something and the pools only cost (cornell 2919 -> 2894) -- and where they do not
 // cost the third resident workgroup (features' 32-KB arena + pools would leave two).  The kernel runs four waves per SIMD = four workgroups
-// per CU (kBounceWaves), which is what the grid and the region cut are sized by, also where LDS leaves three (measured: features, above).
+// per CU by its registers (kBounceWaves); r->bounceWaves, which the grid and the region cut are sized by, is what the LDS lets be resident.
 bool plan_bounce(tinsel_hip* r)
 {
-    const char* repackEnv = getenv("TINSEL_HIP_REPACK");                 // 0 / 1: never / always (A/B, tests: read per call); default: open scenes
     const size_t perCU = 160u*1024u;
     const size_t lds = stack_bytes(r), withPool = lds + kPoolWords*sizeof(uint32_t);
-    const bool want = repackEnv ? atoi(repackEnv) != 0 : !r->sceneEnclosed;
-    r->bounceWaves = kBounceWaves;
-    return want && withPool*3 <= perCU && withPool <= (size_t)r->sharedMemLimit;
+    const bool want = r->tune.repack >= 0 ? r->tune.repack != 0 : !r->sceneEnclosed;      // tinsel_hip_tuning::repack 0 / 1: never / always; default: open scenes
+    const bool pools = want && withPool*3 <= perCU && withPool <= (size_t)r->sharedMemLimit;
+    // the workgroups per CU the grid and the region cut are sized by = the ones that ARE resident: four by the registers, fewer where a
+    // workgroup's LDS (stacks + staged arena + pools) says so (with pools, three fit where four times their LDS do not)
+    const size_t ldsPerGroup = std::max<size_t>(1, pools ? withPool : lds);
+    r->bounceWaves = (int)std::max<size_t>(1, std::min<size_t>((size_t)kBounceWaves, perCU/ldsPerGroup));
+    return pools;
 }
 
 int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FrameParams fp, bool accumulate = true)
@@ -858,9 +857,8 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         // bounces > 0: a workgroup's four regions as ONE stream dealt to its waves -- where a round is long (three or more shadow rays)
         // and where the regions are short (a small batch: the ragged last round of every region and bounce weighs more)
         {
-            const char* shareEnv = getenv("TINSEL_HIP_BOUNCE_SHARE");            // 0 / 1: never / always (A/B, tests: read per call)
             const int shareLen = 512;       // cornell 256^2 x 16 passes (regions of 384): 2258 -> 2311 Msamples/s; 1024^2 x 20 (regions of 2048) +0.3 %
-            a.fp.share = shareEnv ? (atoi(shareEnv) != 0) : (r->neePerPath >= 3 || (int)a.ss.regionLen <= shareLen);
+            a.fp.share = r->tune.bounce_share >= 0 ? (r->tune.bounce_share != 0) : (r->neePerPath >= 3 || (int)a.ss.regionLen <= shareLen);
         }
         // ONE launch takes every region through all the bounces (k_bounce, tn_kernels.h).  (Workgroup b takes region group b: a golden-section
         // step, which k_walk's static ranges need, loses here -- the dispatcher already hands workgroups out dynamically: veach 1970 -> 1904
@@ -886,19 +884,19 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         // 7.8 -> 6.7 ms; staged in the trace kernels too it costs them their fourth wave per SIMD, 1380 -> 1280 Msamples/s, and
         // k_lights reads too little of it to repay the copy, 2.7 -> 3.1 ms)
         const uint32_t arenaLdsTrace = r->scene.arenaLdsBytes;
-        const uint32_t arenaLdsShade = (arenaLdsTrace == 0 && r->scene.arenaBytes <= 61440u && !getenv("TINSEL_HIP_NO_LDS_SCENE")) ? r->scene.arenaBytes : arenaLdsTrace;
+        const uint32_t arenaLdsShade = (arenaLdsTrace == 0 && r->scene.arenaBytes <= 61440u && r->tune.lds_scene != 0) ? r->scene.arenaBytes : arenaLdsTrace;
         const uint32_t ldsShade = r->scene.allInArena ? r->scene.arenaBytes : arenaLdsShade;
         a.walkedOnly = walkedOnly ? 1 : 0;
-        static const bool noSceneWalkEarly = getenv("TINSEL_HIP_NO_SCENE_WALK") != nullptr;
+        const bool noSceneWalkEarly = r->tune.scene_walk == 0;
         // the lean k_extend draws the light samples itself (tn_launch.h launches it when walkedOnly and not counting)
         // ... and so does the variant for a staged arena with meshes in HBM (glass): without the SLP vectoriser it fits 128 VGPRs and
         // saves k_lights' pass over the path state (k_extend 5.7 + k_lights 7.1 -> 11.2 ms per 32 passes, glass 1366 -> 1425 Msamples/s;
-        // round 2, 170 VGPRs: 29.1 apart, 31.5 together).  TINSEL_HIP_LIGHTS_IN_EXTEND=0: k_lights as a kernel of its own (A/B)
+        // round 2, 170 VGPRs: 29.1 apart, 31.5 together; profiles/r03_k_ab_lights_in_extend.txt)
         const bool mixedArena = !r->scene.allInArena && r->scene.arenaLdsBytes != 0 && r->scene.arenaLdsBytes == r->scene.arenaBytes;
         const bool lightsInMixed = !walkedOnly && !r->countDetail && mixedArena && !(!noSceneWalkEarly && !r->scene.flatScan);
         a.lightsInExtend = lightsInMixed ? 1 : 0;
         const bool lightsInExtend = (walkedOnly && !r->countDetail) || lightsInMixed;
-        // No short regions at the end by default here (TINSEL_HIP_TAIL_SPLIT_SPLIT=1: A/B): the launches are many and short, k_walk cuts its
+        // No short regions at the end here: the launches are many and short, k_walk cuts its
         // own list into static ranges, and more regions cost k_seg_prefix / k_walk more than the other kernels' tails gain -- the 524k-triangle
         // config 2319 -> 2254 Msamples/s, many_spheres 2108 -> 2082, glass +-0 (profiles/r03_z5_ab_tail_split.md).  (k_seg_prefix stages
         // the regions' counts in LDS: (sharedMemLimit - 1024)/4 of them at most where a walk list is built.)
@@ -918,7 +916,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         // bounce to pay -- glass 1087 -> 1077, config 3 1891 -> 1881; many_spheres, scene BVH walked inline, 1168 -> 1290)
         // scenes the flat scan cannot take (more than 64 primitives): the scene-level walk with ray replacement (k_swalk, tn_swalk.h)
         // in the place of k_extend / k_shadow; the detail counters count the inline walks
-        static const bool noSceneWalk = getenv("TINSEL_HIP_NO_SCENE_WALK") != nullptr;
+        const bool noSceneWalk = r->tune.scene_walk == 0;
         const bool sceneWalk = !noSceneWalk && !r->scene.flatScan && !r->countDetail && r->walkList != nullptr && !walk;
         const bool ordered = !walk && gridPersist > r->numCUs*2;
         auto order_regions = [&](const uint32_t* front, const uint32_t* back, uint32_t* out) {
@@ -1000,9 +998,9 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 // path state is not already ordered by k_walk's front / back split: many_spheres 2087 -> 2122 Msamples/s, and in the split
                 // pipeline veach 1902 -> 2003, features 1047 -> 1093; it loses in an enclosed scene (glass: no ray leaves, 17.5 -> 19.3 ms) and
                 // where k_walk runs (the 524k-triangle config 6.47 -> 6.86 ms) (profiles/r03_g_ab_shade_sorted.txt, r04_e_rates.md).
-                // TINSEL_HIP_SHADE_SORTED=0 / 1 forces either arm (A/B, tests).
-                static const char* sortedEnv = getenv("TINSEL_HIP_SHADE_SORTED");
-                const bool shadeSorted = sortedEnv ? atoi(sortedEnv) != 0 : (!r->sceneEnclosed && !walk);
+                // tinsel_hip_tuning::shade_sorted = 0 / 1 forces either arm (A/B, tests).
+                const bool shadeSorted = (r->tune.shade_sorted >= 0 ? r->tune.shade_sorted != 0 : (!r->sceneEnclosed && !walk)) &&
+                                         (size_t)ldsShade + kShadeListWords*sizeof(uint32_t) <= (size_t)r->sharedMemLimit;
                 a.grid = gridPersist;
                 a.shadeSorted = shadeSorted ? 1 : 0;
                 a.ldsBytes = ldsShade + (shadeSorted ? (uint32_t)(kShadeListWords*sizeof(uint32_t)) : 0u);
@@ -1135,18 +1133,17 @@ int render_impl(tinsel_hip* r, const tinsel_camera* camera, const tinsel_options
     // k_walk's workgroups take a CU's whole LDS and gain nothing from a neighbour (the 524k-triangle config 2223 -> 2114, glass 1426 ->
     // 1418).  (Two RENDERERS on two streams had looked like +4 % on cornell, profiles/r04_j_two_streams.txt: that was the host's
     // share of a call overlapping, not the device's.)  Default: scenes whose scene level is walked by k_swalk, batches of 8 Mi paths
-    // or more.  TINSEL_HIP_OVERLAP=0 / 1: never / wherever a batch has two passes (A/B, tests); TINSEL_HIP_OVERLAP_MIN_PATHS: the floor.
+    // or more.  tinsel_hip_tuning::overlap = 0 / 1: never / wherever a batch has two passes (A/B, tests).
     int chunkPasses = perBatch;
     int lanes = 1;
     {
-        const char* overlapEnv = getenv("TINSEL_HIP_OVERLAP");         // (read per call: tests switch it)
         const size_t minPaths = (size_t)8u << 20;
         const int pipeline = resolve_pipeline(r);
         const bool can = !traceOnly && perBatch >= 2 && pipeline != TINSEL_PIPELINE_MEGAKERNEL;
-        static const bool noSceneWalk = getenv("TINSEL_HIP_NO_SCENE_WALK") != nullptr;
+        const bool noSceneWalk = r->tune.scene_walk == 0;
         const bool sceneWalked = pipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT && !r->scene.flatScan && !noSceneWalk && !r->countDetail &&
                                  !(r->walkPrims.count > 0 && r->walkEnabled);
-        const bool want = overlapEnv ? atoi(overlapEnv) != 0 : (sceneWalked && perPass*(size_t)perBatch >= minPaths);
+        const bool want = r->tune.overlap >= 0 ? r->tune.overlap != 0 : (sceneWalked && perPass*(size_t)perBatch >= minPaths);
         if (can && want)
         {
             chunkPasses = (perBatch + 1)/2;

@@ -7,7 +7,15 @@ extern "C" {
 
 const char* tinsel_hip_last_error(void) { return g_error.c_str(); }
 
-tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
+void tinsel_hip_tuning_init(tinsel_hip_tuning* t)
+{
+    if (t)
+        *t = tuning_defaults();
+}
+
+tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index) { return tinsel_hip_create_tuned(desc, device_index, nullptr); }
+
+tinsel_hip* tinsel_hip_create_tuned(const tinsel_scene_desc* desc, int device_index, const tinsel_hip_tuning* tuning)
 {
     if (!desc || !desc->primitives || desc->num_primitives <= 0 || !desc->bvh_nodes || desc->num_bvh_nodes <= 0)
     {
@@ -30,30 +38,30 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
 
     tinsel_hip* r = new tinsel_hip();
     r->device = device_index;
+    r->tune = tuning_from_caller(tuning);
+    const tinsel_hip_tuning& tune = r->tune;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_index) == hipSuccess)
     {
         r->numCUs = prop.multiProcessorCount;
         r->sharedMemLimit = (int)prop.sharedMemPerBlock;
     }
-    // every kernel's dynamic-LDS limit is raised here, once, and the results are checked: a device that grants less than it reports is
-    // refused now, by the kernel's name, not at some later launch with a generic error
+    // every kernel's dynamic-LDS limit is raised here, once, and the results are checked.  A runtime that refuses to raise one (it grants
+    // less than the device reports) is not refused in turn: the renderer then plans every launch inside the 64 KB no attribute is needed
+    // for -- 256-thread k_walk / k_swalk workgroups, no shading pools beside a large arena, k_seg_prefix's grids clamped -- and says so
+    // once, by the kernel's name (a device that can render small scenes should)
     prepare_kernels_once(r);
-    if (!r->prepRefused.empty())
+    if (!r->prepRefused.empty() && r->sharedMemLimit > 65536)
     {
-        fail("create: the device refused " + std::to_string(r->sharedMemLimit) + " B of dynamic LDS for " + r->prepRefused);
-        delete r;
-        return nullptr;
+        fprintf(stderr, "tinsel_hip: the runtime refused %d B of dynamic LDS for %s: planning within 65536 B per workgroup\n", r->sharedMemLimit, r->prepRefused.c_str());
+        r->sharedMemLimit = 65536;
+        r->segPrefixLds = std::min(r->segPrefixLds, 65536 - 1024);
     }
 
-    if (const char* e = getenv("TINSEL_HIP_BATCH_PATHS"))
+    if (tune.batch_paths >= 65536)
     {
-        long long v = atoll(e);
-        if (v >= 65536)
-        {
-            r->maxBatchSlots = (size_t)v;
-            r->batchSlotsExplicit = true;
-        }
+        r->maxBatchSlots = (size_t)tune.batch_paths;
+        r->batchSlotsExplicit = true;
     }
 
     DevScene& sc = r->scene;
@@ -84,11 +92,11 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
     for (int i = 0; i < P; ++i)
         if (desc->primitives[i].type == TINSEL_GEOM_MESH && mesh_bytes_estimate(desc->primitives[i].geo.mesh) > kSmallMeshBytes)
             sceneHasBigMesh = true;
-    const int inlineMaxTris = getenv("TINSEL_HIP_INLINE_MAX_TRIS") ? atoi(getenv("TINSEL_HIP_INLINE_MAX_TRIS")) : kInlineMaxTris;
+    const int inlineMaxTris = tune.inline_max_tris >= 0 ? tune.inline_max_tris : kInlineMaxTris;
     auto lives_in_arena = [&](size_t meshBytes, int numTris) {
-        // TINSEL_HIP_SMALL_MESH_BYTES: test / A-B knob (0 = every mesh lives in HBM, so the queue sort and k_walk see them all)
-        if (getenv("TINSEL_HIP_SMALL_MESH_BYTES"))
-            return meshBytes <= (size_t)atoll(getenv("TINSEL_HIP_SMALL_MESH_BYTES"));
+        // tinsel_hip_tuning::small_mesh_bytes: test / A-B knob (0 = every mesh lives in HBM, so the queue sort and k_walk see them all)
+        if (tune.small_mesh_bytes >= 0)
+            return meshBytes <= (size_t)tune.small_mesh_bytes;
         return sceneHasBigMesh ? numTris <= inlineMaxTris && meshBytes <= kSmallMeshBytes : meshBytes <= kSmallMeshBytes;
     };
 
@@ -270,14 +278,14 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         bool everyPrimHasALeaf = true;
         for (int k = 0; k < P; ++k)
             everyPrimHasALeaf = everyPrimHasALeaf && seen[(size_t)k];
-        const bool flatScan = everyPrimHasALeaf && P <= 64 && !getenv("TINSEL_HIP_NO_FLAT_SCAN");
+        const bool flatScan = everyPrimHasALeaf && P <= 64 && tune.flat_scan != 0;
 
         // primitives whose mesh lives in HBM (flat-scan scenes, the first 7): their leaf-box test sorts the ray queues
         // (k_generate, k_shade), and they are walked by k_walk ahead of the scan kernels (tn_walk.h).  That includes trees
         // that stay in L1/L2 (glass.tin's 1280-triangle sphere: 80 KB of nodes; its 12-triangle cube): what the lean kernel
         // buys there is ray replacement for incoherent bounces (glass, maxDepth 12: 924 -> 1001 Msamples/s with the sphere,
         // 1050 with the cube too; with k_walk's work list in image order the sphere had lost, 732 inline vs 657-690).
-        const int walkMinTris = getenv("TINSEL_HIP_WALK_MIN_TRIS") ? atoi(getenv("TINSEL_HIP_WALK_MIN_TRIS")) : kInlineMaxTris + 1;
+        const int walkMinTris = tune.walk_min_tris >= 0 ? tune.walk_min_tris : kInlineMaxTris + 1;
         r->binPrims.count = 0;
         r->walkPrims.count = 0;
         if (flatScan)
@@ -292,7 +300,7 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
                         r->walkPrims.prim[r->walkPrims.count++] = k;
                     }
                 }
-        r->walkEnabled = !getenv("TINSEL_HIP_NO_WALK");
+        r->walkEnabled = tune.walk != 0;
 #ifdef TN_WALK_PROF
         if (hipMalloc((void**)&r->walkProf, 16*sizeof(unsigned long long)) == hipSuccess)
             (void)hipMemset(r->walkProf, 0, 16*sizeof(unsigned long long));
@@ -371,8 +379,8 @@ tinsel_hip* tinsel_hip_create(const tinsel_scene_desc* desc, int device_index)
         {
             sc.arena = arenaDev;
             sc.arenaBytes = (uint32_t)arena.bytes.size();
-            const size_t ldsLimit = getenv("TINSEL_HIP_ARENA_LDS_LIMIT") ? (size_t)atoll(getenv("TINSEL_HIP_ARENA_LDS_LIMIT")) : kArenaLdsLimit;
-            sc.arenaLdsBytes = (arena.bytes.size() <= ldsLimit && !getenv("TINSEL_HIP_NO_LDS_SCENE")) ? sc.arenaBytes : 0u;
+            const size_t ldsLimit = tune.arena_lds_limit >= 0 ? (size_t)tune.arena_lds_limit : kArenaLdsLimit;
+            sc.arenaLdsBytes = (arena.bytes.size() <= ldsLimit && tune.lds_scene != 0) ? sc.arenaBytes : 0u;
             sc.nodes = reinterpret_cast<const Node64*>(arenaDev + offNodes);
             sc.prims = reinterpret_cast<const Prim64*>(arenaDev + offPrims);
             sc.mats = reinterpret_cast<const Mat128*>(arenaDev + offMats);

@@ -330,7 +330,9 @@ void tinsel_hip_group_destroy(tinsel_hip_group* g)
     delete g;
 }
 
-tinsel_hip_group* tinsel_hip_group_create(const tinsel_scene_desc* scene, int num_gpus, int tile)
+tinsel_hip_group* tinsel_hip_group_create(const tinsel_scene_desc* scene, int num_gpus, int tile) { return tinsel_hip_group_create_tuned(scene, num_gpus, tile, nullptr); }
+
+tinsel_hip_group* tinsel_hip_group_create_tuned(const tinsel_scene_desc* scene, int num_gpus, int tile, const tinsel_hip_tuning* tuning)
 {
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
@@ -365,7 +367,7 @@ tinsel_hip_group* tinsel_hip_group_create(const tinsel_scene_desc* scene, int nu
     {
         GroupMember& m = g->members[(size_t)k];
         m.device = g->oneDevice ? 0 : k;
-        m.r = tinsel_hip_create(scene, m.device);
+        m.r = tinsel_hip_create_tuned(scene, m.device, tuning);
         if (!m.r || tinsel_hip_set_shard(m.r, k, n, tile) || hipSetDevice(m.device) != hipSuccess ||
             hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking) != hipSuccess)
         {

@@ -2,10 +2,41 @@
 // (part of the library's one host translation unit: included by tinsel_hip.hip, in this order, never on its own)
 #pragma once
 
+// the defaults of include/tinsel_hip.h's tinsel_hip_tuning: "the library decides" everywhere
+inline tinsel_hip_tuning tuning_defaults()
+{
+    tinsel_hip_tuning t;
+    memset(&t, 0, sizeof(t));
+    t.struct_bytes = (uint32_t)sizeof(t);
+    t.flat_scan = t.lds_scene = t.walk = t.inline_max_tris = t.walk_min_tris = -1;
+    t.small_mesh_bytes = t.arena_lds_limit = -1;
+    t.batch_paths = 0;
+    t.grid_mult = 0;
+    t.bounce_share = t.repack = t.tail_split = t.shade_sorted = t.overlap = t.scene_walk = t.swalk_lds = -1;
+    t.tail_share = 0.0f;
+    t.tail_divide = 4;
+    t.accumulate = TINSEL_ACCUMULATE_AUTO;
+    t.walk_block = 0;
+    t.walk_single = t.walk_lds_stack = -1;
+    t.walk_refill_min = t.walk_leaf_min = 0;
+    return t;
+}
+
+// a caller's struct, possibly shorter than this build's: the fields it has over the defaults
+inline tinsel_hip_tuning tuning_from_caller(const tinsel_hip_tuning* in)
+{
+    tinsel_hip_tuning t = tuning_defaults();
+    if (in && in->struct_bytes >= sizeof(uint32_t))
+        memcpy(&t, in, std::min<size_t>(in->struct_bytes, sizeof(t)));
+    t.struct_bytes = (uint32_t)sizeof(t);
+    return t;
+}
+
 struct tinsel_hip
 {
     int device = 0;
     int numCUs = 256;
+    tinsel_hip_tuning tune = tuning_defaults();     // (tinsel_hip_create_tuned / tinsel_hip_set_tuning; nothing is read from the environment)
 
     DeviceArena sceneMem;
     DevScene scene;
@@ -95,9 +126,9 @@ struct tinsel_hip
     size_t batchStateSlots = 0;         // path slots each set holds (batchSlots: what ps.rad holds)
     hipStream_t laneStream = nullptr;   // the second chunk's stream
     hipEvent_t laneFork = nullptr, laneJoin = nullptr, accDone[2] = { nullptr, nullptr };
-    uint32_t* walkOverflow = nullptr;                   // k_walk's stack entries beyond the LDS ones (TINSEL_HIP_WALK_LDS_STACK)
+    uint32_t* walkOverflow = nullptr;                   // k_walk's stack entries beyond the LDS ones (tinsel_hip_tuning::walk_lds_stack)
     size_t walkOverflowCap = 0;
-    bool walkEnabled = true;                            // TINSEL_HIP_NO_WALK: walk meshes inline in k_extend / k_shadow (A/B)
+    bool walkEnabled = true;                            // tinsel_hip_tuning::walk == 0: walk meshes inline in k_extend / k_shadow (A/B)
     unsigned long long* walkProf = nullptr;             // developer-only (-DTN_WALK_PROF builds): section counters of k_walk
     uint2* probeAlias = nullptr;                        // alias table of the probe (tinsel_hip_set_probe_sampling), built on first use
     int sharedMemLimit = 65536;
@@ -113,7 +144,7 @@ struct tinsel_hip
     int lastPipeline = TINSEL_PIPELINE_WAVEFRONT;   // of the last batch (queue_counts)
     uint32_t lastRegions = 0;
     size_t maxBatchSlots = 8u << 20;
-    bool batchSlotsExplicit = false;     // set by TINSEL_HIP_BATCH_PATHS / tinsel_hip_set_batch_paths
+    bool batchSlotsExplicit = false;     // set by tinsel_hip_tuning::batch_paths / tinsel_hip_set_batch_paths
     int pipeline = TINSEL_PIPELINE_AUTO;
     int arith = TINSEL_ARITH_EXACT;     // which build of the path kernels runs (tinsel_hip_set_arithmetic)
     bool pathKernelsPrepared = false;

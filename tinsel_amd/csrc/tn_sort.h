@@ -45,7 +45,8 @@ __device__ inline int block_scan_excl(int v, int* s_wave /*[kScanBlock/64]*/, in
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ tileSums)
+// (`in` and `out` may be the SAME array -- radix_sort_keys scans its digit counts in place -- so neither is __restrict__: ADVICE r05)
+__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const int* in, int* out, int n, int* __restrict__ tileSums)
 {
     __shared__ int s_wave[kScanBlock/64];
     const int first = blockIdx.x*kScanTile + (int)threadIdx.x*kScanPerThread;

@@ -25,6 +25,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TINSEL_HIP_LIB", os.path.join(_HERE, "libtinsel_hip.so"))     # env: A/B builds only
 
 _lib = None
+# The tuning renderers are created with when the caller passes none: None = the library's defaults (tinsel_hip_create).  A plain module
+# attribute of THIS binding (tests set it through `use_tuning` to push whole suites through another code path) -- the library itself reads
+# no environment variable and has no process-wide state.
+DEFAULT_TUNING = None
 
 
 class TinselHipError(RuntimeError):
@@ -49,6 +53,15 @@ def load_library():
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.tinsel_hip_create.restype = vp
     L.tinsel_hip_create.argtypes = [C.POINTER(abi.SceneDesc), ci]
+    if hasattr(L, "tinsel_hip_create_tuned"):         # absent from libraries built before round 6 (TINSEL_HIP_LIB: an A/B against an older build)
+        L.tinsel_hip_tuning_init.restype = None
+        L.tinsel_hip_tuning_init.argtypes = [C.POINTER(abi.Tuning)]
+        L.tinsel_hip_create_tuned.restype = vp
+        L.tinsel_hip_create_tuned.argtypes = [C.POINTER(abi.SceneDesc), ci, C.POINTER(abi.Tuning)]
+        L.tinsel_hip_set_tuning.argtypes = [vp, C.POINTER(abi.Tuning)]
+        L.tinsel_hip_get_tuning.argtypes = [vp, C.POINTER(abi.Tuning)]
+        L.tinsel_hip_group_create_tuned.restype = vp
+        L.tinsel_hip_group_create_tuned.argtypes = [C.POINTER(abi.SceneDesc), ci, ci, C.POINTER(abi.Tuning)]
     L.tinsel_hip_destroy.restype = None
     L.tinsel_hip_destroy.argtypes = [vp]
     L.tinsel_hip_init.argtypes = [vp, ci, ci]
@@ -133,6 +146,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_group_create", "tinsel_hip_group_destroy", "tinsel_hip_group_init", "tinsel_hip_group_render", "tinsel_hip_group_present",
     "tinsel_hip_group_size", "tinsel_hip_group_member", "tinsel_hip_group_set_lookahead", "tinsel_hip_ubench",
     "tinsel_hip_selftest_arith", "tinsel_hip_selftest_sort", "tinsel_hip_selftest_scan", "tinsel_hip_plan_regions",
+    "tinsel_hip_tuning_init", "tinsel_hip_create_tuned", "tinsel_hip_set_tuning", "tinsel_hip_get_tuning", "tinsel_hip_group_create_tuned",
 ]
 
 
@@ -171,10 +185,14 @@ class Scene:
 class HipRenderer:
     """`Renderer` (render.h:66-73) implemented by the gfx950 streaming path tracer."""
 
-    def __init__(self, scene: Scene, device: int = 0):
+    def __init__(self, scene: Scene, device: int = 0, tuning: "abi.Tuning | None" = None):
         L = load_library()
         self._L = L
-        self._h = L.tinsel_hip_create(C.byref(scene.desc), device)
+        tuning = tuning if tuning is not None else DEFAULT_TUNING
+        if tuning is None:
+            self._h = L.tinsel_hip_create(C.byref(scene.desc), device)
+        else:
+            self._h = L.tinsel_hip_create_tuned(C.byref(scene.desc), device, C.byref(tuning))
         if not self._h:
             msg = L.tinsel_hip_last_error()
             raise TinselHipError("tinsel_hip_create failed: %s" % (msg.decode() if msg else "?"))
@@ -250,6 +268,17 @@ class HipRenderer:
     def set_pipeline(self, pipeline):
         _check(self._L.tinsel_hip_set_pipeline(self._h, pipeline), "tinsel_hip_set_pipeline")
 
+    def set_tuning(self, tuning=None, **fields):
+        """tinsel_hip_set_tuning: the per-render fields of an abi.Tuning (or of the tuning in force with `fields` replaced); the create-time
+        fields (abi.Tuning.CREATE_FIELDS) belong to create_gpu_renderer(scene, device, tuning)."""
+        t = (tuning if tuning is not None else self.get_tuning()).replace(**fields)
+        _check(self._L.tinsel_hip_set_tuning(self._h, C.byref(t)), "tinsel_hip_set_tuning")
+
+    def get_tuning(self):
+        t = abi.Tuning()
+        _check(self._L.tinsel_hip_get_tuning(self._h, C.byref(t)), "tinsel_hip_get_tuning")
+        return t
+
     def set_arithmetic(self, mode):
         """abi.ARITH_EXACT (default: bit-identical to the CPU reference) or abi.ARITH_FAST (FMA / rcp / hardware transcendentals:
         the reference's own -ffast-math trade, inside the 1e-3 L2 bar but not bit-reproducible)."""
@@ -316,18 +345,19 @@ class HipRenderer:
 
     def kernel_times(self):
         """{kernel: (launches, sum of their durations in ms, union of their intervals in ms)}; the union is smaller than the sum where a
-        call's chunks overlap on two streams.  Another build loaded through TINSEL_HIP_LIB (an A/B against an older library) may write
-        the records of before round 4 -- 36 bytes, no union -- and says nothing about it (tinsel_hip_kernel_time_bytes came later still):
-        then the record stride is READ OFF what the library wrote (every name starts with "k_"), and a 36-byte record's union is its sum."""
-        size = self._L.tinsel_hip_kernel_time_bytes() if hasattr(self._L, "tinsel_hip_kernel_time_bytes") else 0
+        call's chunks overlap on two streams.  The record stride is what the LIBRARY says (tinsel_hip_kernel_time_bytes: another build may
+        be loaded through TINSEL_HIP_LIB for an A/B); a library too old to say (before round 5: 36- or 40-byte records, nothing to tell them
+        apart but the payload) is refused rather than guessed at."""
+        if not hasattr(self._L, "tinsel_hip_kernel_time_bytes"):
+            raise TinselHipError("%s predates tinsel_hip_kernel_time_bytes: its timing records cannot be read reliably" % LIB_PATH)
+        size = self._L.tinsel_hip_kernel_time_bytes()
+        if size not in (C.sizeof(abi.KernelTime), C.sizeof(abi.KernelTimeV1)):
+            raise TinselHipError("tinsel_hip_kernel_time_bytes() = %d: a record layout this binding does not know" % size)
         raw = (C.c_ubyte * (16 * C.sizeof(abi.KernelTime)))()
         n = self._L.tinsel_hip_kernel_times(self._h, C.cast(raw, C.POINTER(abi.KernelTime)), 16)
         if n < 0:
             _check(n, "tinsel_hip_kernel_times")
         data = bytes(raw)
-        if size not in (C.sizeof(abi.KernelTime), C.sizeof(abi.KernelTimeV1)):
-            v1 = C.sizeof(abi.KernelTimeV1)
-            size = v1 if (n >= 2 and data[v1:v1 + 2] == b"k_") else C.sizeof(abi.KernelTime)
         T = abi.KernelTime if size == C.sizeof(abi.KernelTime) else abi.KernelTimeV1
         out = {}
         for i in range(n):
@@ -404,10 +434,14 @@ class HipRendererGroup:
     """`Renderer` (render.h:66-73) over several GPUs of one node: the C-ABI's tinsel_hip_group (one host thread per
     device inside the library, pixel-tile shards, ONE RCCL reduce of the accumulator per read-back)."""
 
-    def __init__(self, scene: Scene, num_gpus: int = 0, tile: int = 64):
+    def __init__(self, scene: Scene, num_gpus: int = 0, tile: int = 64, tuning: "abi.Tuning | None" = None):
         L = load_library()
         self._L = L
-        self._h = L.tinsel_hip_group_create(C.byref(scene.desc), num_gpus, tile)
+        tuning = tuning if tuning is not None else DEFAULT_TUNING
+        if tuning is None:
+            self._h = L.tinsel_hip_group_create(C.byref(scene.desc), num_gpus, tile)
+        else:
+            self._h = L.tinsel_hip_group_create_tuned(C.byref(scene.desc), num_gpus, tile, C.byref(tuning))
         if not self._h:
             msg = L.tinsel_hip_last_error()
             raise TinselHipError("tinsel_hip_group_create failed: %s" % (msg.decode() if msg else "?"))
@@ -506,9 +540,28 @@ def selftest_arith(op, variant=-1, device=0):
     return [int(c) for c in counts], int(first.value)
 
 
-def create_gpu_renderer(scene: Scene, device: int = 0) -> HipRenderer:
-    """`Renderer* CreateGpuRenderer(const Scene*)` (render.h:79)."""
-    return HipRenderer(scene, device)
+def create_gpu_renderer(scene: Scene, device: int = 0, tuning: "abi.Tuning | None" = None) -> HipRenderer:
+    """`Renderer* CreateGpuRenderer(const Scene*)` (render.h:79); `tuning`: an abi.Tuning (tinsel_hip_create_tuned), None = the defaults."""
+    return HipRenderer(scene, device, tuning)
+
+
+class use_tuning:
+    """`with use_tuning(walk_min_tris=0, small_mesh_bytes=0): ...` -- renderers created inside the block without an explicit tuning get
+    this one (DEFAULT_TUNING above).  Also usable as `use_tuning(...).__enter__()` / pytest's monkeypatch.setattr(renderer, "DEFAULT_TUNING", ..)."""
+
+    def __init__(self, tuning=None, **fields):
+        self.tuning = (tuning if tuning is not None else abi.Tuning()).replace(**fields)
+
+    def __enter__(self):
+        global DEFAULT_TUNING
+        self._was = DEFAULT_TUNING
+        DEFAULT_TUNING = self.tuning
+        return self.tuning
+
+    def __exit__(self, *exc):
+        global DEFAULT_TUNING
+        DEFAULT_TUNING = self._was
+        return False
 
 
 def resolve(accum):
