@@ -93,6 +93,7 @@ def parse():
     ap.add_argument("--no-ubench", action="store_true", help="skip the stream-copy / record-chase yard-sticks (and the counter calibration)")
     ap.add_argument("--group", action="store_true", help="time the library's own multi-GPU path (tinsel_hip_group over --gpus devices, one process) instead")
     ap.add_argument("--no-group-leg", action="store_true", help="N > 1: do not time the tinsel_hip_group path from rank 0 before the ranks meet")
+    ap.add_argument("--force-comm", action="store_true", help="N = 1 validation: make the library's RCCL communicator of ONE rank and put its ncclReduce inside the timed region")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)      # the child process the PMC passes profile
     return ap.parse_args()
 
@@ -315,15 +316,27 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
 
     passes_per_step = world         # weak scaling: K*N passes over 1/N of the pixels each
     from tinsel_amd import distributed
-    total_buf = torch.empty_like(accum) if world > 1 else None     # the reduce target: allocated outside the timed region
+    # THE collective: the library's own ncclReduce (tinsel_hip_comm_*: the code a tinsel_hip_group's threads run too), its communicator made
+    # here, outside every timed region; torch only carries the id.  rccl_seen = the ranks RCCL itself counts (ncclCommCount).  Not with a
+    # CPU backend (gloo: the one-device stand-in, two ranks sharing a GPU, which RCCL refuses) -- and if ANY rank fails to join, every rank
+    # falls back to torch's reduce and the line says so (`reduce_impl`).
+    rccl_seen = 0
+    if (world > 1 and backend == "nccl") or (world == 1 and args.force_comm):
+        rccl_seen = distributed.init_library_comm(r, rank, world)
+    use_lib = rccl_seen > 0
+    reducing = world > 1 or use_lib
+    reduce_impl = ("library ncclReduce (tinsel_hip_comm_reduce_accum)" if use_lib else
+                   ("torch.distributed reduce, %s backend%s" % (backend, " (FALLBACK: the library communicator did not come up)" if backend == "nccl" else " (one-device stand-in)")
+                    if world > 1 else None))
+    total_buf = torch.empty_like(accum) if reducing else None     # the reduce target: allocated outside the timed region
     reduced = [accum]
 
     def run(steps, per_step=None):
         r.render_async(cam, opt, passes=steps*(passes_per_step if per_step is None else per_step), stream=stream)
-        if world > 1:
+        if reducing:
             # the ONE collective of the path, out of place: `accum` keeps this rank's own partial sums (a later render + reduce
             # cannot count a sample twice); RCCL over xGMI on the render stream, or the gloo stand-in through host memory
-            reduced[0] = distributed.reduce_accum(accum, dst=0, out=total_buf)
+            reduced[0] = distributed.reduce_accum(accum, dst=0, out=total_buf, renderer=r if use_lib else None, rank=rank)
 
     def sync():
         if world > 1:
@@ -443,6 +456,13 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
             world, last_first, last_first + last_passes, "ok" if ok else "MISMATCH",
             float(np.abs(got - want).max())), file=sys.stderr, flush=True)
         if not ok:
+            raise SystemExit(3)
+
+    if world == 1 and use_lib:
+        torch.cuda.synchronize()
+        same = bool(torch.equal(reduced[0], accum))
+        print("validation: 1-rank library ncclReduce of the accumulator: %s" % ("ok" if same else "MISMATCH"), file=sys.stderr, flush=True)
+        if not same:
             raise SystemExit(3)
 
     # ---- the API's own call pattern, N = 1 only -------------------------------------------------
@@ -630,6 +650,15 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         "kernel": dom_name, "launches": dom_launches, "avg_launch_ms": avg_launch_s*1e3, "concurrent_launches": dom_concurrency, "traffic": traffic,
         "frac_model": drow.get("frac_model"),
         "algorithmic_GBs": drow.get("algorithmic_GBs"), "frac_hbm_algorithmic": (alg_gbs/HBM_PEAK_GBS) if alg_gbs else None,
+        # SURVEY.md 8(d)'s own number, as written there: (rays x B_ray + samples x B_fb) / seconds / 8e12 over the TIMED step (the driver's
+        # clock, not the kernel's).  Above 1 wherever the scene is on chip: the model bills every node / primitive fetch to HBM
+        "frac_survey_8d": job_bytes/elapsed/(HBM_PEAK_GBS*1e9) if elapsed > 0 else None,
+        # what the job MUST move through HBM with the scene on chip (48 B per ray + the footprint's RMW per sample) over the same seconds
+        "frac_hbm_compulsory": job_compulsory/elapsed/(HBM_PEAK_GBS*1e9) if elapsed > 0 else None,
+        # issue utilisation x lanes active: the share of the chip's peak LANE-operations per second the dominant kernel's instructions use
+        # (every issued instruction still counts as useful: the parity arm's IEEE divide / sqrt expansions are in it)
+        "useful_frac": (drow.get("valu_frac_of_issue_peak")*drow.get("valu_lanes_active")) if (drow.get("valu_frac_of_issue_peak") and drow.get("valu_lanes_active")) else None,
+        "valu_frac_of_issue_peak": drow.get("valu_frac_of_issue_peak"),
         "counter_GBs": drow.get("counter_GBs"), "frac_hbm_counter": drow.get("frac_hbm_counter"),
         "l2_hit_rate": drow.get("l2_hit_rate"),
         "valu_wave_insts_per_launch": valu_per_launch, "valu_lanes_active": drow.get("valu_lanes_active"), "wave_cycles_waiting": drow.get("wave_cycles_waiting"),
@@ -707,6 +736,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         "api_1pass_plain_msamples_s": api_1pass_plain,
         "api_1pass_pinned_output_msamples_s": api_1pass_pinned,
         "arithmetic": args.arith,
+        "reduce": {"impl": reduce_impl, "rccl_ranks_seen": rccl_seen if use_lib else None},
         "fast_msamples_s": fast["msamples_s"] if fast else None,
         "fast_l2": fast["l2_vs_exact_at_spp"][0] if (fast and fast.get("l2_vs_exact_at_spp")) else None,
         # what bit-exactness costs: the opt-in tolerance arm's rate over the timed (exact) arm's, same workload
@@ -846,8 +876,8 @@ def first_collective_watchdog(args, rank, world, backend, seconds=None):
 
 LINE_LIMIT_BYTES = 6144
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_model", "kernel", "launches", "avg_launch_ms", "traffic",
-                 "frac_hbm_algorithmic", "frac_hbm_counter", "job_counter_over_compulsory", "valu_lanes_active", "wave_cycles_waiting",
-                 "waves_per_simd", "l2_hit_rate")
+                 "frac_survey_8d", "useful_frac", "frac_hbm_compulsory", "frac_hbm_counter", "frac_hbm_algorithmic", "valu_frac_of_issue_peak",
+                 "job_counter_over_compulsory", "valu_lanes_active", "wave_cycles_waiting", "waves_per_simd", "l2_hit_rate")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 BASELINE_INDEX = {"cornell": 1, LARGE: 2, "glass": 3, "veach": 4}      # scene -> index into BASELINE.json's `configs`
 CONFIG_SPP = {"cornell": 256, LARGE: 512, "glass": 1024, "veach": 4096}
@@ -875,12 +905,13 @@ def compact_config(res):
     rf, cpu = res.get("roofline") or {}, res.get("cpu_baseline") or {}
     out = {"workload": res["config"]["workload"], "baseline_config": res.get("baseline_config"), "value": res["value"], "ms_per_step": res["ms_per_step"],
            "mrays_per_s": res.get("mrays_per_s"), "kernel": rf.get("kernel"), "avg_launch_ms": rf.get("avg_launch_ms"), "bound": rf.get("bound"),
-           "frac": rf.get("frac"), "frac_model": rf.get("frac_model"), "frac_hbm_counter": rf.get("frac_hbm_counter"),
+           "frac": rf.get("frac"), "frac_model": rf.get("frac_model"), "frac_survey_8d": rf.get("frac_survey_8d"), "useful_frac": rf.get("useful_frac"),
+           "frac_hbm_compulsory": rf.get("frac_hbm_compulsory"), "frac_hbm_counter": rf.get("frac_hbm_counter"),
            "job_counter_over_compulsory": rf.get("job_counter_over_compulsory"),
            "cpu_msamples_s": cpu.get("value"), "cpu_cores": cpu.get("cores"),
            "fast_over_exact": res.get("fast_over_exact"), "fast_l2_at_spp": (res.get("fast") or {}).get("l2_vs_exact_at_spp")}
     if res.get("strong"):
-        out["strong_msamples_s"] = res["strong"]["msamples_s"]
+        out["strong_msamples_s"] = out["value_fixed_work"] = res["strong"]["msamples_s"]
     return out
 
 
@@ -898,6 +929,9 @@ def contract_line(args, world, head, more=(), group=None, group5=None, detail_fi
     line = {
         "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        # the same K full-frame passes as N = 1 split over the ranks (north_star's 8-GPU configuration is a FIXED job); at N = 1 the two coincide
+        "value_fixed_work": (head.get("strong") or {}).get("msamples_s") if world > 1 else head["value"],
+        "reduce_impl": (head.get("reduce") or {}).get("impl"), "rccl_ranks_seen": (head.get("reduce") or {}).get("rccl_ranks_seen"),
         "data": "synthetic: the reference's scene files as scene packs (ajax: a procedural 524,288-triangle stand-in); rays, seeds and all downstream generated on the GPU",
         "config": _pick(head["config"], ("workload", "scene_pack", "parallelism", "rays_per_sample")),
         "mrays_per_s": head.get("mrays_per_s"),

@@ -480,6 +480,18 @@ int tinsel_hip_group_size(tinsel_hip_group* g);
  * Whatever the group had speculated is dropped first (look-ahead starts over with the next read-back). */
 tinsel_hip* tinsel_hip_group_member(tinsel_hip_group* g, int rank);
 
+/* One process per GPU (an MPI-style host: bench.py --gpus N under torch.distributed.run): the SAME collective as the group's -- one
+ * ncclReduce(SUM, float, 4*W*H) of the accumulators to `root` -- with the communicator made by ncclCommInitRank.  The host language only
+ * carries the 128-byte id from rank 0 to the other ranks (a torch.distributed broadcast, MPI_Bcast, a file); set_shard(rank, world, tile)
+ * is the caller's, as before.  comm_init is collective (every rank calls it); comm_size = ncclCommCount of the communicator (0: none);
+ * comm_reduce_accum enqueues on `stream`, WAITS for it, and leaves the sum in `out_device` (W*H*4 floats of device memory) on `root`
+ * only -- this rank's own accumulator is never written, so a later render + reduce cannot count a sample twice. */
+#define TINSEL_HIP_COMM_ID_BYTES 128
+int tinsel_hip_comm_unique_id(unsigned char* id_bytes, int capacity);
+int tinsel_hip_comm_init(tinsel_hip* r, const unsigned char* id_bytes, int rank, int world);
+int tinsel_hip_comm_size(tinsel_hip* r);
+int tinsel_hip_comm_reduce_accum(tinsel_hip* r, float* out_device, int root, void* stream);
+
 /* How a batch of `slots` path slots is cut into regions on a device of `num_cus` CUs (the dense path state of the wavefront pipelines:
  * DESIGN.md section 4; `fused` != 0: the fused pipeline, which ends a batch with shorter regions).  Pure host arithmetic -- no device is
  * touched: out[6] = number of regions, positions per region, regions of that length (the rest are short), positions per short region,

@@ -36,6 +36,8 @@ def test_two_ranks_on_one_device():
     g = d["group"]
     assert g["one_device_validation"] is True and g["kpass_msamples_s"] > 0 and g["api_1pass_plain_msamples_s"] > 0 and g["api_1pass_lookahead_msamples_s"] > 0, g
     assert d["ranks"]["communicator_world_size"] == 2 and d["ranks"]["kernel_ms_min_max"][0] > 0
+    # the fixed-work rate as a top-level key beside `value`; the gloo stand-in says that it is not the library's RCCL arm
+    assert d["value_fixed_work"] == d["strong_msamples_s"] and d["rccl_ranks_seen"] is None and "gloo" in d["reduce_impl"]
     # the full record (stderr, behind a prefix; also bench_detail.json): every rank's share of the work
     full = json.loads([l for l in p.stderr.splitlines() if l.startswith("bench_detail: ")][-1][len("bench_detail: "):])
     rk = full["ranks"]
@@ -68,3 +70,37 @@ def test_group_mode_prints_one_line():
     assert len(lines) == 1
     g = json.loads(lines[0])
     assert g["n_gpus"] == 2 and g["kpass_passes_per_call"] == 8 and g["api_1pass_lookahead_pinned_output_msamples_s"] > 0
+
+
+def test_library_reduce_arm_with_one_rank():
+    """The process-per-GPU arm of the ONE collective (tinsel_hip_comm_*: the library's own ncclReduce, the code a tinsel_hip_group's threads
+    run too) executed end to end with the only world size a one-GPU box allows: `bench.py --force-comm` makes the communicator from a unique
+    id (ncclCommInitRank), puts the reduce inside the timed region and checks the reduced image against the accumulator.  The line says which
+    implementation reduced and how many ranks RCCL ITSELF counted (ncclCommCount)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-comm", "--steps", "4", "--warmup", "1", "--width", "256", "--height", "256",
+                        "--no-pmc", "--no-fast", "--no-api", "--no-ubench", "--no-cpu-baseline", "--no-second-config", "--no-more-configs"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "validation: 1-rank library ncclReduce of the accumulator: ok" in p.stderr, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["rccl_ranks_seen"] == 1 and d["reduce_impl"].startswith("library ncclReduce"), d
+    assert d["value"] > 0 and d["value_fixed_work"] == d["value"]
+
+
+def test_comm_entry_points_refuse_what_they_must():
+    import tinsel_amd
+    from tests.test_gpu_parity import _load
+    scene, cam, opt, g = _load("cornell")
+    r = tinsel_amd.create_gpu_renderer(scene)
+    assert r.comm_size() == 0
+    with pytest.raises(tinsel_amd.TinselHipError, match="no communicator"):
+        r.comm_reduce_accum(None, 0, None)
+    ident = r.comm_unique_id()
+    assert len(ident) == 128 and any(ident)
+    with pytest.raises(tinsel_amd.TinselHipError, match="bad arguments"):
+        r.comm_init(ident, 2, 2)
+    r.comm_init(ident, 0, 1)
+    assert r.comm_size() == 1
+    with pytest.raises(tinsel_amd.TinselHipError, match="accumulator"):
+        r.comm_reduce_accum(None, 0, None)          # no init() yet
+    r.close()

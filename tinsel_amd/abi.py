@@ -156,6 +156,7 @@ class Tuning(C.Structure):
 
 
 ACCUMULATE_AUTO, ACCUMULATE_TILED, ACCUMULATE_WIDE, ACCUMULATE_PIPED = 0, 1, 2, 3
+COMM_ID_BYTES = 128
 MODE_NORMALS, MODE_COMPLEXITY, MODE_PATHTRACE = 0, 1, 2
 BVH_REFERENCE, BVH_LBVH, BVH_PLOC = 0, 1, 2
 SCENE_BVH_NODES, SCENE_BVH_DEVICE = 0, 1

@@ -2,6 +2,8 @@
 // (part of the library's one host translation unit: included by tinsel_hip.hip, in this order, never on its own)
 #pragma once
 
+namespace { void comm_release(tinsel_hip* r); }      // (tn_host_group.h: the RCCL communicator of the process-per-GPU arm)
+
 extern "C" {
 
 
@@ -513,6 +515,7 @@ void tinsel_hip_destroy(tinsel_hip* r)
     (void)hipSetDevice(r->device);
     lookahead_release(r);
     (void)hipDeviceSynchronize();
+    comm_release(r);
     if (r->laneStream) (void)hipStreamDestroy(r->laneStream);
     if (r->laneFork) (void)hipEventDestroy(r->laneFork);
     if (r->laneJoin) (void)hipEventDestroy(r->laneJoin);

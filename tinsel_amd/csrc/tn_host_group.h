@@ -16,6 +16,9 @@ struct RcclApi
 {
     void* lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -35,12 +38,15 @@ struct RcclApi
             return false;
         }
         CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+        CommCount = (decltype(CommCount))dlsym(lib, "ncclCommCount");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
         Reduce = (decltype(Reduce))dlsym(lib, "ncclReduce");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-        if (!CommInitAll || !CommDestroy || !Reduce || !GetErrorString)
+        if (!CommInitAll || !GetUniqueId || !CommInitRank || !CommCount || !CommDestroy || !Reduce || !GetErrorString)
         {
-            error = "RCCL library lacks ncclCommInitAll / ncclReduce";
+            error = "RCCL library lacks ncclCommInitAll / ncclCommInitRank / ncclReduce";
             lib = nullptr;
             return false;
         }
@@ -49,6 +55,30 @@ struct RcclApi
 };
 
 RcclApi g_rccl;
+
+// THE collective of the path -- the only place the library calls ncclReduce: sum of every rank's W*H float4 accumulator (or look-ahead snapshot)
+// into `dst` on `root` (dst is read on the root only), on the caller's stream, then a wait for that stream.  Its callers: a group's worker
+// threads (one communicator per member, ncclCommInitAll) and the process-per-GPU arm below (tinsel_hip_comm_*: ncclCommInitRank).
+void comm_release(tinsel_hip* r)
+{
+    if (r && r->comm && g_rccl.CommDestroy)
+        (void)g_rccl.CommDestroy((ncclComm_t)r->comm);
+    if (r)
+    {
+        r->comm = nullptr;
+        r->commWorld = 0;
+    }
+}
+
+int rccl_reduce_accum(ncclComm_t comm, const float4* src, float4* dst, size_t pixels, int root, hipStream_t st, const char* who)
+{
+    const ncclResult_t e = g_rccl.Reduce(src, dst, pixels*4, ncclFloat, ncclSum, root, comm, st);
+    if (e != ncclSuccess)
+        return fail(std::string(who) + ": ncclReduce: " + g_rccl.GetErrorString(e));
+    if (hipStreamSynchronize(st) != hipSuccess)
+        return fail(std::string(who) + ": the reduce failed on the device");
+    return 0;
+}
 
 } // namespace
 
@@ -152,11 +182,7 @@ void group_worker(tinsel_hip_group* g, int rank)
         {
             // every member enters the collective from its own thread and stream: the ring runs over xGMI
             (void)hipSetDevice(m.device);
-            const ncclResult_t e = g_rccl.Reduce(m.r->accum, g->total, (size_t)g->width*g->height*4, ncclFloat, ncclSum, 0, m.comm, m.stream);
-            if (e != ncclSuccess)
-                rc = fail(std::string("group: ncclReduce: ") + g_rccl.GetErrorString(e));
-            else if (hipStreamSynchronize(m.stream) != hipSuccess)
-                rc = fail("group: the reduce failed on the device");
+            rc = rccl_reduce_accum(m.comm, m.r->accum, g->total, (size_t)g->width*g->height, 0, m.stream, "group");
         }
         else if (job == GJ_AHEAD)
         {
@@ -185,11 +211,7 @@ void group_worker(tinsel_hip_group* g, int rank)
                     rc = fail("group: look-ahead wait failed");
                 else
                 {
-                    const ncclResult_t e = g_rccl.Reduce(shot.buf, g->totalNext, (size_t)g->width*g->height*4, ncclFloat, ncclSum, 0, m.comm, m.stream);
-                    if (e != ncclSuccess)
-                        rc = fail(std::string("group: ncclReduce: ") + g_rccl.GetErrorString(e));
-                    else if (hipStreamSynchronize(m.stream) != hipSuccess)
-                        rc = fail("group: the look-ahead reduce failed on the device");
+                    rc = rccl_reduce_accum(m.comm, shot.buf, g->totalNext, (size_t)g->width*g->height, 0, m.stream, "group look-ahead");
                 }
             }
         }
@@ -566,6 +588,67 @@ tinsel_hip* tinsel_hip_group_member(tinsel_hip_group* g, int rank)
         return nullptr;
     group_ahead_drop(g);        // the caller may do anything to the member: nothing speculated may be in flight or survive
     return g->members[(size_t)rank].r;
+}
+
+
+// ---------------------------------------------------------------------------
+// One process per GPU (bench.py --gpus N under torch.distributed.run; any MPI-style host): the same collective, the communicator made
+// with ncclCommInitRank from a unique id that the HOST LANGUAGE carries from rank 0 to the others (a torch.distributed broadcast, an
+// MPI_Bcast, a file) -- the library opens no sockets of its own beyond RCCL's.
+
+int tinsel_hip_comm_unique_id(unsigned char* id_bytes, int capacity)
+{
+    if (!id_bytes || capacity < (int)sizeof(ncclUniqueId))
+        return fail("comm_unique_id: the buffer must hold TINSEL_HIP_COMM_ID_BYTES bytes");
+    if (!g_rccl.load())
+        return fail("comm_unique_id: " + g_rccl.error);
+    ncclUniqueId id;
+    const ncclResult_t e = g_rccl.GetUniqueId(&id);
+    if (e != ncclSuccess)
+        return fail(std::string("comm_unique_id: ncclGetUniqueId: ") + g_rccl.GetErrorString(e));
+    memset(id_bytes, 0, (size_t)capacity);
+    memcpy(id_bytes, &id, sizeof(id));
+    return 0;
+}
+
+int tinsel_hip_comm_init(tinsel_hip* r, const unsigned char* id_bytes, int rank, int world)
+{
+    if (!r || !id_bytes || world < 1 || rank < 0 || rank >= world)
+        return fail("comm_init: bad arguments");
+    if (!g_rccl.load())
+        return fail("comm_init: " + g_rccl.error);
+    comm_release(r);
+    HIP_TRY(hipSetDevice(r->device));
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t e = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (e != ncclSuccess)
+        return fail(std::string("comm_init: ncclCommInitRank: ") + g_rccl.GetErrorString(e));
+    r->comm = comm;
+    r->commRank = rank;
+    r->commWorld = world;
+    return 0;
+}
+
+int tinsel_hip_comm_size(tinsel_hip* r)
+{
+    if (!r || !r->comm)
+        return 0;
+    int n = 0;
+    if (g_rccl.CommCount((ncclComm_t)r->comm, &n) != ncclSuccess)
+        return -1;
+    return n;
+}
+
+int tinsel_hip_comm_reduce_accum(tinsel_hip* r, float* out_device, int root, void* stream)
+{
+    if (!r || !r->comm || !r->accum)
+        return fail("comm_reduce_accum: no communicator (tinsel_hip_comm_init) or no accumulator (tinsel_hip_init)");
+    if (root < 0 || root >= r->commWorld || (r->commRank == root && !out_device))
+        return fail("comm_reduce_accum: bad root / the root needs an output buffer");
+    HIP_TRY(hipSetDevice(r->device));
+    return rccl_reduce_accum((ncclComm_t)r->comm, r->accum, (float4*)out_device, (size_t)r->width*r->height, root, (hipStream_t)stream, "comm_reduce_accum");
 }
 
 } // extern "C"

@@ -172,6 +172,10 @@ struct tinsel_hip
     void* pinnedPtr = nullptr;          // caller's output buffer, page-locked in place (hipHostRegister) for the D2H DMA
     size_t pinnedBytes = 0;
 
+    // process-per-GPU arm of the reduce (tinsel_hip_comm_*, tn_host_group.h): this rank's RCCL communicator
+    void* comm = nullptr;               // ncclComm_t
+    int commRank = 0, commWorld = 0;
+
     bool timing = false;
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> eventPool;

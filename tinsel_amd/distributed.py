@@ -14,8 +14,37 @@ the accumulation buffer, a commutative float sum (render.cpp:439).  So
 One process per GPU; launched by torch.distributed.run (bench.py --gpus N).  The same shard + reduce inside ONE process,
 for the reference's single-threaded C++ caller, is the C-ABI's tinsel_hip_group (include/tinsel_hip.h;
 tinsel_amd.HipRendererGroup).
+
+ONE implementation of the collective on GPUs: the library's own ncclReduce (tn_host_group.h rccl_reduce_accum), entered by a group's
+worker threads and -- here -- by every rank of a process-per-GPU job through tinsel_hip_comm_* (`init_library_comm` + `reduce_accum(...,
+renderer=r)`).  torch.distributed is the launcher's plumbing: rendezvous, the 128-byte id's broadcast, barriers, the timing's max over
+ranks.  Without a library communicator (CPU tests under gloo; the one-device stand-in of bench.py) `reduce_accum` is torch's reduce.
 """
 import numpy as np
+
+
+def init_library_comm(renderer, rank, world, group=None):
+    """Collective over the torch.distributed group: rank 0 makes an RCCL unique id, torch carries it to the other ranks, every rank enters
+    tinsel_hip_comm_init on its renderer.  Returns the number of ranks RCCL itself reports for the communicator (ncclCommCount) when
+    EVERY rank succeeded, else 0 with the communicator dropped everywhere -- so the ranks agree on which reduce they will enter."""
+    import torch
+    import torch.distributed as dist
+    ids = [renderer.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(ids, src=0, group=group)
+    ok, seen = 1, 0
+    try:
+        renderer.comm_init(ids[0], rank, world)
+        seen = renderer.comm_size()
+        ok = 1 if seen == world else 0
+    except Exception:
+        ok = 0
+    if world > 1:
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag.item())
+    return seen if ok else 0
 
 
 def owned_mask(width, height, rank, world, tile=32):
@@ -28,9 +57,10 @@ def owned_mask(width, height, rank, world, tile=32):
     return (t % world) == rank
 
 
-def reduce_accum(accum, dst=0, group=None, out=None):
+def reduce_accum(accum, dst=0, group=None, out=None, renderer=None, rank=None):
     """The one collective of the path: the sum over ranks of the per-rank accumulators [H,W,4], returned on rank `dst`
-    (None elsewhere).  `accum` itself is left untouched on every rank -- it keeps the rank's OWN partial sums since
+    (None elsewhere).  `renderer` with a library communicator (init_library_comm) and `accum` its device accumulator: the library's own
+    ncclReduce on the current stream, into `out` (required on `dst`), then a wait for that stream.  `accum` itself is left untouched on every rank -- it keeps the rank's OWN partial sums since
     Init, so a later render + reduce_accum cannot count earlier samples twice (an in-place reduce would leave rank
     dst holding everyone's samples, and the gloo backend also overwrites the non-dst inputs).  The price is one
     accumulator-sized scratch tensor: `out` (same shape, dtype and device) when the caller keeps one -- it is filled
@@ -38,6 +68,13 @@ def reduce_accum(accum, dst=0, group=None, out=None):
     synchronises; a device tensor under a CPU backend (`gloo`: the one-device stand-in of bench.py) travels through
     host memory."""
     import torch.distributed as dist
+    if renderer is not None and renderer.comm_size() > 0:
+        import torch
+        me = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        if me == dst and out is None:
+            out = torch.empty_like(accum)
+        renderer.comm_reduce_accum(out.data_ptr() if (out is not None and me == dst) else None, dst, torch.cuda.current_stream().cuda_stream)
+        return out if me == dst else None
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         # one rank: the sum is the rank's own accumulator; a caller's `out` is filled like in the multi-rank paths
         if out is None:

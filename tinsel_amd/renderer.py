@@ -62,6 +62,10 @@ def load_library():
         L.tinsel_hip_get_tuning.argtypes = [vp, C.POINTER(abi.Tuning)]
         L.tinsel_hip_group_create_tuned.restype = vp
         L.tinsel_hip_group_create_tuned.argtypes = [C.POINTER(abi.SceneDesc), ci, ci, C.POINTER(abi.Tuning)]
+        L.tinsel_hip_comm_unique_id.argtypes = [vp, ci]
+        L.tinsel_hip_comm_init.argtypes = [vp, vp, ci, ci]
+        L.tinsel_hip_comm_size.argtypes = [vp]
+        L.tinsel_hip_comm_reduce_accum.argtypes = [vp, vp, ci, vp]
     L.tinsel_hip_destroy.restype = None
     L.tinsel_hip_destroy.argtypes = [vp]
     L.tinsel_hip_init.argtypes = [vp, ci, ci]
@@ -147,6 +151,7 @@ EXPORTED_SYMBOLS = [
     "tinsel_hip_group_size", "tinsel_hip_group_member", "tinsel_hip_group_set_lookahead", "tinsel_hip_ubench",
     "tinsel_hip_selftest_arith", "tinsel_hip_selftest_sort", "tinsel_hip_selftest_scan", "tinsel_hip_plan_regions",
     "tinsel_hip_tuning_init", "tinsel_hip_create_tuned", "tinsel_hip_set_tuning", "tinsel_hip_get_tuning", "tinsel_hip_group_create_tuned",
+    "tinsel_hip_comm_unique_id", "tinsel_hip_comm_init", "tinsel_hip_comm_size", "tinsel_hip_comm_reduce_accum",
 ]
 
 
@@ -267,6 +272,27 @@ class HipRenderer:
 
     def set_pipeline(self, pipeline):
         _check(self._L.tinsel_hip_set_pipeline(self._h, pipeline), "tinsel_hip_set_pipeline")
+
+    # -- the process-per-GPU arm of the one collective (tinsel_hip_comm_*): the library's own ncclReduce, the id carried by the host language
+    @staticmethod
+    def comm_unique_id():
+        """bytes of an RCCL unique id (rank 0 makes it, the host language hands it to the other ranks)"""
+        buf = (C.c_ubyte*abi.COMM_ID_BYTES)()
+        _check(load_library().tinsel_hip_comm_unique_id(buf, abi.COMM_ID_BYTES), "tinsel_hip_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, id_bytes, rank, world):
+        """collective: every rank calls it with rank 0's id"""
+        buf = (C.c_ubyte*abi.COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        _check(self._L.tinsel_hip_comm_init(self._h, buf, int(rank), int(world)), "tinsel_hip_comm_init")
+
+    def comm_size(self):
+        """ranks of this renderer's RCCL communicator as RCCL counts them (ncclCommCount); 0: none"""
+        return int(self._L.tinsel_hip_comm_size(self._h)) if hasattr(self._L, "tinsel_hip_comm_size") else 0
+
+    def comm_reduce_accum(self, out_ptr, root=0, stream=None):
+        """sum of every rank's accumulator into device memory `out_ptr` (W*H*4 floats) on `root`; waits for `stream`"""
+        _check(self._L.tinsel_hip_comm_reduce_accum(self._h, out_ptr, int(root), stream), "tinsel_hip_comm_reduce_accum")
 
     def set_tuning(self, tuning=None, **fields):
         """tinsel_hip_set_tuning: the per-render fields of an abi.Tuning (or of the tuning in force with `fields` replaced); the create-time
