@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 static_assert(sizeof(Primitive) == sizeof(tinsel_primitive), "Primitive layout");
 static_assert(sizeof(BVHNode) == sizeof(tinsel_bvh_node), "BVHNode layout");
@@ -109,6 +110,66 @@ extern "C" int HipRendererPresent(Renderer* r, const Options& options, Color* fi
 {
     HipRenderer* h = static_cast<HipRenderer*>(r);
     return h->group ? tinsel_hip_group_present(h->group, (const tinsel_options*)&options, nlmWidth, nlmFalloff, (float*)filtered) : -1;
+}
+
+// The NEXT FRAME of an animation on the renderer the caller already has.  The reference's batch mode (main.cpp:314-327) deletes its renderer
+// and re-runs Init per frame: loader, Scene::Build, a new GpuRenderer -- every mesh converted and uploaded again.  When `next` is `prev` (the
+// scene this renderer was created from, or last updated to) with other primitive transforms -- a rigid animation -- only the moved primitives'
+// records are rewritten (tinsel_hip_set_primitive_transform) and the scene level is rebuilt from next->bvh, the reference's own Scene::Build of
+// that frame (tinsel_hip_rebuild_scene): bit-identical to a renderer created from `next`.  The pass index goes back to 0, where a fresh renderer
+// starts.  Returns 0 when done; 1 when the frames differ in more than transforms (nothing changed: delete + CreateGpuRenderer, as the reference
+// does); -1 on error.
+static bool same_mesh(const MeshGeometry& a, const MeshGeometry& b)
+{
+    if (a.numVertices != b.numVertices || a.numIndices != b.numIndices || a.numNodes != b.numNodes || a.area != b.area)
+        return false;
+    return memcmp(a.positions, b.positions, sizeof(Vec3)*a.numVertices) == 0 && memcmp(a.normals, b.normals, sizeof(Vec3)*a.numVertices) == 0 &&
+           memcmp(a.indices, b.indices, sizeof(int)*a.numIndices) == 0 && memcmp(a.nodes, b.nodes, sizeof(BVHNode)*a.numNodes) == 0 &&
+           memcmp(a.cdf, b.cdf, sizeof(float)*(a.numIndices/3)) == 0;
+}
+
+extern "C" int HipRendererUpdateScene(Renderer* r, const Scene* prev, const Scene* next)
+{
+    HipRenderer* h = static_cast<HipRenderer*>(r);
+    if (!h->group || !prev || !next)
+        return -1;
+    const size_t P = prev->primitives.size();
+    if (next->primitives.size() != P || memcmp(&prev->sky.horizon, &next->sky.horizon, sizeof(Vec3)) != 0 || memcmp(&prev->sky.zenith, &next->sky.zenith, sizeof(Vec3)) != 0)
+        return 1;
+    const Probe &pa = prev->sky.probe, &pb = next->sky.probe;
+    if (pa.valid != pb.valid || (pa.valid && (pa.width != pb.width || pa.height != pb.height || memcmp(pa.data, pb.data, sizeof(Color)*pa.width*pa.height) != 0)))
+        return 1;
+    for (size_t i = 0; i < P; ++i)
+    {
+        const Primitive &a = prev->primitives[i], &b = next->primitives[i];
+        // (Material::bumpMap holds a host pointer -- bump mapping is dead code in the reference -- so the material is compared around it)
+        const char *ma = (const char*)&a.material, *mb = (const char*)&b.material;
+        if (a.type != b.type || a.lightSamples != b.lightSamples || memcmp(ma, mb, 88) != 0 || memcmp(ma + 96, mb + 96, sizeof(Material) - 96) != 0)
+            return 1;
+        if (a.type == eSphere && a.sphere.radius != b.sphere.radius)
+            return 1;
+        if (a.type == ePlane && memcmp(a.plane.plane, b.plane.plane, sizeof(a.plane.plane)) != 0)
+            return 1;
+        if (a.type == eMesh && !same_mesh(a.mesh, b.mesh))
+            return 1;
+    }
+    const int n = tinsel_hip_group_size(h->group);
+    for (int k = 0; k < n; ++k)
+    {
+        tinsel_hip* m = tinsel_hip_group_member(h->group, k);
+        for (size_t i = 0; i < P; ++i)
+        {
+            const Primitive &a = prev->primitives[i], &b = next->primitives[i];
+            if (memcmp(&a.startTransform, &b.startTransform, sizeof(Transform)) == 0 && memcmp(&a.endTransform, &b.endTransform, sizeof(Transform)) == 0)
+                continue;
+            if (tinsel_hip_set_primitive_transform(m, (int)i, (const tinsel_transform*)&b.startTransform, (const tinsel_transform*)&b.endTransform))
+                return -1;
+        }
+        if (tinsel_hip_rebuild_scene(m, TINSEL_SCENE_BVH_NODES, (const tinsel_bvh_node*)next->bvh.nodes, next->bvh.numNodes, NULL) ||
+            tinsel_hip_set_pass_index(m, 0))
+            return -1;
+    }
+    return 0;
 }
 
 extern "C" int HipRendererNumGpus(Renderer* r)

@@ -155,3 +155,33 @@ def test_headless_cli_and_resume(tmp_path, gold):
     _headless("-spp=4", "-width=32", "-height=16", "-out=%s" % pfm, pack)
     data = open(pfm, "rb").read()
     assert data.startswith(b"PF\n32 16\n-") and len(data) == data.index(b"\n", 10) + 1 + 32*16*12
+
+
+def test_headless_batch_mode_one_renderer_for_an_animation(tmp_path):
+    """main.cpp's batch / animation mode (:104-118 a `%d` file name, :314-327 PNG per frame, renderer deleted and re-created per frame) the
+    MI355X way: ONE renderer for the batch, frames that differ in primitive transforms only are updated in place
+    (tinsel_hip_set_primitive_transform + tinsel_hip_rebuild_scene from the frame's own nodes).  Four frames of a cornell box whose sphere moves
+    DURING each exposure and whose light drifts (tests/golden/make_animation.py: the reference's own Scene::Build per frame), then a fifth
+    frame that is another scene altogether: every PNG must be, byte for byte, the file a fresh renderer writes for that frame alone."""
+    import shutil
+    for k in range(4):
+        shutil.copy(os.path.join(GOLDEN, "anim_cornell_%d.pack" % k), tmp_path / ("anim_%d.pack" % k))
+    shutil.copy(os.path.join(GOLDEN, "veach.pack"), tmp_path / "anim_4.pack")
+    args = ["-spp=24", "-width=96", "-height=64"]
+    out = _headless(*args, str(tmp_path / "anim_%d.pack"))
+    ready = [l for l in out.splitlines() if l.startswith("frame ")]
+    assert len(ready) == 5, out
+    assert "renderer created" in ready[0] and all("updated in place" in l for l in ready[1:4]) and "re-created" in ready[4], ready
+    assert "5 frames" in out and "3 later frames updated in place" in out
+    frames = []
+    for k in range(5):
+        batch_png = tmp_path / ("anim_%d.pack.png" % k)                 # (main.cpp:113-115: input file + ".png")
+        fresh_png = tmp_path / ("fresh_%d.png" % k)
+        _headless(*args, "-out=%s" % fresh_png, str(tmp_path / ("anim_%d.pack" % k)))
+        a, b = open(batch_png, "rb").read(), open(fresh_png, "rb").read()
+        assert a == b, "frame %d: the batch's PNG differs from a fresh renderer's" % k
+        frames.append(a)
+    assert len(set(frames)) == 5                                        # (the frames really differ)
+    # -out with a %d: the caller's own naming
+    _headless(*args, "-out=%s" % (tmp_path / "f%02d.png"), str(tmp_path / "anim_%d.pack"))
+    assert open(tmp_path / "f02.png", "rb").read() == frames[2]

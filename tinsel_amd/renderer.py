@@ -187,6 +187,48 @@ class Scene:
         return self.desc.num_primitives
 
 
+def _bytes_at(ptr, n):
+    return C.string_at(ptr, n) if (ptr and n > 0) else b""
+
+
+def scene_delta(old: Scene, new: Scene):
+    """What turns a renderer created from `old` into one for `new` WITHOUT re-uploading anything: ([(primitive, start, end)], the new scene
+    BVH's nodes) when `new` is `old` with other primitive transforms -- the frames of a rigid animation, what the reference's batch mode
+    re-loads and re-creates per frame (main.cpp:314-327) -- else None (geometry, materials, lights, sky or probe differ: re-create)."""
+    a, b = old.desc, new.desc
+    if a.num_primitives != b.num_primitives or bytes(a.sky_horizon) != bytes(b.sky_horizon) or bytes(a.sky_zenith) != bytes(b.sky_zenith):
+        return None
+    if (a.probe_valid, a.probe_width, a.probe_height) != (b.probe_valid, b.probe_width, b.probe_height):
+        return None
+    if a.probe_valid and _bytes_at(a.probe_data, a.probe_width*a.probe_height*16) != _bytes_at(b.probe_data, b.probe_width*b.probe_height*16):
+        return None
+    P = a.num_primitives
+    pa, pb = (abi.Primitive*P).from_address(a.primitives), (abi.Primitive*P).from_address(b.primitives)
+    moves = []
+    for i in range(P):
+        x, y = pa[i], pb[i]
+        mx, my = bytes(x.material), bytes(y.material)
+        # (the material's bump-map texture is a host pointer at bytes [88, 96): bump mapping is dead code in the reference and not uploaded)
+        if x.type != y.type or x.light_samples != y.light_samples or mx[:88] != my[:88] or mx[96:] != my[96:]:
+            return None
+        if x.type == abi.GEOM_SPHERE and x.geo.sphere.radius != y.geo.sphere.radius:
+            return None
+        if x.type == abi.GEOM_PLANE and bytes(x.geo.plane) != bytes(y.geo.plane):
+            return None
+        if x.type == abi.GEOM_MESH:
+            g, h = x.geo.mesh, y.geo.mesh
+            if (g.num_vertices, g.num_indices, g.num_nodes, g.area) != (h.num_vertices, h.num_indices, h.num_nodes, h.area):
+                return None
+            for f, n in (("positions", g.num_vertices*12), ("normals", g.num_vertices*12), ("indices", g.num_indices*4), ("nodes", g.num_nodes*32),
+                         ("cdf", (g.num_indices//3)*4)):
+                if _bytes_at(getattr(g, f), n) != _bytes_at(getattr(h, f), n):
+                    return None
+        if bytes(x.start_transform) != bytes(y.start_transform) or bytes(x.end_transform) != bytes(y.end_transform):
+            moves.append((i, abi.Transform.from_buffer_copy(bytes(y.start_transform)), abi.Transform.from_buffer_copy(bytes(y.end_transform))))
+    nodes = (abi.BVHNode*b.num_bvh_nodes).from_buffer_copy(_bytes_at(b.bvh_nodes, b.num_bvh_nodes*C.sizeof(abi.BVHNode)))
+    return moves, nodes
+
+
 class HipRenderer:
     """`Renderer` (render.h:66-73) implemented by the gfx950 streaming path tracer."""
 
@@ -335,6 +377,20 @@ class HipRenderer:
             rc = self._L.tinsel_hip_rebuild_scene(self._h, abi.SCENE_BVH_NODES, C.cast(nodes, C.c_void_p), len(nodes), C.byref(ms))
         _check(rc, "tinsel_hip_rebuild_scene")
         return ms.value
+
+    def update_scene(self, old: Scene, new: Scene):
+        """The next frame of an animation on THIS renderer: when `new` is `old` (the scene this renderer holds) with other primitive transforms,
+        the moved primitives' records are rewritten in place and the scene level is rebuilt from `new`'s own nodes (the reference's
+        Scene::Build for that frame) -- bit-identical to a renderer created from `new`, nothing re-uploaded.  False (and nothing changed)
+        when the frames differ in more than that: the caller re-creates, as the reference always does (main.cpp:318-327)."""
+        d = scene_delta(old, new)
+        if d is None:
+            return False
+        moves, nodes = d
+        for i, s, e in moves:
+            self.set_primitive_transform(i, s, e)
+        self.rebuild_scene(nodes)
+        return True
 
     def set_probe_sampling(self, mode):
         """abi.PROBE_CDF (the reference's binary searches: sample-identical) or abi.PROBE_ALIAS (O(1) alias table: same distribution)."""
