@@ -12,8 +12,10 @@ legs, per-rank statistics -- go to bench_detail.json beside this file (and to st
   configs[0]   BASELINE configs[2]: data/ajax.tin with the 524,288-triangle stand-in mesh (ajax.obj is not in the reference tree)
                at 1920x1080 maxDepth 4 -- the configuration whose scene lives in HBM / the Infinity Cache (HBM fractions from
                counter bytes; the node-visit rate of k_walk next to this GPU's record-chase ceilings in the detail file).
-  configs[1]   BASELINE configs[3]: data/glass.tin 1920x1080 maxDepth 12.
-  configs[2]   BASELINE configs[4]: data/veach.tin 3840x2160 (at N = 1 the whole frame; at N > 1 every rank's pixel tiles of it).
+  configs[1]   the same configuration with a REAL scanned mesh: the reference's Aphrodite_from_jotero_com.obj, 1 -> 4 subdivided to 427,384
+               triangles by the reference's own importer and builder (tests/golden/make_large.py aphrodite) -- an irregular tree.
+  configs[2]   BASELINE configs[3]: data/glass.tin 1920x1080 maxDepth 12.
+  configs[3]   BASELINE configs[4]: data/veach.tin 3840x2160 (at N = 1 the whole frame; at N > 1 every rank's pixel tiles of it).
 
 Scenes come from scene packs written by the reference's own loader (tests/golden/*.pack); camera rays, RNG seeds and
 everything downstream are generated on the GPU, so inputs are resident in HBM when a timed region starts, and the
@@ -65,6 +67,7 @@ VALU_PEAK = SIMDS*CLOCK_HZ/2    # a wave64 VALU instruction issues over 2 cycles
 MIN_TIMED_S = 0.5
 GROUP_LEG_LIMIT_S = 60            # each tinsel_hip_group leg of an N-rank run (child process of rank 0, after the ranks' timed regions)
 LARGE = "large/ajax_standin"
+REAL_MESH = "large/ajax_aphrodite"   # config 3 once more: ajax.tin with the reference's own Aphrodite scan, 1 -> 4 subdivided (427,384 triangles, an irregular tree)
 YARD = [None]                   # this run's yard-sticks (yard_sticks(): stream copy, record chases), N = 1 only
 
 
@@ -879,8 +882,8 @@ ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_model", "ker
                  "frac_survey_8d", "useful_frac", "frac_hbm_compulsory", "frac_hbm_counter", "frac_hbm_algorithmic", "valu_frac_of_issue_peak",
                  "job_counter_over_compulsory", "valu_lanes_active", "wave_cycles_waiting", "waves_per_simd", "l2_hit_rate")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
-BASELINE_INDEX = {"cornell": 1, LARGE: 2, "glass": 3, "veach": 4}      # scene -> index into BASELINE.json's `configs`
-CONFIG_SPP = {"cornell": 256, LARGE: 512, "glass": 1024, "veach": 4096}
+BASELINE_INDEX = {"cornell": 1, LARGE: 2, REAL_MESH: 2, "glass": 3, "veach": 4}      # scene -> index into BASELINE.json's `configs`
+CONFIG_SPP = {"cornell": 256, LARGE: 512, REAL_MESH: 512, "glass": 1024, "veach": 4096}
 
 
 def _round(o, digits=5):
@@ -932,7 +935,7 @@ def contract_line(args, world, head, more=(), group=None, group5=None, detail_fi
         # the same K full-frame passes as N = 1 split over the ranks (north_star's 8-GPU configuration is a FIXED job); at N = 1 the two coincide
         "value_fixed_work": (head.get("strong") or {}).get("msamples_s") if world > 1 else head["value"],
         "reduce_impl": (head.get("reduce") or {}).get("impl"), "rccl_ranks_seen": (head.get("reduce") or {}).get("rccl_ranks_seen"),
-        "data": "synthetic: the reference's scene files as scene packs (ajax: a procedural 524,288-triangle stand-in); rays, seeds and all downstream generated on the GPU",
+        "data": "synthetic: the reference's scene files as scene packs (ajax.obj is a missing blob: a procedural 524,288-triangle stand-in, and the reference's Aphrodite scan x4); rays, seeds and all downstream generated on the GPU",
         "config": _pick(head["config"], ("workload", "scene_pack", "parallelism", "rays_per_sample")),
         "mrays_per_s": head.get("mrays_per_s"),
         "roofline": _pick(head.get("roofline"), ROOFLINE_KEYS),
@@ -1050,7 +1053,10 @@ def main():
             another(LARGE, 1920, 1080, 4, what)
         else:
             more.append({"config": {"workload": what},
-                         "unavailable": "tests/golden/large/ajax_standin.pack is not on this box (72 MB, git-ignored; written by tests/golden/make_large.py)"})
+                         "unavailable": "tests/golden/large/ajax_standin.pack is not on this box (48 MB, git-ignored; written by tests/golden/make_large.py)"})
+        # ... and with a REAL scanned mesh in the stand-in's place (SURVEY.md 0.1's other option): an irregular SAH tree
+        if os.path.exists(os.path.join(ROOT, "tests", "golden", REAL_MESH + ".pack")):
+            another(REAL_MESH, 1920, 1080, 4, "ajax.tin + Aphrodite scan (427,384 triangles) 1920x1080 maxDepth=4")
     if default_headline and not args.no_more_configs:
         if world == 1:
             another("glass", 1920, 1080, 12, "glass.tin 1920x1080 maxDepth=12")     # BASELINE configs[3]

@@ -43,6 +43,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 #include <vector>
 
@@ -209,6 +210,83 @@ int ref_scene_add_standin_mesh(void* h, int slices, int segments, float scale, c
     rs->scene.bvh.nodes = NULL;
     rs->scene.Build();
     return 0;
+}
+
+// A REAL scanned mesh for data/ajax.tin (SURVEY.md 0.1's other option: ajax.obj is a missing blob, the largest shipped mesh is
+// data/meshes/Aphrodite_from_jotero_com.obj, 106,846 triangles): the reference's own ImportMesh (mesh.cpp:105-132: importer, Normalize,
+// CalculateNormals, RebuildBVH), then `subdivisions` rounds of 1 -> 4 midpoint subdivision (every edge's midpoint shared by the two
+// triangles on it) and the same post-processing again -- Normalize, CalculateNormals, the reference's SAH BVHBuilder, RebuildCDF.  An
+// IRREGULAR tree (a scan: triangle sizes over two orders of magnitude), unlike the stand-in's regular tessellation.
+// `axisShift`: the file's axes cyclically shifted by that many places first (new[(i + shift) % 3] = old[i]: a proper rotation of the mesh data,
+// so that the primitive keeps ajax.tin's identity rotation) -- the Aphrodite scan's up axis is z.
+int ref_scene_add_obj_mesh(void* h, const char* path, int subdivisions, int axisShift, float scale, const tinsel_material* material, int insertAt)
+{
+    RefScene* rs = (RefScene*)h;
+    Mesh* mesh = ImportMesh(path);
+    if (!mesh)
+        return -1;
+    axisShift = ((axisShift % 3) + 3) % 3;
+    if (axisShift)
+        for (size_t i = 0; i < mesh->positions.size(); ++i)
+        {
+            const float old[3] = { mesh->positions[i].x, mesh->positions[i].y, mesh->positions[i].z };
+            float nw[3];
+            for (int c = 0; c < 3; ++c)
+                nw[(c + axisShift) % 3] = old[c];
+            mesh->positions[i] = Vec3(nw[0], nw[1], nw[2]);
+        }
+    for (int round = 0; round < subdivisions; ++round)
+    {
+        std::map<std::pair<int, int>, int> mid;
+        std::vector<int> out;
+        out.reserve(mesh->indices.size()*4);
+        auto midpoint = [&](int a, int b) -> int {
+            const std::pair<int, int> key(a < b ? a : b, a < b ? b : a);
+            std::map<std::pair<int, int>, int>::iterator it = mid.find(key);
+            if (it != mid.end())
+                return it->second;
+            const int idx = (int)mesh->positions.size();
+            mesh->positions.push_back((mesh->positions[a] + mesh->positions[b])*0.5f);
+            mid[key] = idx;
+            return idx;
+        };
+        const size_t numTris = mesh->indices.size()/3;
+        for (size_t t = 0; t < numTris; ++t)
+        {
+            const int a = mesh->indices[t*3 + 0], b = mesh->indices[t*3 + 1], c = mesh->indices[t*3 + 2];
+            const int ab = midpoint(a, b), bc = midpoint(b, c), ca = midpoint(c, a);
+            const int tri[12] = { a, ab, ca, ab, b, bc, ca, bc, c, ab, bc, ca };
+            out.insert(out.end(), tri, tri + 12);
+        }
+        mesh->indices.swap(out);
+    }
+    if (subdivisions > 0 || axisShift)
+    {
+        mesh->normals.resize(mesh->positions.size());
+        mesh->Normalize();
+        mesh->CalculateNormals();
+        mesh->RebuildBVH();
+    }
+
+    rs->extraMeshes.push_back(mesh);
+    rs->scene.meshes.push_back(mesh);
+
+    Primitive prim;
+    prim.type = eMesh;
+    prim.mesh = GeometryFromMesh(mesh);
+    prim.startTransform = Transform(Vec3(0.0f), Quat(), scale);
+    prim.endTransform = prim.startTransform;
+    memcpy(&prim.material, material, sizeof(Material));
+    prim.lightSamples = 0;
+
+    if (insertAt < 0 || insertAt > (int)rs->scene.primitives.size())
+        insertAt = (int)rs->scene.primitives.size();
+    rs->scene.primitives.insert(rs->scene.primitives.begin() + insertAt, prim);
+
+    delete[] rs->scene.bvh.nodes;
+    rs->scene.bvh.nodes = NULL;
+    rs->scene.Build();
+    return (int)(mesh->indices.size()/3);
 }
 
 // A primitive moves: new start / end transforms, then the reference's own Scene::Build (scene.cpp:4-16: BVHBuilder over

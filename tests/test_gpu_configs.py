@@ -20,6 +20,9 @@ from tests import oracle_api as oa
 pytestmark = pytest.mark.gpu
 
 LARGE = os.path.join(oa.GOLDEN, "large", "ajax_standin.pack")
+# config 3 once more with a REAL scanned mesh: the reference's Aphrodite_from_jotero_com.obj, 1 -> 4 subdivided to 427,384 triangles, imported and
+# built by the reference itself (tests/golden/make_large.py aphrodite): an irregular SAH tree where the stand-in is a regular tessellation
+APHRODITE = os.path.join(oa.GOLDEN, "large", "ajax_aphrodite.pack")
 
 CONFIGS = [
     # name, pack, W, H, maxDepth, window origin
@@ -130,7 +133,8 @@ def _busiest_window(scene, cam, opt, size=96, step=48):
     ("cfg5 veach 3840x2160", os.path.join(oa.GOLDEN, "veach.pack"), 3840, 2160, 4, 137),
     ("cfg4 glass 1920x1080 depth 12", os.path.join(oa.GOLDEN, "glass.pack"), 1920, 1080, 12, 1000),
     ("cfg3 ajax stand-in 524288 tris 1920x1080", LARGE, 1920, 1080, 4, 211),
-], ids=["cfg5", "cfg4", "cfg3"])
+    ("cfg3 ajax.tin + Aphrodite 427384 tris 1920x1080", APHRODITE, 1920, 1080, 4, 173),
+], ids=["cfg5", "cfg4", "cfg3", "cfg3-aphrodite"])
 def test_silhouette_window_at_a_late_pass_is_bit_identical(label, pack, W, H, depth, pass_index):
     """A second window per big config, placed by the scene itself on its busiest silhouettes (incoherent traversal, rays
     that graze the mesh, k_walk with half-empty waves) and at a pass index in the hundreds (the seed chain far from its
@@ -163,6 +167,7 @@ FULL_FRAMES = [
     # label, pack, W, H, maxDepth, spp: what the reference's own PathTrace does in seconds on the GPU box's host threads
     ("cfg2 cornell 1024x1024 spp 256 (the config's own spp)", os.path.join(oa.GOLDEN, "cornell.pack"), 1024, 1024, 4, 256),
     ("cfg3 ajax stand-in 524288 tris 1920x1080 spp 8", LARGE, 1920, 1080, 4, 8),
+    ("cfg3-aphrodite ajax.tin + Aphrodite 427384 tris 1920x1080 spp 8", APHRODITE, 1920, 1080, 4, 8),
     ("cfg4 glass 1920x1080 depth 12 spp 4", os.path.join(oa.GOLDEN, "glass.pack"), 1920, 1080, 12, 4),
     ("cfg5 veach 3840x2160 spp 2", os.path.join(oa.GOLDEN, "veach.pack"), 3840, 2160, 4, 2),
 ]
@@ -201,3 +206,28 @@ def test_whole_frame_equals_the_reference(label, pack, W, H, depth, spp):
         label, type(O).__name__, l2, 100.0*same, t_gpu, t_cpu, trace_s, os.cpu_count() or 1))
     assert np.array_equal(out, want), "%s: %d pixels differ, L2 %.3e" % (label, int((out != want).any(axis=-1).sum()), l2)
     assert np.isfinite(out).all() and (out[..., 3] > 0).mean() > 0.99      # (at 2 spp a pixel may sit between every footprint)
+
+
+@pytest.mark.skipif(not os.path.exists(APHRODITE), reason="tests/golden/large/ajax_aphrodite.pack not generated (make_large.py aphrodite)")
+@pytest.mark.parametrize("bvh", [abi.BVH_LBVH, abi.BVH_PLOC], ids=["lbvh", "ploc"])
+def test_real_mesh_under_device_built_trees(bvh):
+    """The scanned mesh under the device builders (tn_lbvh.h): an irregular triangle soup (sizes over two orders of magnitude, long thin
+    triangles from the scan) is what Morton-order builders handle worst.  Same hits as the reference's tree except exact-t ties."""
+    import tinsel_amd
+    scene = tinsel_amd.Scene.load_pack(APHRODITE)
+    cam, opt = scene.camera, scene.options.copy()
+    opt.width, opt.height, opt.max_depth = 480, 270, 4
+    r = tinsel_amd.create_gpu_renderer(scene)
+    assert r.walked_prims == 1
+    r.init(opt.width, opt.height)
+    want = r.render(cam, opt, passes=2)
+    rad_ref = r.batch_radiance(2, opt.height, opt.width)
+    ms = r.set_mesh_bvh(bvh)
+    r.init(opt.width, opt.height)
+    r.set_pass_index(0)
+    out = r.render(cam, opt, passes=2)
+    rad = r.batch_radiance(2, opt.height, opt.width)
+    r.close()
+    same = float((rad == rad_ref).all(axis=-1).mean())
+    print("aphrodite 427,384 triangles: device tree built in %.2f ms, %.4f %% of the paths identical to the reference tree's" % (ms, 100.0*same))
+    assert same >= 0.999 and oa.image_l2(out, want) <= 1e-3
