@@ -119,13 +119,55 @@ extern "C" int HipRendererPresent(Renderer* r, const Options& options, Color* fi
 // that frame (tinsel_hip_rebuild_scene): bit-identical to a renderer created from `next`.  The pass index goes back to 0, where a fresh renderer
 // starts.  Returns 0 when done; 1 when the frames differ in more than transforms (nothing changed: delete + CreateGpuRenderer, as the reference
 // does); -1 on error.
-static bool same_mesh(const MeshGeometry& a, const MeshGeometry& b)
+static const char* mesh_difference(const MeshGeometry& a, const MeshGeometry& b)
 {
-    if (a.numVertices != b.numVertices || a.numIndices != b.numIndices || a.numNodes != b.numNodes || a.area != b.area)
-        return false;
-    return memcmp(a.positions, b.positions, sizeof(Vec3)*a.numVertices) == 0 && memcmp(a.normals, b.normals, sizeof(Vec3)*a.numVertices) == 0 &&
-           memcmp(a.indices, b.indices, sizeof(int)*a.numIndices) == 0 && memcmp(a.nodes, b.nodes, sizeof(BVHNode)*a.numNodes) == 0 &&
-           memcmp(a.cdf, b.cdf, sizeof(float)*(a.numIndices/3)) == 0;
+    if (a.numVertices != b.numVertices || a.numIndices != b.numIndices || a.numNodes != b.numNodes)
+        return "mesh topology";
+    if (a.area != b.area)
+        return "mesh area";
+    if (memcmp(a.positions, b.positions, sizeof(Vec3)*a.numVertices) != 0) return "mesh vertex positions";
+    if (memcmp(a.normals, b.normals, sizeof(Vec3)*a.numVertices) != 0) return "mesh vertex normals";
+    if (memcmp(a.indices, b.indices, sizeof(int)*a.numIndices) != 0) return "mesh indices";
+    if (memcmp(a.nodes, b.nodes, sizeof(BVHNode)*a.numNodes) != 0) return "mesh BVH";
+    if (memcmp(a.cdf, b.cdf, sizeof(float)*(a.numIndices/3)) != 0) return "mesh area CDF";
+    return NULL;
+}
+
+// what keeps `next` from being `prev` with other primitive transforms (NULL: nothing); *prim: the primitive, or -1
+static const char* scene_difference(const Scene* prev, const Scene* next, int* prim)
+{
+    *prim = -1;
+    const size_t P = prev->primitives.size();
+    if (next->primitives.size() != P)
+        return "number of primitives";
+    if (memcmp(&prev->sky.horizon, &next->sky.horizon, sizeof(Vec3)) != 0 || memcmp(&prev->sky.zenith, &next->sky.zenith, sizeof(Vec3)) != 0)
+        return "sky";
+    const Probe &pa = prev->sky.probe, &pb = next->sky.probe;
+    if (pa.valid != pb.valid || (pa.valid && (pa.width != pb.width || pa.height != pb.height || memcmp(pa.data, pb.data, sizeof(Color)*pa.width*pa.height) != 0)))
+        return "probe";
+    for (size_t i = 0; i < P; ++i)
+    {
+        const Primitive &a = prev->primitives[i], &b = next->primitives[i];
+        *prim = (int)i;
+        if (a.type != b.type)
+            return "primitive type";
+        if (a.lightSamples != b.lightSamples)
+            return "lightSamples";
+        // (the material's parameters: bytes [0, 84) and [112, 128) -- between them 4 bytes of padding, whatever the loader's stack held, and
+        // Material::bumpMap, a host pointer + sizes of a texture the integrator never reads: bump mapping is dead code in the reference)
+        const char *ma = (const char*)&a.material, *mb = (const char*)&b.material;
+        if (memcmp(ma, mb, 84) != 0 || memcmp(ma + 112, mb + 112, sizeof(Material) - 112) != 0)
+            return "material";
+        if (a.type == eSphere && a.sphere.radius != b.sphere.radius)
+            return "sphere radius";
+        if (a.type == ePlane && memcmp(a.plane.plane, b.plane.plane, sizeof(a.plane.plane)) != 0)
+            return "plane equation";
+        if (a.type == eMesh)
+            if (const char* why = mesh_difference(a.mesh, b.mesh))
+                return why;
+    }
+    *prim = -1;
+    return NULL;
 }
 
 extern "C" int HipRendererUpdateScene(Renderer* r, const Scene* prev, const Scene* next)
@@ -133,26 +175,16 @@ extern "C" int HipRendererUpdateScene(Renderer* r, const Scene* prev, const Scen
     HipRenderer* h = static_cast<HipRenderer*>(r);
     if (!h->group || !prev || !next)
         return -1;
-    const size_t P = prev->primitives.size();
-    if (next->primitives.size() != P || memcmp(&prev->sky.horizon, &next->sky.horizon, sizeof(Vec3)) != 0 || memcmp(&prev->sky.zenith, &next->sky.zenith, sizeof(Vec3)) != 0)
-        return 1;
-    const Probe &pa = prev->sky.probe, &pb = next->sky.probe;
-    if (pa.valid != pb.valid || (pa.valid && (pa.width != pb.width || pa.height != pb.height || memcmp(pa.data, pb.data, sizeof(Color)*pa.width*pa.height) != 0)))
-        return 1;
-    for (size_t i = 0; i < P; ++i)
+    int where = -1;
+    if (const char* why = scene_difference(prev, next, &where))
     {
-        const Primitive &a = prev->primitives[i], &b = next->primitives[i];
-        // (Material::bumpMap holds a host pointer -- bump mapping is dead code in the reference -- so the material is compared around it)
-        const char *ma = (const char*)&a.material, *mb = (const char*)&b.material;
-        if (a.type != b.type || a.lightSamples != b.lightSamples || memcmp(ma, mb, 88) != 0 || memcmp(ma + 96, mb + 96, sizeof(Material) - 96) != 0)
-            return 1;
-        if (a.type == eSphere && a.sphere.radius != b.sphere.radius)
-            return 1;
-        if (a.type == ePlane && memcmp(a.plane.plane, b.plane.plane, sizeof(a.plane.plane)) != 0)
-            return 1;
-        if (a.type == eMesh && !same_mesh(a.mesh, b.mesh))
-            return 1;
+        if (where >= 0)
+            fprintf(stderr, "HipRendererUpdateScene: the frames differ in more than transforms (primitive %d: %s)\n", where, why);
+        else
+            fprintf(stderr, "HipRendererUpdateScene: the frames differ in more than transforms (%s)\n", why);
+        return 1;
     }
+    const size_t P = prev->primitives.size();
     const int n = tinsel_hip_group_size(h->group);
     for (int k = 0; k < n; ++k)
     {

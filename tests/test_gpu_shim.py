@@ -61,7 +61,7 @@ def test_cxx_batch_mode_updates_one_renderer_in_place(tmp_path):
     out = subprocess.run([EXE, str(tmp_path / "f%d.tin")] + args, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     ready = [l for l in out.stdout.splitlines() if l.startswith("frame ")]
-    assert len(ready) == 4 and "renderer created" in ready[0] and "updated in place" in ready[1] and "updated in place" in ready[2] and "re-created" in ready[3], out.stdout
+    assert len(ready) == 4 and "renderer created" in ready[0] and "updated in place" in ready[1] and "updated in place" in ready[2] and "re-created" in ready[3], "\n".join(ready) + out.stderr[-1500:]
     pngs = []
     for k in range(4):
         alone = tmp_path / ("alone%d.png" % k)

@@ -57,13 +57,27 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
     const size_t K = split ? (size_t)r->neePerPath : 0;
     // (half as many again as the widest grid: the short regions at the end of a batch, split_tail_regions)
     const size_t maxRegions = (size_t)r->numCUs*(size_t)grid_mult(r)*(kBlock/kWave)*3/2;
-    const size_t cap = slots + maxRegions*kWave;        // a region is a whole number of waves long
+    const size_t cap = (slots + maxRegions*kWave + kWave - 1)/kWave*kWave;       // a region is a whole number of waves long; whole 64-position blocks
     SplitState& ss = r->ss;
     memset(&ss, 0, sizeof(ss));
+#if TN_STATE_BLOCKS
+    if (cap*kStateFields >= 0xffffffffull)      // (sidx() is 32-bit arithmetic; 858 M positions are 250 GB of path state anyway)
+        return fail("render: batch too large for the path-state blocks");
+#endif
     for (int b = 0; b < 2; ++b)
+    {
+#if TN_STATE_BLOCKS
+        // ONE allocation per buffer: blocks of 64 positions x 5 fields (tn_layout.h); a field's pointer is its first block entry
+        float4* base = nullptr;
+        if (batch_alloc(r, &base, cap*kStateFields))
+            return -1;
+        ss.rayO[b] = base; ss.rayD[b] = base + 64; ss.thr[b] = base + 128; ss.rad[b] = base + 192; ss.rngId[b] = base + 256;
+#else
         if (batch_alloc(r, &ss.rayO[b], cap) || batch_alloc(r, &ss.rayD[b], cap) || batch_alloc(r, &ss.thr[b], cap) ||
             batch_alloc(r, &ss.rad[b], cap) || batch_alloc(r, &ss.rngId[b], cap))
             return -1;
+#endif
+    }
     if (batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)) ||
         batch_alloc(r, &r->regionOrder, maxRegions/(kBlock/kWave)) || batch_alloc(r, &r->regionOrderNee, maxRegions/(kBlock/kWave)))
         return -1;
@@ -77,7 +91,20 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
     if (!split)
         return 0;
 
+#if TN_STATE_BLOCKS
+    {
+        // the hand-over records by position, one block of 64: hit (1 KB) | hit primitive (256 B) | NEE position (256 B)
+        float4* hbase = nullptr;
+        if (batch_alloc(r, &hbase, cap/kWave*kHitBlockF4))
+            return -1;
+        ss.hit = hbase;
+        ss.hitPrim = reinterpret_cast<int32_t*>(hbase) + 256;
+        ss.pathNee = reinterpret_cast<uint32_t*>(hbase) + 320;
+    }
+    if (
+#else
     if (batch_alloc(r, &ss.hit, cap) || batch_alloc(r, &ss.hitPrim, cap) || batch_alloc(r, &ss.pathNee, K ? cap : 1) ||
+#endif
         batch_alloc(r, &ss.neeRay, cap*K*2) || batch_alloc(r, &ss.neeSky, r->scene.probe.valid ? cap : 1) ||
         batch_alloc(r, &ss.neeTime, K ? cap : 1) || batch_alloc(r, &ss.neeRes, cap*K) ||
         batch_alloc(r, &ss.neeFront, maxRegions*(size_t)maxDepth) || batch_alloc(r, &ss.neeBack, maxRegions*(size_t)maxDepth))

@@ -305,14 +305,14 @@ TN_D bool begin_path(const CameraParams& cam, const FrameParams& fp, const uint3
 // local too.
 struct SplitState
 {
-    float4* rayO[2];    // [bounce & 1][position]: origin.xyz, time
+    float4* rayO[2];    // [bounce & 1][sidx(position)]: origin.xyz, time
     float4* rayD[2];    // dir.xyz, bsdfPdf
     float4* thr[2];     // throughput.xyz, rayEta
     float4* rad[2];     // radiance.xyz, rayType (int bits)
     float4* rngId[2];   // rng.s1, rng.s2, path slot (bits), the medium the ray travels in (PathRegs::medium: a primitive index as bits, -1 = none)
-    float4* hit;        // [position] this bounce's closest hit: t, n.xyz
-    int32_t* hitPrim;
-    uint32_t* pathNee;  // [position] NEE position q of the path's shadow rays of this bounce
+    float4* hit;        // [hidx(position)] this bounce's closest hit: t, n.xyz
+    int32_t* hitPrim;   // [hidx1(position)]
+    uint32_t* pathNee;  // [hidx1(position)] NEE position q of the path's shadow rays of this bounce
     float4* neeRay;     // [(k*2 + {0, 1})*capacity + q] = {o, dist} {wi, nl}: lanes are consecutive q        (k_lights -> k_walk, k_shadow, k_shade)
     float4* neeSky;     // [q] the probe sample's {skyColor, skyPdf}                                           (k_lights -> k_shade)
     float* neeTime;     // [q] rayTime of the path                                                              (k_lights -> k_walk, k_shadow)
@@ -386,8 +386,9 @@ TN_D StateBuf state_buf(const SplitState& ss, int buf) { StateBuf b = { ss.rayO[
 
 TN_D void load_state(const DevScene& sc, const StateBuf& sb, uint32_t pos, PathRegs& p, uint32_t& slot, bool hasMedia)
 {
-    const float4 ro = sb.rayO[pos], rd = sb.rayD[pos], th = sb.thr[pos], ra = sb.rad[pos];
-    const float4 rr = sb.rngId[pos];
+    const uint32_t at = sidx(pos);
+    const float4 ro = sb.rayO[at], rd = sb.rayD[at], th = sb.thr[at], ra = sb.rad[at];
+    const float4 rr = sb.rngId[at];
     p.o = V3(ro.x, ro.y, ro.z); p.time = ro.w;
     p.d = V3(rd.x, rd.y, rd.z); p.bsdfPdf = rd.w;
     p.thr = V3(th.x, th.y, th.z); p.eta = th.w;
@@ -405,11 +406,12 @@ TN_D void load_state(const DevScene& sc, const SplitState& ss, int buf, uint32_t
 
 TN_D void store_state(const StateBuf& sb, uint32_t pos, const PathRegs& p, uint32_t slot)
 {
-    sb.rayO[pos] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
-    sb.rayD[pos] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
-    sb.thr[pos] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
-    sb.rad[pos] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
-    sb.rngId[pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), __int_as_float(p.medium));
+    const uint32_t at = sidx(pos);
+    sb.rayO[at] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
+    sb.rayD[at] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
+    sb.thr[at] = make_float4(p.thr.x, p.thr.y, p.thr.z, p.eta);
+    sb.rad[at] = make_float4(p.rad.x, p.rad.y, p.rad.z, __int_as_float(p.rayType));
+    sb.rngId[at] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), __int_as_float(p.medium));
 }
 
 TN_D void store_state(const SplitState& ss, int buf, uint32_t pos, const PathRegs& p, uint32_t slot)
@@ -930,9 +932,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(SplitState ss, QueueCtl 
             if (live)
             {
                 // ray and RNG only: the rest of a fresh path's state is constant and k_shade knows it (ShadeFetch::issue)
-                ss.rayO[0][pos] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
-                ss.rayD[0][pos] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
-                ss.rngId[0][pos] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), __int_as_float(-1));
+                const uint32_t at = sidx(pos);
+                ss.rayO[0][at] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
+                ss.rayD[0][at] = make_float4(p.d.x, p.d.y, p.d.z, p.bsdfPdf);
+                ss.rngId[0][at] = make_float4(__uint_as_float(p.rng.s1), __uint_as_float(p.rng.s2), __uint_as_float(slot), __int_as_float(-1));
             }
         }
         if (lane == 0)
@@ -974,7 +977,7 @@ TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& b
     bool front = bp.count == 0;         // no big mesh: everything goes to the front
     if (has)
     {
-        const float2 rr = *reinterpret_cast<const float2*>(ss.rngId[cur] + pos);
+        const float2 rr = *reinterpret_cast<const float2*>(ss.rngId[cur] + sidx(pos));
         rng.s1 = __float_as_uint(rr.x); rng.s2 = __float_as_uint(rr.y);
 
         // the first shadow ray stays in registers across the append; the others are drawn after it
@@ -1009,8 +1012,8 @@ TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& b
             store_nee_ray(ss, qn, k, g);
         }
         ss.neeTime[qn] = time;
-        ss.pathNee[pos] = qn;
-        *reinterpret_cast<float2*>(ss.rngId[cur] + pos) = make_float2(__uint_as_float(rng.s1), __uint_as_float(rng.s2));
+        ss.pathNee[hidx1(pos)] = qn;
+        *reinterpret_cast<float2*>(ss.rngId[cur] + sidx(pos)) = make_float2(__uint_as_float(rng.s1), __uint_as_float(rng.s2));
     }
 }
 
@@ -1057,15 +1060,15 @@ __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_
             float time = 0.0f;
             if (j < n)
             {
-                const float4 ro = ss.rayO[cur][pos];
-                const float4 rd = ss.rayD[cur][pos];
+                const float4 ro = ss.rayO[cur][sidx(pos)];
+                const float4 rd = ss.rayD[cur][sidx(pos)];
                 sc.walkItem = pos*walkPrims;        // only front rays ever reach a walked primitive
 
                 float t;
                 const int prim = trace<SceneT<LDS, WONLY, 2, MIXED>, LdsStack<kBlock>, COUNT>(sc, st, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), ro.w, t, hitN, ctr);
 
-                ss.hit[pos] = make_float4(t, hitN.x, hitN.y, hitN.z);
-                ss.hitPrim[pos] = prim;
+                ss.hit[hidx(pos)] = make_float4(t, hitN.x, hitN.y, hitN.z);
+                ss.hitPrim[hidx1(pos)] = prim;
                 rays++;
                 has = prim >= 0;
                 hitP = V3(ro.x, ro.y, ro.z) + V3(rd.x, rd.y, rd.z)*t;       // on_hit_begin's h.p (render.cpp:275)
@@ -1113,7 +1116,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
         uint32_t npos = region_pos(rBase, rLen, nFront, lane < n ? lane : 0u);
         if (lane < n)
         {
-            nro = ss.rayO[cur][npos]; nrd = ss.rayD[cur][npos]; nhh = ss.hit[npos]; nprim = ss.hitPrim[npos];
+            nro = ss.rayO[cur][sidx(npos)]; nrd = ss.rayD[cur][sidx(npos)]; nhh = ss.hit[hidx(npos)]; nprim = ss.hitPrim[hidx1(npos)];
         }
         for (uint32_t j0 = 0; j0 < n; j0 += kWave)
         {
@@ -1126,7 +1129,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
                 npos = region_pos(rBase, rLen, nFront, jn < n ? jn : 0u);
                 if (jn < n)
                 {
-                    nro = ss.rayO[cur][npos]; nrd = ss.rayD[cur][npos]; nhh = ss.hit[npos]; nprim = ss.hitPrim[npos];
+                    nro = ss.rayO[cur][sidx(npos)]; nrd = ss.rayD[cur][sidx(npos)]; nhh = ss.hit[hidx(npos)]; nprim = ss.hitPrim[hidx1(npos)];
                 }
             }
             V3 hitP, hitN;
@@ -1233,7 +1236,8 @@ struct ShadeFetch
     {
         if (!valid)
             return;
-        ro = sb.rayO[pos]; rd = sb.rayD[pos];
+        const uint32_t at = sidx(pos);
+        ro = sb.rayO[at]; rd = sb.rayD[at];
         if (fresh)
         {
             th = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
@@ -1241,12 +1245,12 @@ struct ShadeFetch
         }
         else
         {
-            th = sb.thr[pos]; ra = sb.rad[pos];
+            th = sb.thr[at]; ra = sb.rad[at];
         }
-        rr = sb.rngId[pos];
-        hh = hit[pos];
-        prim = hitPrim[pos];
-        qn = hasNee ? pathNee[pos] : 0u;
+        rr = sb.rngId[at];
+        hh = hit[hidx(pos)];
+        prim = hitPrim[hidx1(pos)];
+        qn = hasNee ? pathNee[hidx1(pos)] : 0u;
     }
     TN_D void issue(const SplitState& ss, int buf, uint32_t pos, bool valid, bool hasMedia, bool hasNee, bool fresh)
     {
@@ -1417,7 +1421,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade_sorted(DevScen
         // their positions, or -- region read -- shades what is left, class after class, in as few rounds as the leftovers' sum needs.
         int nextPrim = -1;          // the hit primitives of the next round are requested a round ahead (4 B per path)
         if (lane < n)
-            nextPrim = ss.hitPrim[region_pos(rBase, rLen, nFront, lane)];
+            nextPrim = ss.hitPrim[hidx1(region_pos(rBase, rLen, nFront, lane))];
         uint32_t j0 = 0, e0 = 0;
         for (;;)
         {
@@ -1443,7 +1447,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_SHADE) void k_shade_sorted(DevScen
                 const uint32_t at = region_pos(rBase, rLen, nFront, j < n ? j : 0u);
                 const int prim = nextPrim;
                 if (j + kWave < n)
-                    nextPrim = ss.hitPrim[region_pos(rBase, rLen, nFront, j + kWave)];
+                    nextPrim = ss.hitPrim[hidx1(region_pos(rBase, rLen, nFront, j + kWave))];
                 int cls = -1;
                 if (j < n)
                 {

@@ -103,8 +103,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : TN_WAVES_SWALK) void k_s
         else
         {
             const V3 n = face_forward(cn, -d);              // render.cpp:59
-            ss.hit[pos] = make_float4(minT, n.x, n.y, n.z);
-            ss.hitPrim[pos] = closest;
+            ss.hit[hidx(pos)] = make_float4(minT, n.x, n.y, n.z);
+            ss.hitPrim[hidx1(pos)] = closest;
         }
     };
 
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : TN_WAVES_SWALK) void k_s
                     }
                     else
                     {
-                        ro = ss.rayO[cur][pos]; rd = ss.rayD[cur][pos];
+                        ro = ss.rayO[cur][sidx(pos)]; rd = ss.rayD[cur][sidx(pos)];
                         time = ro.w;
                     }
                     o = V3(ro.x, ro.y, ro.z);

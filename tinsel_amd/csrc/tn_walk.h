@@ -40,6 +40,7 @@
 #pragma once
 
 #include "tn_isect.h"
+#include "tn_layout.h"
 
 namespace tn {
 
@@ -49,7 +50,7 @@ struct WalkJob
 {
     const uint32_t* queue;          // the positions to walk (k_seg_expand: the front entries of every region), *frontCount of them
     const uint32_t* frontCount;
-    const float4* rayO;             // extension rays: origin|time, dir|- by path position (SplitState::rayO / rayD of the bounce)
+    const float4* rayO;             // extension rays: origin|time, dir|- by path position (SplitState::rayO / rayD of the bounce: [sidx(position)])
     const float4* rayD;
     const float4* nee;              // shadow rays: SplitState::neeRay [(k*2 + {0: o|dist, 1: wi|nl})*neeStride + q] by NEE position q
     uint32_t neeStride;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     }
                     else
                     {
-                        ro = job.rayO[slot]; rd = job.rayD[slot];
+                        ro = job.rayO[sidx(slot)]; rd = job.rayD[sidx(slot)];
                         time = ro.w;
                     }
                     const V3 wo(ro.x, ro.y, ro.z), wd(rd.x, rd.y, rd.z);
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob
                     }
                     else
                     {
-                        ro = job.rayO[slot]; rd = job.rayD[slot];
+                        ro = job.rayO[sidx(slot)]; rd = job.rayD[sidx(slot)];
                         time = ro.w;
                     }
                     const V3 wo(ro.x, ro.y, ro.z), wd(rd.x, rd.y, rd.z);

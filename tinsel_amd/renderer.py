@@ -208,8 +208,9 @@ def scene_delta(old: Scene, new: Scene):
     for i in range(P):
         x, y = pa[i], pb[i]
         mx, my = bytes(x.material), bytes(y.material)
-        # (the material's bump-map texture is a host pointer at bytes [88, 96): bump mapping is dead code in the reference and not uploaded)
-        if x.type != y.type or x.light_samples != y.light_samples or mx[:88] != my[:88] or mx[96:] != my[96:]:
+        # (the material's parameters: bytes [0, 84) and [112, 128); between them padding and the bump-map texture -- a host pointer and sizes
+        # the integrator never reads: bump mapping is dead code in the reference)
+        if x.type != y.type or x.light_samples != y.light_samples or mx[:84] != my[:84] or mx[112:] != my[112:]:
             return None
         if x.type == abi.GEOM_SPHERE and x.geo.sphere.radius != y.geo.sphere.radius:
             return None
