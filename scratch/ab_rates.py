@@ -4,7 +4,7 @@
 the spread over PROCESSES is what the split pipeline's streaming kernels were quoted as ranges for.
 
   python scratch/ab_rates.py --lib name=path [--lib name=path ...] [--repeat 5] [--steps 20] workload [workload ...]
-  workloads: cornell, veach4k, glass, cfg3, aphrodite, many_spheres, motionblur, cfg1
+  workloads: cornell, veach4k, glass, cfg3, aphrodite, many_spheres, motionblur, cfg1, table, transmission, meshlight
 """
 import argparse
 import json
@@ -23,6 +23,9 @@ WORK = {
     "aphrodite": ["--scene", "large/ajax_aphrodite", "--width", "1920", "--height", "1080", "--maxdepth", "4"],
     "many_spheres": ["--scene", "many_spheres", "--width", "1024", "--height", "768"],
     "motionblur": ["--scene", "motionblur", "--width", "1920", "--height", "1080"],
+    "table": ["--scene", "large/table", "--width", "1920", "--height", "1080"],
+    "transmission": ["--scene", "large/transmission", "--width", "1920", "--height", "1080"],
+    "meshlight": ["--scene", "large/meshlight", "--width", "1920", "--height", "1080"],
 }
 
 

@@ -119,6 +119,20 @@ extern "C" int HipRendererPresent(Renderer* r, const Options& options, Color* fi
 // that frame (tinsel_hip_rebuild_scene): bit-identical to a renderer created from `next`.  The pass index goes back to 0, where a fresh renderer
 // starts.  Returns 0 when done; 1 when the frames differ in more than transforms (nothing changed: delete + CreateGpuRenderer, as the reference
 // does); -1 on error.
+// two trees node by node.  Not a memcmp: a leaf's rightIndex bits are whatever the builder's heap held (bvh.h:9-20 stores the item in
+// leftIndex and sets `leaf`; nothing ever reads the other 31 bits), and they differ from one load of the same file to the next.
+static bool same_nodes(const BVHNode* a, const BVHNode* b, int n)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        if (memcmp(&a[i].bounds, &b[i].bounds, sizeof(Bounds)) != 0 || a[i].leftIndex != b[i].leftIndex || a[i].leaf != b[i].leaf)
+            return false;
+        if (!a[i].leaf && a[i].rightIndex != b[i].rightIndex)
+            return false;
+    }
+    return true;
+}
+
 static const char* mesh_difference(const MeshGeometry& a, const MeshGeometry& b)
 {
     if (a.numVertices != b.numVertices || a.numIndices != b.numIndices || a.numNodes != b.numNodes)
@@ -128,7 +142,7 @@ static const char* mesh_difference(const MeshGeometry& a, const MeshGeometry& b)
     if (memcmp(a.positions, b.positions, sizeof(Vec3)*a.numVertices) != 0) return "mesh vertex positions";
     if (memcmp(a.normals, b.normals, sizeof(Vec3)*a.numVertices) != 0) return "mesh vertex normals";
     if (memcmp(a.indices, b.indices, sizeof(int)*a.numIndices) != 0) return "mesh indices";
-    if (memcmp(a.nodes, b.nodes, sizeof(BVHNode)*a.numNodes) != 0) return "mesh BVH";
+    if (!same_nodes(a.nodes, b.nodes, a.numNodes)) return "mesh BVH";
     if (memcmp(a.cdf, b.cdf, sizeof(float)*(a.numIndices/3)) != 0) return "mesh area CDF";
     return NULL;
 }

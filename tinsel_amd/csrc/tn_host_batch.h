@@ -396,7 +396,8 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     // ONE walked primitive: its tree as kernel-argument scalars (tinsel_hip_tuning::walk_single = 0: per-lane pointers as for several; tests)
     a.walkSingle = (r->walkPrims.count == 1 && r->tune.walk_single != 0) ? 1 : 0;
 
-    const size_t ctl = kWalkCtlWords*sizeof(uint32_t);
+    // (k_walk_rays keeps one LDS entry per walked primitive behind its control words: tn_walk.h kWalkPrimWords)
+    const size_t ctl = (kWalkCtlWords + (a.walkSingle ? 0 : kWalkMaxPrims*kWalkPrimWords))*sizeof(uint32_t);
     // n stack entries per lane in LDS (tinsel_hip_tuning::walk_lds_stack, default 8; 0: the deepest tree's need, one workgroup per CU), the
     // rest of the deepest tree's need in HBM, and TWO 1024-thread workgroups per CU (8 waves per SIMD at 64 VGPRs) sharing the CU's
     // LDS: the 524k-triangle config's k_walk 19.0 -> 16.6 ms per 32 passes (2042 -> 2199 Msamples/s; 6 entries 17.2, 12 entries 16.7),

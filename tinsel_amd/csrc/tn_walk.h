@@ -497,6 +497,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 // its own, not a mode of k_walk: written as one template, the one-primitive kernel of the 524k-triangle config came out 4-8 % slower with an
 // identical node phase (profiles/r05_g_ab_walk_single_refill.md) -- its source is left exactly as rounds 3-4 tuned it.
 constexpr int kWalkRayRows = 3;         // k_walk's two per-lane LDS rows + the ray
+// The walked primitives' records in LDS (round 6): a refill used to be a chain of FIVE dependent global round trips -- queue -> ray -> Prim64 ->
+// mesh table entry -> (tree pointers, root) -- and took a third of the kernel's cycles on glass (63 k cycles per refill against 5 k per node
+// phase, profiles/r05_z_walk_profile.txt).  The last three are the same few records for every ray: one entry per walked primitive is staged at
+// the kernel's start (the Prim64, then the tree's nodes / triangles pointers and its root ref), and a refill reads its primitive's entry from LDS.
+constexpr int kWalkPrimWords = 24;      // 16 (Prim64) + 2 (nodes) + 2 (tris) + 1 (root) + 3 (padding: entries stay 16-B aligned)
 
 template <int BLOCK, int WAVES>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob job)
@@ -512,7 +517,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob
     float* const s_stop = reinterpret_cast<float*>(s_walk + (job.stackEntries + 1)*BLOCK + threadIdx.x);    // shadow rays: an accepted hit closer than this ends the walk
     uint32_t* const s_ray = s_walk + (job.stackEntries + 2)*BLOCK + threadIdx.x;            // several walked primitives: the lane's ray (slot | k << 27: the host checks the ranges) while primitives are left
     uint32_t* const s_ctl = s_walk + (job.stackEntries + kWalkRayRows)*BLOCK;               // [0] the workgroup's cursor
-    WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_ctl + kWalkCtlWords);
+    uint32_t* const s_prim = s_ctl + kWalkCtlWords;                                          // [walked primitive][kWalkPrimWords]
+    WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_prim + kWalkMaxPrims*kWalkPrimWords);
 
     const int lane = (int)__lane_id();
     const uint32_t Kx = job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
@@ -537,6 +543,22 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob
     *s_item = 0xffffffffu;
     *s_stop = -kFltMax;                 // (never, for extension rays)
 
+    // one entry per walked primitive: what a refill needs of it (see kWalkPrimWords)
+    if (bbeg < end && threadIdx.x < (uint32_t)job.numPrims)
+    {
+        int primIndex = job.prim[0];
+#pragma unroll
+        for (int q = 1; q < kWalkMaxPrims; ++q)
+            if ((uint32_t)q == threadIdx.x) primIndex = job.prim[q];
+        const float4* pp = reinterpret_cast<const float4*>(sc.prims + primIndex);
+        float4* dst = reinterpret_cast<float4*>(s_prim + threadIdx.x*kWalkPrimWords);
+        const float4 r0 = pp[0], r1 = pp[1], r2 = pp[2], r3 = pp[3];
+        dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+        const DevMesh* m = sc.meshes + __float_as_uint(r3.z);
+        const unsigned long long pn = (unsigned long long)(uintptr_t)m->nodes, pt = (unsigned long long)(uintptr_t)m->tris;
+        uint32_t* e = s_prim + threadIdx.x*kWalkPrimWords + 16;
+        e[0] = (uint32_t)pn; e[1] = (uint32_t)(pn >> 32); e[2] = (uint32_t)pt; e[3] = (uint32_t)(pt >> 32); e[4] = m->root;
+    }
     // stage the tops of the walked trees (a workgroup with nothing to do skips it)
     if (bbeg < end)
     {
@@ -695,7 +717,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob
                         // the primitive to walk now: the lowest one left
                         const uint32_t kb = (uint32_t)__builtin_ctz(pend);
                         pend &= pend - 1u;
-                        int index = job.prim[0];
                         uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
                         {
 #pragma unroll
@@ -703,22 +724,23 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob
                             {
                                 if ((uint32_t)q == kb)
                                 {
-                                    index = job.prim[q];
                                     tb = run;
                                     tn = (uint32_t)job.topCount[q];
                                 }
                                 run += (uint32_t)job.topCount[q];
                             }
                         }
-                        // PrimitiveIntersect's mesh branch up to IntersectRayMesh (intersection.h:977-990)
-                        const Prim64 p = load_prim(sc.prims, index);
+                        // PrimitiveIntersect's mesh branch up to IntersectRayMesh (intersection.h:977-990); the primitive's record and its
+                        // tree from the entry staged in LDS
+                        const uint32_t* const entry = s_prim + kb*kWalkPrimWords;
+                        const Prim64 p = load_prim(reinterpret_cast<const Prim64*>(entry), 0);
                         const Xform x = prim_pose(sc, p, time);
                         pose_inv_ray(p, x, wo, wd, o, d, rcp, &wrcp);
                         {
-                            const DevMesh* m = sc.meshes + p.mesh;
-                            mnodes = as_global(m->nodes);
-                            mtris = as_global(m->tris);
-                            ref = m->root;
+                            const uint4 tr = *reinterpret_cast<const uint4*>(entry + 16);
+                            mnodes = (GlobalF4)(uintptr_t)((unsigned long long)tr.x | ((unsigned long long)tr.y << 32));
+                            mtris = (GlobalF4)(uintptr_t)((unsigned long long)tr.z | ((unsigned long long)tr.w << 32));
+                            ref = entry[20];
                         }
                         topBase = tb;
                         topN = tn;

@@ -191,6 +191,23 @@ def _bytes_at(ptr, n):
     return C.string_at(ptr, n) if (ptr and n > 0) else b""
 
 
+_NODE = np.dtype([("bounds", "<f4", 6), ("left", "<u4"), ("right", "<u4")])
+
+
+def _same_nodes(pa, pb, n):
+    """two reference-format trees node by node.  Not a byte compare: a leaf's rightIndex bits are whatever the reference builder's heap held
+    (bvh.h:236-237 sets leftIndex and `leaf` only) and differ from one load of the same file to the next."""
+    if n <= 0:
+        return True
+    a = np.frombuffer(_bytes_at(pa, n*32), _NODE)
+    b = np.frombuffer(_bytes_at(pb, n*32), _NODE)
+    leaf_a, leaf_b = a["right"] >> 31, b["right"] >> 31
+    if not (np.array_equal(a["bounds"].view(np.uint32), b["bounds"].view(np.uint32)) and np.array_equal(a["left"], b["left"]) and np.array_equal(leaf_a, leaf_b)):
+        return False
+    inner = leaf_a == 0
+    return bool(np.array_equal(a["right"][inner], b["right"][inner]))
+
+
 def scene_delta(old: Scene, new: Scene):
     """What turns a renderer created from `old` into one for `new` WITHOUT re-uploading anything: ([(primitive, start, end)], the new scene
     BVH's nodes) when `new` is `old` with other primitive transforms -- the frames of a rigid animation, what the reference's batch mode
@@ -220,10 +237,11 @@ def scene_delta(old: Scene, new: Scene):
             g, h = x.geo.mesh, y.geo.mesh
             if (g.num_vertices, g.num_indices, g.num_nodes, g.area) != (h.num_vertices, h.num_indices, h.num_nodes, h.area):
                 return None
-            for f, n in (("positions", g.num_vertices*12), ("normals", g.num_vertices*12), ("indices", g.num_indices*4), ("nodes", g.num_nodes*32),
-                         ("cdf", (g.num_indices//3)*4)):
+            for f, n in (("positions", g.num_vertices*12), ("normals", g.num_vertices*12), ("indices", g.num_indices*4), ("cdf", (g.num_indices//3)*4)):
                 if _bytes_at(getattr(g, f), n) != _bytes_at(getattr(h, f), n):
                     return None
+            if not _same_nodes(g.nodes, h.nodes, g.num_nodes):
+                return None
         if bytes(x.start_transform) != bytes(y.start_transform) or bytes(x.end_transform) != bytes(y.end_transform):
             moves.append((i, abi.Transform.from_buffer_copy(bytes(y.start_transform)), abi.Transform.from_buffer_copy(bytes(y.end_transform))))
     nodes = (abi.BVHNode*b.num_bvh_nodes).from_buffer_copy(_bytes_at(b.bvh_nodes, b.num_bvh_nodes*C.sizeof(abi.BVHNode)))
