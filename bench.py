@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--no-ubench", action="store_true", help="skip the stream-copy / record-chase yard-sticks (and the counter calibration)")
     ap.add_argument("--group", action="store_true", help="time the library's own multi-GPU path (tinsel_hip_group over --gpus devices, one process) instead")
     ap.add_argument("--no-group-leg", action="store_true", help="N > 1: do not time the tinsel_hip_group path from rank 0 before the ranks meet")
+    ap.add_argument("--tuning", default="", help='A/B: a tinsel_hip_tuning as JSON, e.g. \'{"walk_refill_min": 16}\' (tinsel_amd.abi.Tuning; the default run sets nothing)')
     ap.add_argument("--force-comm", action="store_true", help="N = 1 validation: make the library's RCCL communicator of ONE rank and put its ncclReduce inside the timed region")
     ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)      # the child process the PMC passes profile
     return ap.parse_args()
@@ -189,6 +190,8 @@ def pmc_pass(args, scene, width, height, maxdepth, steps, counters, timeout=150)
                "--maxdepth", str(maxdepth), "--steps", str(steps), "--pipeline", args.pipeline, "--bvh", args.bvh, "--roulette", str(args.roulette)]
         if args.no_ubench:
             cmd.append("--no-ubench")
+        if args.tuning:
+            cmd += ["--tuning", args.tuning]
         env = dict(os.environ, TMPDIR="/tmp")
         p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
         files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
@@ -983,6 +986,9 @@ def write_detail(detail):
 
 def main():
     args = parse()
+    if args.tuning:
+        from tinsel_amd import abi, renderer
+        renderer.DEFAULT_TUNING = abi.Tuning(**json.loads(args.tuning))     # (every renderer this process creates; never set by the default run)
     if args.inner_pmc:
         return inner_pmc(args)
     if args.group:

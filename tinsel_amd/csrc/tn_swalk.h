@@ -12,6 +12,8 @@
 // Extension rays leave the hit where k_shade looks for it (SplitState::hit / hitPrim), shadow rays their 8-B verdict (neeRes).
 #pragma once
 
+#include "tn_split.h"
+
 namespace tn {
 
 #ifndef TN_WAVES_SWALK

@@ -191,21 +191,31 @@ def _bytes_at(ptr, n):
     return C.string_at(ptr, n) if (ptr and n > 0) else b""
 
 
-_NODE = np.dtype([("bounds", "<f4", 6), ("left", "<u4"), ("right", "<u4")])
+_libc = C.CDLL(None)
+_libc.memcmp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+
+
+def _same_bytes(pa, pb, n):
+    """memcmp of two host arrays in place (a frame's mesh arrays are tens of MB: no copies)"""
+    if n <= 0 or pa == pb:
+        return True
+    return bool(pa) and bool(pb) and _libc.memcmp(pa, pb, n) == 0
 
 
 def _same_nodes(pa, pb, n):
-    """two reference-format trees node by node.  Not a byte compare: a leaf's rightIndex bits are whatever the reference builder's heap held
-    (bvh.h:236-237 sets leftIndex and `leaf` only) and differ from one load of the same file to the next."""
-    if n <= 0:
+    """two reference-format trees node by node.  Not just a byte compare: a leaf's rightIndex bits are whatever the reference builder's heap
+    held (bvh.h:236-237 sets leftIndex and `leaf` only) and may differ from one load of the same file to the next."""
+    if n <= 0 or _same_bytes(pa, pb, n*32):
         return True
-    a = np.frombuffer(_bytes_at(pa, n*32), _NODE)
-    b = np.frombuffer(_bytes_at(pb, n*32), _NODE)
-    leaf_a, leaf_b = a["right"] >> 31, b["right"] >> 31
-    if not (np.array_equal(a["bounds"].view(np.uint32), b["bounds"].view(np.uint32)) and np.array_equal(a["left"], b["left"]) and np.array_equal(leaf_a, leaf_b)):
+    a = np.ctypeslib.as_array((C.c_uint32*(n*8)).from_address(pa)).reshape(n, 8)
+    b = np.ctypeslib.as_array((C.c_uint32*(n*8)).from_address(pb)).reshape(n, 8)
+    if not np.array_equal(a[:, :7], b[:, :7]):                      # bounds (6 floats as bits) + leftIndex
+        return False
+    leaf_a, leaf_b = a[:, 7] >> 31, b[:, 7] >> 31
+    if not np.array_equal(leaf_a, leaf_b):
         return False
     inner = leaf_a == 0
-    return bool(np.array_equal(a["right"][inner], b["right"][inner]))
+    return bool(np.array_equal(a[inner, 7], b[inner, 7]))
 
 
 def scene_delta(old: Scene, new: Scene):
@@ -217,7 +227,7 @@ def scene_delta(old: Scene, new: Scene):
         return None
     if (a.probe_valid, a.probe_width, a.probe_height) != (b.probe_valid, b.probe_width, b.probe_height):
         return None
-    if a.probe_valid and _bytes_at(a.probe_data, a.probe_width*a.probe_height*16) != _bytes_at(b.probe_data, b.probe_width*b.probe_height*16):
+    if a.probe_valid and not _same_bytes(a.probe_data, b.probe_data, a.probe_width*a.probe_height*16):
         return None
     P = a.num_primitives
     pa, pb = (abi.Primitive*P).from_address(a.primitives), (abi.Primitive*P).from_address(b.primitives)
@@ -238,7 +248,7 @@ def scene_delta(old: Scene, new: Scene):
             if (g.num_vertices, g.num_indices, g.num_nodes, g.area) != (h.num_vertices, h.num_indices, h.num_nodes, h.area):
                 return None
             for f, n in (("positions", g.num_vertices*12), ("normals", g.num_vertices*12), ("indices", g.num_indices*4), ("cdf", (g.num_indices//3)*4)):
-                if _bytes_at(getattr(g, f), n) != _bytes_at(getattr(h, f), n):
+                if not _same_bytes(getattr(g, f), getattr(h, f), n):
                     return None
             if not _same_nodes(g.nodes, h.nodes, g.num_nodes):
                 return None
