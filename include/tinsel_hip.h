@@ -210,6 +210,8 @@ typedef struct tinsel_hip_tuning {
     int32_t walk_lds_stack;     /* -1 default (8) | stack entries per lane kept in LDS (0: all of them, one workgroup per CU) */
     int32_t walk_refill_min;    /* 0 default (24) | idle lanes of a wave that trigger k_walk's refill */
     int32_t walk_leaf_min;      /* 0 default (8) | lanes waiting at a leaf that trigger k_walk's triangle phase */
+    int32_t walk_grid_mult;     /* 0 default (1) | k_walk's grid in resident sets of workgroups: each workgroup a contiguous 1/grid of the work list */
+    int32_t _reserved;
 } tinsel_hip_tuning;
 enum { TINSEL_ACCUMULATE_AUTO = 0, TINSEL_ACCUMULATE_TILED = 1, TINSEL_ACCUMULATE_WIDE = 2, TINSEL_ACCUMULATE_PIPED = 3 };
 
@@ -581,7 +583,7 @@ static_assert(sizeof(tinsel_filter) == 16, "Filter");
 static_assert(sizeof(tinsel_options) == 48, "Options");
 static_assert(offsetof(tinsel_options, max_depth) == 40, "Options.maxDepth");
 static_assert(sizeof(tinsel_pack_header) == 256, "pack header");
-static_assert(sizeof(tinsel_hip_tuning) == 112, "tuning");
+static_assert(sizeof(tinsel_hip_tuning) == 120, "tuning");
 #endif
 
 #endif /* TINSEL_HIP_H */

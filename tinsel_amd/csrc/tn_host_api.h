@@ -904,7 +904,7 @@ int tinsel_hip_set_tuning(tinsel_hip* r, const tinsel_hip_tuning* tuning)
     lookahead_cancel(r);
     tinsel_hip_tuning t = tuning_from_caller(tuning);
     if (t.grid_mult < 0 || t.grid_mult > 256 || (t.walk_block != 0 && t.walk_block != 256 && t.walk_block != 1024) ||
-        t.accumulate < TINSEL_ACCUMULATE_AUTO || t.accumulate > TINSEL_ACCUMULATE_PIPED || t.walk_refill_min > 64 || t.walk_leaf_min > 64 ||
+        t.accumulate < TINSEL_ACCUMULATE_AUTO || t.accumulate > TINSEL_ACCUMULATE_PIPED || t.walk_refill_min > 64 || t.walk_leaf_min > 64 || t.walk_grid_mult < 0 || t.walk_grid_mult > 64 ||
         (t.tail_split > 0 && (!(t.tail_share >= 0.0f) || t.tail_divide < 1)) || (t.batch_paths != 0 && t.batch_paths < 1024))
         return fail("set_tuning: a field is out of range");
     HIP_TRY(hipSetDevice(r->device));

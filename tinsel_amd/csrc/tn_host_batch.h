@@ -349,7 +349,7 @@ uint32_t seg_prefix_max_regions(tinsel_hip* r)
 int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* regionCounts, bool shadowRays)
 {
     // (measured and settled, profiles/EXPERIMENTS.md: one resident set of workgroups; a refill once 24 lanes idle; a triangle phase once 8 wait)
-    const int gridMult = 1, refillMin = r->tune.walk_refill_min > 0 ? r->tune.walk_refill_min : 24, leafMin = r->tune.walk_leaf_min > 0 ? r->tune.walk_leaf_min : 8;
+    const int gridMult = r->tune.walk_grid_mult > 0 ? r->tune.walk_grid_mult : 1, refillMin = r->tune.walk_refill_min > 0 ? r->tune.walk_refill_min : 24, leafMin = r->tune.walk_leaf_min > 0 ? r->tune.walk_leaf_min : 8;
     const int forceBlock = r->tune.walk_block;
     prepare_kernels_once(r);
     // the work list: the front entries of every region (paths / shadow-ray bundles whose ray enters a walked mesh's box)
