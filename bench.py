@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--maxdepth", type=int, default=0, help="0 = the scene's own / BASELINE value")
-    ap.add_argument("--pipeline", choices=["auto", "wavefront", "mega", "split"], default="auto")
+    ap.add_argument("--pipeline", choices=["auto", "wavefront", "mega", "split", "paired"], default="auto")
     ap.add_argument("--bvh", choices=["reference", "lbvh", "ploc"], default="reference",
                     help="mesh BVHs: the reference's host-built trees (parity path) or rebuilt on the device")
     ap.add_argument("--roulette", type=int, default=0, help="opt-in Russian roulette from this bounce on (0 = the reference's behaviour)")
@@ -230,7 +230,7 @@ def inner_pmc(args):
         r.set_mesh_bvh(abi.BVH_LBVH if args.bvh == "lbvh" else abi.BVH_PLOC)
     if args.roulette > 0:
         r.set_russian_roulette(args.roulette)
-    r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
+    r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT, "paired": abi.PIPELINE_WAVEFRONT_PAIRED}[args.pipeline])
     r.init(opt.width, opt.height)
     r.reserve(args.steps, opt.max_depth)
     r.render(cam, opt, passes=args.steps, readback=False)
@@ -310,7 +310,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     bvh_build_ms = r.set_mesh_bvh(abi.BVH_LBVH if args.bvh == "lbvh" else abi.BVH_PLOC) if args.bvh != "reference" else None
     if args.roulette > 0:
         r.set_russian_roulette(args.roulette)
-    r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
+    r.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT, "paired": abi.PIPELINE_WAVEFRONT_PAIRED}[args.pipeline])
     if args.arith == "fast":
         r.set_arithmetic(abi.ARITH_FAST)
     if world > 1:
@@ -356,6 +356,9 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
     torch.cuda.synchronize()
     c = r.stats()
     r.set_detail_counters(False)
+    # (the counted pass may run another pipeline -- the paired one counts nothing -- and so give the path buffers back: reserve again, outside
+    # every timed region)
+    r.reserve(max(args.steps, args.warmup, 1)*world, opt.max_depth)
     rays_c = max(1, c["rays"])
     I_bar, T_bar, P_bar = c["internal_visits"]/rays_c, c["tri_tests"]/rays_c, c["prim_tests"]/rays_c
     B_ray = 48.0 + 64.0*I_bar + 48.0*T_bar + 84.0*P_bar
@@ -523,7 +526,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
             optL = opt.copy()
             optL.width, optL.height = opt.width//f, opt.height//f
             rf = tinsel_amd.create_gpu_renderer(scene, local)
-            rf.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT}[args.pipeline])
+            rf.set_pipeline({"auto": abi.PIPELINE_AUTO, "wavefront": abi.PIPELINE_WAVEFRONT, "mega": abi.PIPELINE_MEGAKERNEL, "split": abi.PIPELINE_WAVEFRONT_SPLIT, "paired": abi.PIPELINE_WAVEFRONT_PAIRED}[args.pipeline])
             rf.init(optL.width, optL.height)
             rf.reserve(max(spp, args.steps), opt.max_depth)
             exact_img = rf.render(cam, optL, passes=spp)
@@ -730,7 +733,7 @@ def run_config(args, scene_name, width, height, maxdepth, rank, world, local, di
         "timed_blocks": len(blocks), "timed_seconds": total, "block_ms_min_median_max": [min(blocks)*1e3, elapsed*1e3, max(blocks)*1e3],
         "config": {"workload": "%s.tin %dx%d maxDepth=%d, %d pass(es) per step, pipeline=%s" % (
             scene_name, opt.width, opt.height, opt.max_depth, passes_per_step,
-            args.pipeline if args.pipeline != "auto" else "auto->" + ("wavefront(fused)" if "k_bounce" in ktimes else "wavefront(split%s)" % ("+k_walk" if "k_walk" in ktimes else ""))),
+            args.pipeline if args.pipeline != "auto" else "auto->" + ("wavefront(fused)" if "k_bounce" in ktimes else "wavefront(%s%s)" % ("paired" if "k_step" in ktimes else "split", "+k_walk" if "k_walk" in ktimes else ""))),
             "scene_pack": os.path.relpath(pack, ROOT), "parallelism": "pixel-tile shard x%d + RCCL reduce" % world if world > 1 else "1 GPU",
             "filter": "gaussian w=%.2f" % fw, "rays_per_sample": tot_rays/max(1.0, tot_samples),
             "mesh_bvh": args.bvh, "mesh_bvh_build_ms": bvh_build_ms, "russian_roulette_from_bounce": args.roulette},

@@ -165,6 +165,9 @@ typedef struct tinsel_hip tinsel_hip;       /* opaque */
  * path) and WAVEFRONT_SPLIT (extend / shade / shadow kernels per bounce) are A/B arms with
  * identical per-path arithmetic. */
 enum { TINSEL_PIPELINE_WAVEFRONT = 0, TINSEL_PIPELINE_MEGAKERNEL = 1, TINSEL_PIPELINE_WAVEFRONT_SPLIT = 2,
+       /* PAIRED: the split pipeline re-cut for scenes with meshes in HBM -- a bounce's shadow rays and the next bounce's extension rays are
+        * walked in ONE k_walk launch, ONE streaming kernel per bounce does the rest (tn_paired.h); same arithmetic, same bits */
+       TINSEL_PIPELINE_WAVEFRONT_PAIRED = 4,
        /* default: WAVEFRONT (fused bounce kernel) when the whole scene is LDS-resident and a bounce casts at
         * most two NEE rays, else WAVEFRONT_SPLIT, whose trace-only kernels run at twice the occupancy
         * (measured crossover: DESIGN.md section 5) */

@@ -4,7 +4,8 @@
 the spread over PROCESSES is what the split pipeline's streaming kernels were quoted as ranges for.
 
   python scratch/ab_rates.py --lib name=path [--lib name=path ...] [--repeat 5] [--steps 20] workload [workload ...]
-  (--lib name=tuning:{"walk_refill_min": 16}  runs the in-tree library under that tinsel_hip_tuning instead of another build)
+  (--lib name=tuning:{"walk_refill_min": 16}  runs the in-tree library under that tinsel_hip_tuning instead of another build;
+   --lib 'name=args:--pipeline paired'        the in-tree library with extra bench.py arguments)
   workloads: cornell, veach4k, glass, cfg3, aphrodite, many_spheres, motionblur, cfg1, table, transmission, meshlight
 """
 import argparse
@@ -32,12 +33,16 @@ WORK = {
 
 def one(lib, work, steps):
     """lib: a library path, or `tuning:{json}` for the in-tree library under a tinsel_hip_tuning"""
-    tuning = None
+    tuning, extra = None, []
     if lib.startswith("tuning:"):
         tuning, lib = lib[len("tuning:"):], ""
+    elif lib.startswith("args:"):
+        extra, lib = lib[len("args:"):].split(), ""
     env = dict(os.environ, TINSEL_HIP_LIB=lib) if lib else dict(os.environ)
+    if lib.endswith("_step5.so"):
+        extra = ["--pipeline", "paired"]
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "5", "--no-pmc", "--no-fast", "--no-api", "--no-ubench",
-           "--no-cpu-baseline", "--no-second-config", "--no-more-configs"] + WORK[work] + (["--tuning", tuning] if tuning else [])
+           "--no-cpu-baseline", "--no-second-config", "--no-more-configs"] + WORK[work] + (["--tuning", tuning] if tuning else []) + extra
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     if p.returncode != 0:
         return None, {}

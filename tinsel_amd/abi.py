@@ -166,7 +166,7 @@ PROBE_CDF, PROBE_ALIAS = 0, 1
 LOOKAHEAD_OFF, LOOKAHEAD_ON, LOOKAHEAD_PIN_OUTPUT = 0, 1, 2
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 GEOM_SPHERE, GEOM_PLANE, GEOM_MESH = 0, 1, 2
-PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT_SPLIT, PIPELINE_AUTO = 0, 1, 2, 3
+PIPELINE_WAVEFRONT, PIPELINE_MEGAKERNEL, PIPELINE_WAVEFRONT_SPLIT, PIPELINE_AUTO, PIPELINE_WAVEFRONT_PAIRED = 0, 1, 2, 3, 4
 
 assert C.sizeof(Transform) == 32 and C.sizeof(BVHNode) == 32 and C.sizeof(Camera) == 40
 assert C.sizeof(Material) == 128 and C.sizeof(MeshGeometry) == 64 and C.sizeof(Primitive) == 272

@@ -735,7 +735,7 @@ int tinsel_hip_get_arithmetic(tinsel_hip* r) { return r ? r->arith : TINSEL_ARIT
 int tinsel_hip_set_pipeline(tinsel_hip* r, int pipeline)
 {
     lookahead_cancel(r);
-    if (!r || pipeline < TINSEL_PIPELINE_WAVEFRONT || pipeline > TINSEL_PIPELINE_AUTO)
+    if (!r || pipeline < TINSEL_PIPELINE_WAVEFRONT || pipeline > TINSEL_PIPELINE_WAVEFRONT_PAIRED)
         return fail("set_pipeline: bad arguments");
     r->pipeline = pipeline;
     return 0;

@@ -39,8 +39,39 @@ int batch_alloc(tinsel_hip* r, T** out, size_t count)
 constexpr int kGridMultDefault = 32;
 int grid_mult(const tinsel_hip* r) { return r->tune.grid_mult > 0 ? r->tune.grid_mult : kGridMultDefault; }
 
+// the paired pipeline (tn_paired.h) takes flat-scan scenes without detail counting; anything else asked of it runs the split pipeline
+bool paired_can(const tinsel_hip* r) { return r->scene.flatScan != 0 && !r->countDetail; }
+
+// AUTO's choice between the split pipeline and its paired re-cut, by what was measured (profiles/r06_h_ab_paired.md, Msamples/s split -> paired):
+// k_step runs a path's shadow resolve, its closest hit and its shading in ONE kernel at four waves per SIMD, so it wins where all three are lean --
+// every mesh walked by k_walk (the scan kernels' WONLY variants: no inline mesh walk, no deep stack), nothing moving (no pose interpolated per ray),
+// lights that are sampled without a search (spheres, a probe, small meshes): the 524k-triangle config 2232 -> 2536, the Aphrodite scan 2865 -> 3290,
+// transmission.tin 1211 -> 1338 -- and is a wash or loses elsewhere: glass 1613 -> 1608 and table.tin 1323 -> 1307 (a mesh walked inline),
+// motionblur 1488 -> 1410 (a moving mesh), meshlight.tin 1471 -> 1380 (a 36,752-triangle light: a CDF search per sample).
+bool paired_preferred(const tinsel_hip* r)
+{
+    if (!paired_can(r) || r->walkPrims.count == 0 || !r->walkEnabled)
+        return false;
+    int meshPrims = 0;
+    for (int m : r->primMesh)
+        meshPrims += m >= 0 ? 1 : 0;
+    if (meshPrims != r->walkPrims.count)
+        return false;
+    for (const Prim64& p : r->primsHost)
+        if (p.flags & kPrimMoving)
+            return false;
+    for (int32_t i : r->lightPrims)
+        if (r->primMesh[(size_t)i] >= 0 && r->meshesNow[(size_t)r->primMesh[(size_t)i]].numTris > 64)
+            return false;
+    return true;
+}
+
 int resolve_pipeline(const tinsel_hip* r)
 {
+    if (r->pipeline == TINSEL_PIPELINE_WAVEFRONT_PAIRED)
+        return paired_can(r) ? TINSEL_PIPELINE_WAVEFRONT_PAIRED : TINSEL_PIPELINE_WAVEFRONT_SPLIT;
+    if (r->pipeline == TINSEL_PIPELINE_AUTO && !r->scene.allInArena && paired_preferred(r))
+        return TINSEL_PIPELINE_WAVEFRONT_PAIRED;
     if (r->pipeline != TINSEL_PIPELINE_AUTO)
         return r->pipeline;
     // A scene whose arena is staged whole into LDS runs the fused kernel, whatever its shadow rays per bounce (fused ->
@@ -52,9 +83,9 @@ int resolve_pipeline(const tinsel_hip* r)
 
 // The wavefront pipelines' state (SplitState, tn_kernels.h): by POSITION, two buffers of everything a bounce rewrites; for the
 // split pipeline also what its kernels hand to each other (hit, shadow rays and their results, k_walk's records and list)
-int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
+int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split, bool paired = false)
 {
-    const size_t K = split ? (size_t)r->neePerPath : 0;
+    const size_t K = (split || paired) ? (size_t)r->neePerPath : 0;
     // (half as many again as the widest grid: the short regions at the end of a batch, split_tail_regions)
     const size_t maxRegions = (size_t)r->numCUs*(size_t)grid_mult(r)*(kBlock/kWave)*3/2;
     const size_t cap = (slots + maxRegions*kWave + kWave - 1)/kWave*kWave;       // a region is a whole number of waves long; whole 64-position blocks
@@ -78,7 +109,7 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
             return -1;
 #endif
     }
-    if (batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 1)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 1)) ||
+    if (batch_alloc(r, &ss.segFront, maxRegions*((size_t)maxDepth + 2)) || batch_alloc(r, &ss.segBack, maxRegions*((size_t)maxDepth + 2)) ||
         batch_alloc(r, &r->regionOrder, maxRegions/(kBlock/kWave)) || batch_alloc(r, &r->regionOrderNee, maxRegions/(kBlock/kWave)))
         return -1;
     ss.radOut = r->ps.rad;
@@ -88,6 +119,19 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split)
     r->walkRec = nullptr;
     r->walkList = nullptr;
     r->segPrefix = nullptr;
+    if (paired)
+    {
+        // the K pending light samples of every path, by position, double-buffered like the state (tn_paired.h); k_walk's records: K + 1 rays per position
+        ss.neePerPath = (int32_t)K;
+        for (int b = 0; b < 2; ++b)
+            if (batch_alloc(r, &ss.pairThr[b], K ? cap : 1) || batch_alloc(r, &ss.pairRay[b], cap*K*2) || batch_alloc(r, &ss.pairPend[b], cap*K*2))
+                return -1;
+        if (r->walkPrims.count > 0 && r->walkEnabled && (double)cap*(double)(K + 1)*r->walkPrims.count < 2147483648.0)
+            if (batch_alloc(r, &r->walkRec, cap*(K + 1)*(size_t)r->walkPrims.count*2) || batch_alloc(r, &r->walkList, cap) ||
+                batch_alloc(r, &r->segPrefix, maxRegions + 1))
+                return -1;
+        return 0;
+    }
     if (!split)
         return 0;
 
@@ -158,7 +202,7 @@ int ensure_batch(tinsel_hip* r, size_t slots, int maxDepth, size_t stateSlots = 
     if (pipeline != TINSEL_PIPELINE_MEGAKERNEL)
         for (int lane = lanes; lane-- > 0; )
         {
-            if (alloc_dense(r, stateSlots, maxDepth, pipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT))
+            if (alloc_dense(r, stateSlots, maxDepth, pipeline == TINSEL_PIPELINE_WAVEFRONT_SPLIT, pipeline == TINSEL_PIPELINE_WAVEFRONT_PAIRED))
                 return -1;
             if (lane > 0)
                 lane_swap(r);           // the set just made becomes laneB
@@ -346,7 +390,8 @@ uint32_t seg_prefix_max_regions(tinsel_hip* r)
 // One 1024-thread workgroup per CU whose LDS holds the traversal stacks and, in what is left of the 160 KB, the top of
 // the walked trees; trees too deep for that (a device-built LBVH of 524k triangles: 48 entries per lane) run 256-thread
 // workgroups without a staged top.
-int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* regionCounts, bool shadowRays)
+// (mixed: the paired pipeline's walk -- K shadow rays + the extension ray of every queued position, tn_paired.h)
+int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* regionCounts, bool shadowRays, bool mixed = false)
 {
     // (measured and settled, profiles/EXPERIMENTS.md: one resident set of workgroups; a refill once 24 lanes idle; a triangle phase once 8 wait)
     const int gridMult = r->tune.walk_grid_mult > 0 ? r->tune.walk_grid_mult : 1, refillMin = r->tune.walk_refill_min > 0 ? r->tune.walk_refill_min : 24, leafMin = r->tune.walk_leaf_min > 0 ? r->tune.walk_leaf_min : 8;
@@ -380,6 +425,14 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     job.neeTime = ss.neeTime;
     job.rec = r->walkRec;
     job.neePerPath = shadowRays ? r->neePerPath : 0;
+    job.mixed = 0;
+    if (r->lastPipeline == TINSEL_PIPELINE_WAVEFRONT_PAIRED)
+    {
+        job.nee = ss.pairRay[a.bounce & 1];
+        job.mixed = mixed ? 1 : 0;
+        if (shadowRays && !mixed)
+            job.mixed = 2;          // shadow rays only, their time in the state (tn_walk.h reads rayO[slot].w whenever `mixed` is set)
+    }
     job.numPrims = r->walkPrims.count;
     int entries = 1;
     for (int k = 0; k < kWalkMaxPrims; ++k)
@@ -429,7 +482,7 @@ int launch_walk(tinsel_hip* r, hipStream_t st, LaunchArgs a, const uint32_t* reg
     // (k_walk_rays, whatever the number of walked primitives: ADVICE r05)
     if (!a.walkSingle && (ss.capacity >= (1u << 27) || r->neePerPath >= 32))
         return fail("k_walk_rays: batch too large (>= 2^27 positions) or too many shadow rays per path (>= 32): lower tinsel_hip_tuning::batch_paths");
-    const size_t items = r->lastBatchSlots*(size_t)(shadowRays && r->neePerPath > 1 ? r->neePerPath : 1);
+    const size_t items = r->lastBatchSlots*(size_t)((shadowRays && r->neePerPath > 1 ? r->neePerPath : 1) + (mixed ? 1 : 0));
     const int perCU = big ? gridMult*(twoPerCU ? 2 : 1) : gridMult*4;
     a.grid = (int)std::max<size_t>(1, std::min<size_t>((items + block - 1)/block, (size_t)r->numCUs*(size_t)perCU));
     a.walkBig = big ? (twoPerCU ? 2 : 1) : 0;
@@ -896,6 +949,48 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         a.order = nullptr;
         ScopedTimer t(r, KN_BOUNCE, st);
         launch_path(r, PK_BOUNCE, a, st);
+    }
+    else if (pipeline == TINSEL_PIPELINE_WAVEFRONT_PAIRED)
+    {
+        // ONE k_walk and ONE streaming kernel per bounce (tn_paired.h): walk { shadow rays of bounce b - 1, extension rays of bounce b }, then k_step(b)
+        const bool walk = walk_records(r) != nullptr;
+        int meshPrims = 0;
+        for (int m : r->primMesh)
+            meshPrims += m >= 0 ? 1 : 0;
+        const bool walkedOnly = walk && meshPrims == r->walkPrims.count && !r->scene.allInArena;
+        const int stackScan = walkedOnly ? std::max(1, pick_stack(r->sceneStackNeed)) : r->stackNeed;
+        const uint32_t ldsTrace = walkedOnly ? (uint32_t)(((size_t)stackScan*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes) : a.ldsBytes;
+        a.walkedOnly = walkedOnly ? 1 : 0;
+        if (r->walkList != nullptr)
+            gridPersist = std::max(1, std::min(gridPersist, (int)(seg_prefix_max_regions(r)/(kBlock/kWave))));
+        if (cut_regions(r, a, slots, &gridPersist, (size_t)0))
+            return -1;
+        const size_t W = a.ss.numRegions;
+        {
+            ScopedTimer t(r, KN_GENERATE, st);
+            a.grid = gridPersist;
+            launch_path(r, PK_GENERATE, a, st);
+        }
+        const int K = r->neePerPath;
+        // (the step after the last bounce only resolves the last bounce's light samples: nothing to do without lights)
+        const int steps = fp.maxDepth + (K > 0 ? 1 : 0);
+        for (int bounce = 0; bounce < steps; ++bounce)
+        {
+            a.bounce = bounce;
+            a.order = nullptr;
+            if (walk)
+            {
+                a.grid = gridPersist;
+                const bool first = bounce == 0, last = bounce >= fp.maxDepth;
+                if (launch_walk(r, st, a, r->ss.segFront + (size_t)bounce*W, /*shadowRays*/ !first && K > 0, /*mixed*/ !first && !last && K > 0))
+                    return -1;
+            }
+            ScopedTimer t(r, KN_STEP, st);
+            a.grid = gridPersist;
+            a.ldsBytes = ldsTrace;
+            a.stackEntries = stackScan;
+            launch_path(r, PK_STEP, a, st);
+        }
     }
     else
     {

@@ -239,6 +239,7 @@ tinsel_hip* tinsel_hip_create_tuned(const tinsel_scene_desc* desc, int device_in
     }
 
     r->primMesh.assign((size_t)P, -1);
+    r->lightPrims = lights;
     for (int i = 0; i < P && ok; ++i)
     {
         set_prim_derived(prims[(size_t)i]);

@@ -50,6 +50,7 @@ struct tinsel_hip
     std::vector<int> meshNumVertices;
     std::vector<std::vector<int32_t>> meshIndices;
     std::vector<int> primMesh;
+    std::vector<int32_t> lightPrims;    // primitives with lightSamples > 0
     std::vector<float> primEndScale;
     // ... and what moving a PRIMITIVE needs (tinsel_hip_set_primitive_transform / tinsel_hip_rebuild_scene): the Prim64 records as
     // uploaded, where they and the Moving64 slots (one per primitive) sit in the arena, every mesh's root box in mesh space and its

@@ -202,28 +202,54 @@ TN_D bool nee_light_reached(const NeeGeo& g, int hitPrim, float t)
     return hitPrim >= 0 && fabsf(t - g.dist) <= kTolerance && !(absf(g.nl) < 1.e-6f);
 }
 
-// render.cpp:196-219 for a sample that reached its light: MIS weight, BSDFPdf / BSDFEval toward wi, the contribution
-TN_D V3 nee_contrib_light(const DevScene& sc, const Mat& surf, const HitCtx& h, V3 wi, float nl, int light, int hitPrim, float t)
+// render.cpp:196-219 for a sample that reached its light, in two halves.  The BSDF terms of the sample (render.cpp:198-199) are pure
+// functions of the hit and of `wi` -- they do not depend on the shadow ray's fate -- and the rest (light pdf, MIS weight, the product) is a
+// handful of operations on them, on the shadow hit's t and on the emission of the primitive it hit.  nee_contrib_light below evaluates both
+// halves after the trace (only samples that arrive pay for the BSDF: the fused and the split pipelines); the paired pipeline (tn_paired.h)
+// evaluates the first half where the sample is drawn and carries its five floats across the trace.  Same operations on the same operands in
+// the same order either way: the same bits.
+struct NeeTerms
+{
+    V3 f;               // BSDFEval toward wi (0 when bsdfPdf <= 0: never used then)
+    float bsdfPdf;      // BSDFPdf toward wi
+    float absDot;       // |dot(wi, n)|
+};
+
+TN_D NeeTerms nee_bsdf_terms(const Mat& surf, const HitCtx& h, V3 wi)
+{
+    NeeTerms e;
+    e.f = V3(0.0f);
+    e.absDot = 0.0f;
+    e.bsdfPdf = bsdf_pdf(surf, h.etaI, h.etaO, h.n, h.wo, wi);
+    if (e.bsdfPdf > 0.0f)
+    {
+        e.f = bsdf_eval(surf, h.etaI, h.etaO, h.n, h.wo, wi);
+        e.absDot = absf(dot(wi, h.n));
+    }
+    return e;
+}
+
+TN_D V3 nee_combine_light(const DevScene& sc, const NeeTerms& e, float nl, int light, int hitPrim, float t)
 {
     V3 L(0.0f);
     const Mat128* lm = sc.mats + light;
     float tSq = t*t;
     float lightPdf = (lm->rcpArea*tSq)/nl;          // ((1.0f/lightArea)*t*t)/nl, the reciprocal divided on the host (Mat128)
-
-    const float bsdfPdf = bsdf_pdf(surf, h.etaI, h.etaO, h.n, h.wo, wi);
-    if (bsdfPdf > 0.0f)
+    if (e.bsdfPdf > 0.0f)
     {
         float cbsdf = lm->cbsdf;                    // kBsdfSamples/N, float(lightSamples)/N: the host's (Mat128)
         float clight = lm->clight;
-        float weight = clight*lightPdf/(cbsdf*bsdfPdf + clight*lightPdf);
-
-        const V3 f = bsdf_eval(surf, h.etaI, h.etaO, h.n, h.wo, wi);
-        const float absDot = absf(dot(wi, h.n));
+        float weight = clight*lightPdf/(cbsdf*e.bsdfPdf + clight*lightPdf);
         const Mat128* hm = sc.mats + hitPrim;
         V3 em(hm->emission[0], hm->emission[1], hm->emission[2]);
-        L = weight*f*em*(absDot/maxT(1.e-3f, lightPdf));
+        L = weight*e.f*em*(e.absDot/maxT(1.e-3f, lightPdf));
     }
     return L;
+}
+
+TN_D V3 nee_contrib_light(const DevScene& sc, const Mat& surf, const HitCtx& h, V3 wi, float nl, int light, int hitPrim, float t)
+{
+    return nee_combine_light(sc, nee_bsdf_terms(surf, h, wi), nl, light, hitPrim, t);
 }
 
 // render.cpp:107-116: the probe sample and its shadow ray

@@ -5,6 +5,7 @@
 //   tn_fused.h        FUSED wavefront pipeline (scene staged whole into LDS): k_bounce, one launch over all bounces of a batch
 //   tn_split.h        SPLIT wavefront pipeline (meshes / a scene BVH in HBM): k_generate, k_extend, k_lights, k_shadow, k_shade(_sorted),
 //                     k_region_order, k_seg_prefix / k_seg_expand
+//   tn_paired.h       PAIRED wavefront pipeline (meshes in HBM): ONE k_walk and ONE streaming kernel (k_step) per bounce
 //   tn_walk.h         k_walk / k_walk_rays: the mesh walk of meshes in HBM with ray replacement
 //   tn_swalk.h        k_swalk: the scene-level walk with ray replacement (scenes beyond the flat scan)
 //   tn_accumulate.h   AddSample as an order-preserving gather: k_accumulate, k_accumulate_tiled, k_accumulate_piped
@@ -22,6 +23,7 @@
 #include "tn_fused.h"
 #include "tn_split.h"
 #include "tn_swalk.h"
+#include "tn_paired.h"
 #include "tn_accumulate.h"
 
 namespace tn {

@@ -17,7 +17,7 @@ namespace tn {
 
 enum PathKernel : int
 {
-    PK_GENERATE = 0, PK_EXTEND, PK_SHADE, PK_SHADOW, PK_BOUNCE, PK_MEGA, PK_WALK, PK_LIGHTS, PK_SWALK_EXTEND, PK_SWALK_SHADOW,
+    PK_GENERATE = 0, PK_EXTEND, PK_SHADE, PK_SHADOW, PK_BOUNCE, PK_MEGA, PK_WALK, PK_LIGHTS, PK_SWALK_EXTEND, PK_SWALK_SHADOW, PK_STEP,
 };
 
 struct LaunchArgs
@@ -126,6 +126,17 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
                 TN_LAUNCH_BOUNCE(false);
         }
 #undef TN_LAUNCH_BOUNCE
+        break;
+    case PK_STEP:
+        // (LDS, WONLY, MIXED) as k_extend's variants: every mesh walked + arena staged / every mesh walked, generic pointers / arena staged, some
+        // meshes inline / whole scene in LDS / generic pointers
+#define TN_LAUNCH_STEP(L, W, M) hipLaunchKernelGGL((k_step<L, W, M>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order)
+        if (a.walkedOnly && mixed) TN_LAUNCH_STEP(true, true, true);
+        else if (a.walkedOnly && !lds) TN_LAUNCH_STEP(false, true, false);
+        else if (mixed) TN_LAUNCH_STEP(true, false, true);
+        else if (lds) TN_LAUNCH_STEP(true, false, false);
+        else TN_LAUNCH_STEP(false, false, false);
+#undef TN_LAUNCH_STEP
         break;
     case PK_SWALK_EXTEND:
     case PK_SWALK_SHADOW:

@@ -57,6 +57,8 @@ struct WalkJob
     const float* neeTime;           // shadow rays: SplitState::neeTime [q]
     float4* rec;                    // out: [((position*K + k)*numPrims + walked primitive)][2] = {t,u,v,w} {n.xyz, tri};  t == FLT_MAX: no hit
     int neePerPath;                 // 0: extension rays; K > 0: the K shadow rays of every queued slot
+    int mixed;                      // paired pipeline (tn_paired.h).  1: K + 1 rays per queued slot -- its K shadow rays (`nee`), then its extension ray (rayO / rayD;
+                                    // an all-zero direction: the path has none).  2: its K shadow rays only.  Either way a shadow ray's time is rayO[slot].w
     int numPrims;                   // walked primitives (1..7)
     int prim[kWalkMaxPrims];
     int topCount[kWalkMaxPrims];    // Node64 records of each walked primitive's tree staged into LDS (a prefix: breadth-first order)
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
     WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_ctl + kWalkCtlWords);
 
     const int lane = (int)__lane_id();
-    const uint32_t Kx = job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
+    const uint32_t Kx = job.mixed == 1 ? (uint32_t)job.neePerPath + 1u : job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
     const uint32_t Kb = (uint32_t)job.numPrims;
     const uint32_t per = Kx*Kb;                                 // work items per queued slot
     const uint32_t total = (*job.frontCount)*per;
@@ -275,19 +277,22 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
 
                     float4 ro, rd;
                     float time;
-                    if (job.neePerPath > 0)
+                    if (job.neePerPath > 0 && !(job.mixed == 1 && k == (uint32_t)job.neePerPath))
                     {
                         const float4* np = job.nee + (size_t)(k*2u)*job.neeStride + slot;
                         ro = np[0]; rd = np[job.neeStride];
-                        time = job.neeTime[slot];
+                        time = job.mixed ? job.rayO[sidx(slot)].w : job.neeTime[slot];
                         *s_stop = shadow_stop(ro.w);    // the record's .w is the sample's distance (< 0: probe sample)
                     }
                     else
                     {
                         ro = job.rayO[sidx(slot)]; rd = job.rayD[sidx(slot)];
                         time = ro.w;
+                        if (job.mixed)
+                            *s_stop = -kFltMax;         // (the lane's last ray may have been a shadow ray)
                     }
                     const V3 wo(ro.x, ro.y, ro.z), wd(rd.x, rd.y, rd.z);
+                    const bool noRay = job.mixed == 1 && rd.x == 0.0f && rd.y == 0.0f && rd.z == 0.0f;      // (a path without an extension ray)
 
                     int index = job.prim[0];
                     uint32_t tb = 0, tn = (uint32_t)job.topCount[0], run = (uint32_t)job.topCount[0];
@@ -319,7 +324,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                     if (__float_as_uint(b1.z) == 0u && ray_sane(wo))
                         enters = ray_aabb(wo, wrcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tbox);
 
-                    if (!enters)
+                    if (noRay)
+                    {
+                    }
+                    else if (!enters)
                     {
                         job.rec[(size_t)recAt*2] = make_float4(kFltMax, 0.0f, 0.0f, 0.0f);
                     }
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob
     WalkF4* const s_top = reinterpret_cast<WalkF4*>(s_prim + kWalkMaxPrims*kWalkPrimWords);
 
     const int lane = (int)__lane_id();
-    const uint32_t Kx = job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
+    const uint32_t Kx = job.mixed == 1 ? (uint32_t)job.neePerPath + 1u : job.neePerPath > 0 ? (uint32_t)job.neePerPath : 1u;
     const uint32_t Kb = (uint32_t)job.numPrims;
     // A work item is a RAY (slot, k).  With several walked primitives the lane that takes it tests all their leaf boxes once -- the records
     // are wave-uniform -- and walks the ones the ray enters one after the other (`pend`: a bit per primitive still to visit).  (Until round 5
@@ -672,20 +680,23 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob
                 {
                     float4 ro, rd;
                     float time;
-                    if (job.neePerPath > 0)
+                    if (job.neePerPath > 0 && !(job.mixed == 1 && k == (uint32_t)job.neePerPath))
                     {
                         const float4* np = job.nee + (size_t)(k*2u)*job.neeStride + slot;
                         ro = np[0]; rd = np[job.neeStride];
-                        time = job.neeTime[slot];
+                        time = job.mixed ? job.rayO[sidx(slot)].w : job.neeTime[slot];
                         *s_stop = shadow_stop(ro.w);    // the record's .w is the sample's distance (< 0: probe sample)
                     }
                     else
                     {
                         ro = job.rayO[sidx(slot)]; rd = job.rayD[sidx(slot)];
                         time = ro.w;
+                        if (job.mixed)
+                            *s_stop = -kFltMax;         // (the lane's last ray may have been a shadow ray)
                     }
                     const V3 wo(ro.x, ro.y, ro.z), wd(rd.x, rd.y, rd.z);
                     const V3 wrcp = rcp3_cr(wd);
+                    const bool noRay = job.mixed == 1 && rd.x == 0.0f && rd.y == 0.0f && rd.z == 0.0f;      // (a path without an extension ray)
 
                     // which walked primitives does the ray enter?  The leaf-box test of the scan (trace_flat / the scene BVH walk): same
                     // function, same operands; rays the scan does not box-test (ray_sane) are walked unconditionally.  A primitive whose
@@ -703,8 +714,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob
                                     const float4* bp = reinterpret_cast<const float4*>(sc.primBoxes + job.prim[q]);     // (wave-uniform)
                                     const float4 b0 = bp[0], b1 = bp[1];
                                     float tbox;
-                                    bool in = true;
-                                    if (__float_as_uint(b1.z) == 0u && sane)
+                                    bool in = !noRay;
+                                    if (__float_as_uint(b1.z) == 0u && sane && !noRay)
                                         in = ray_aabb(wo, wrcp, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, tbox);
                                     pend |= in ? (1u << q) : 0u;
                                 }
