@@ -34,13 +34,14 @@ WORK = {
 def one(lib, work, steps):
     """lib: a library path, or `tuning:{json}` for the in-tree library under a tinsel_hip_tuning"""
     tuning, extra = None, []
-    if lib.startswith("tuning:"):
-        tuning, lib = lib[len("tuning:"):], ""
-    elif lib.startswith("args:"):
-        extra, lib = lib[len("args:"):].split(), ""
+    if lib.startswith("tuning:") or lib.startswith("args:"):
+        for part in lib.split(";"):
+            if part.startswith("tuning:"):
+                tuning = part[len("tuning:"):]
+            elif part.startswith("args:"):
+                extra = part[len("args:"):].split()
+        lib = ""
     env = dict(os.environ, TINSEL_HIP_LIB=lib) if lib else dict(os.environ)
-    if lib.endswith("_step5.so"):
-        extra = ["--pipeline", "paired"]
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "5", "--no-pmc", "--no-fast", "--no-api", "--no-ubench",
            "--no-cpu-baseline", "--no-second-config", "--no-more-configs"] + WORK[work] + (["--tuning", tuning] if tuning else []) + extra
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)

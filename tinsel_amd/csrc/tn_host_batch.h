@@ -124,7 +124,7 @@ int alloc_dense(tinsel_hip* r, size_t slots, int maxDepth, bool split, bool pair
         // the K pending light samples of every path, by position, double-buffered like the state (tn_paired.h); k_walk's records: K + 1 rays per position
         ss.neePerPath = (int32_t)K;
         for (int b = 0; b < 2; ++b)
-            if (batch_alloc(r, &ss.pairThr[b], K ? cap : 1) || batch_alloc(r, &ss.pairRay[b], cap*K*2) || batch_alloc(r, &ss.pairPend[b], cap*K*2))
+            if (batch_alloc(r, &ss.pairThr[b], K ? cap : 1) || batch_alloc(r, &ss.pairRay[b], cap*K*2) || batch_alloc(r, &ss.pairPend[b], K > 1 ? cap*K*2 : cap))     // (sample k's two records at (2k, 2k + 1)*cap; sample 0 has no second one)
                 return -1;
         if (r->walkPrims.count > 0 && r->walkEnabled && (double)cap*(double)(K + 1)*r->walkPrims.count < 2147483648.0)
             if (batch_alloc(r, &r->walkRec, cap*(K + 1)*(size_t)r->walkPrims.count*2) || batch_alloc(r, &r->walkList, cap) ||

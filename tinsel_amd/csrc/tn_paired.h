@@ -32,6 +32,8 @@ constexpr int kStepTypeMask = 0xff;
 #define TN_WAVES_STEP 4
 #endif
 
+TN_D bool g_is_probe(float dist) { return dist < 0.0f; }     // NeeGeo::dist < 0 marks the probe sample (tn_integrator.h)
+
 // records per position of bounce `bounce`'s walk: bounce 0 has extension rays only, the step after the last bounce shadow rays only
 TN_D uint32_t paired_per(int bounce, int maxDepth, int K) { return bounce == 0 ? 1u : bounce >= maxDepth ? (uint32_t)K : (uint32_t)K + 1u; }
 
@@ -95,13 +97,15 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_STEP) void k_step(DevScene scIn, S
             // ---- (1) the light samples of the previous bounce: does each reach its light?  (render.cpp:117-118, 172-196 and what follows them)
             if (valid && (flags & kStepHasNee))
             {
-                const float4 tn4 = ss.pairThr[cur][pos];
+                const float4* thrp = ss.pairThr[cur] + pos;     // throughput when the samples were drawn; .w: sample 0's |dot(wi, n)|
                 const float4* rayp = ss.pairRay[cur] + pos;
                 const float4* pendp = ss.pairPend[cur] + pos;
                 const float time = p.time;
+                LightCursor lights;                             // which light a sample belongs to is its index's: recomputed, not carried
                 V3 sum = nee_sum(sc, [&](int k) -> V3 {
                     const float4 a = rayp[(size_t)(k*2)*cap], bb = rayp[(size_t)(k*2 + 1)*cap];
                     const float4 pa = pendp[(size_t)(k*2)*cap];
+                    const int light = (g_is_probe(a.w)) ? -1 : lights.next(sc);
                     NeeGeo g;
                     g.o = V3(a.x, a.y, a.z); g.dist = a.w;
                     g.wi = V3(bb.x, bb.y, bb.z); g.nl = bb.w;
@@ -116,11 +120,13 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_STEP) void k_step(DevScene scIn, S
                         return (hp < 0) ? V3(pa.x, pa.y, pa.z) : V3(0.0f);       // probe sample: its whole contribution was known when it was drawn
                     if (!nee_light_reached(g, hp, ts))
                         return V3(0.0f);
-                    const float4 pb = pendp[(size_t)(k*2 + 1)*cap];
                     NeeTerms e;
-                    e.f = V3(pa.x, pa.y, pa.z); e.bsdfPdf = pa.w; e.absDot = pb.x;
-                    return nee_combine_light(sc, e, g.nl, __float_as_int(pb.y), hp, ts);
+                    e.f = V3(pa.x, pa.y, pa.z); e.bsdfPdf = pa.w;
+                    // (sample 0's rides in the throughput record's spare word; read here, not held in a register across the traces)
+                    e.absDot = k == 0 ? reinterpret_cast<const float*>(thrp)[3] : pendp[(size_t)(k*2 + 1)*cap].x;
+                    return nee_combine_light(sc, e, g.nl, light, hp, ts);
                 });
+                const float4 tn4 = *thrp;
                 p.rad = p.rad + V3(tn4.x, tn4.y, tn4.z)*sum;
             }
 
@@ -131,7 +137,6 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_STEP) void k_step(DevScene scIn, S
             NeeGeo g0;                      // the first light sample stays in registers across the append
             V3 sky0;
             float skyPdf0 = 0.0f;
-            int light0 = -1;
             Rng rngAfter0;                  // the stream behind the first sample: where the re-draw of samples 1.. starts
             LightCursor lightsAfter0;
             V3 thrNee;
@@ -161,10 +166,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_STEP) void k_step(DevScene scIn, S
                         if (sc.probe.valid)
                             nee_sample_probe(sc, h.p, h.n, p.rng, g0, sky0, skyPdf0);
                         else
-                        {
-                            light0 = lights.next(sc);
-                            nee_sample_light(sc, h.p, h.n, p.time, light0, p.rng, g0);
-                        }
+                            nee_sample_light(sc, h.p, h.n, p.time, lights.next(sc), p.rng, g0);
                         front = front || ray_enters_big_mesh(sc.primBoxes, bp, g0.o, g0.wi);
                         rngAfter0 = p.rng;
                         lightsAfter0 = lights;
@@ -202,11 +204,12 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_STEP) void k_step(DevScene scIn, S
                 store_state(ss, nxt, np, p, slot);
                 if (newFlags & kStepHasNee)
                 {
-                    ss.pairThr[nxt][np] = make_float4(thrNee.x, thrNee.y, thrNee.z, 0.0f);
                     float4* rayp = ss.pairRay[nxt] + np;
                     float4* pendp = ss.pairPend[nxt] + np;
                     const Mat mat = load_mat(sc.mats, prim);        // (read again rather than kept across the BSDF step)
-                    // sample 0
+                    // sample 0: its |dot(wi, n)| in the throughput record's spare word (one light sample per bounce -- every BASELINE scene but
+                    // veach -- then needs 64 B of pending records, not 80)
+                    float absDot0 = 0.0f;
                     rayp[0] = make_float4(g0.o.x, g0.o.y, g0.o.z, g0.dist);
                     rayp[cap] = make_float4(g0.wi.x, g0.wi.y, g0.wi.z, g0.nl);
                     if (g0.dist < 0.0f)
@@ -218,8 +221,9 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_STEP) void k_step(DevScene scIn, S
                     {
                         const NeeTerms e = nee_bsdf_terms(mat, h, g0.wi);
                         pendp[0] = make_float4(e.f.x, e.f.y, e.f.z, e.bsdfPdf);
-                        pendp[cap] = make_float4(e.absDot, __int_as_float(light0), 0.0f, 0.0f);
+                        absDot0 = e.absDot;
                     }
+                    ss.pairThr[nxt][np] = make_float4(thrNee.x, thrNee.y, thrNee.z, absDot0);
                     // samples 1 .. K-1: the same draws again, from the stream as it stood behind sample 0
                     Rng replay = rngAfter0;
                     LightCursor lights = lightsAfter0;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_STEP) void k_step(DevScene scIn, S
                         rayp[(size_t)(k*2)*cap] = make_float4(g.o.x, g.o.y, g.o.z, g.dist);
                         rayp[(size_t)(k*2 + 1)*cap] = make_float4(g.wi.x, g.wi.y, g.wi.z, g.nl);
                         pendp[(size_t)(k*2)*cap] = make_float4(e.f.x, e.f.y, e.f.z, e.bsdfPdf);
-                        pendp[(size_t)(k*2 + 1)*cap] = make_float4(e.absDot, __int_as_float(light), 0.0f, 0.0f);
+                        pendp[(size_t)(k*2 + 1)*cap] = make_float4(e.absDot, 0.0f, 0.0f, 0.0f);
                     }
                 }
             }

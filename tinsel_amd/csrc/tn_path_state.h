@@ -305,9 +305,9 @@ struct SplitState
     float* neeTime;     // [q] rayTime of the path                                                              (k_lights -> k_walk, k_shadow)
     float2* neeRes;     // [k*capacity + q] = {primitive whose emission arrives (int bits; < 0: nothing does), t}  (k_shadow -> k_shade)
     // the PAIRED pipeline's hand-over records (tn_paired.h), by position like the state and double-buffered with it: a path's K pending light samples
-    float4* pairThr[2];     // [bounce & 1][position] throughput when the samples were drawn (xyz)
+    float4* pairThr[2];     // [bounce & 1][position] throughput when the samples were drawn (xyz), sample 0's |dot(wi, n)|
     float4* pairRay[2];     // [(k*2 + {0, 1})*capacity + position] = {o, dist} {wi, nl}: the shadow rays (k_walk's `nee` in mixed mode)
-    float4* pairPend[2];    // [(k*2 + {0, 1})*capacity + position] = {f.xyz, bsdfPdf} {absDot, light (int bits)}; probe sample: {its contribution if unoccluded}
+    float4* pairPend[2];    // [(k*2)*capacity + position] = {f.xyz, bsdfPdf} (probe sample: its contribution if unoccluded); [(k*2 + 1)*capacity + position].x = |dot(wi, n)| of sample k >= 1
     float4* radOut;     // [slot] radiance of finished paths (PathState::rad: what the accumulate kernels read)
     uint32_t* segFront; // [bounce][region] paths packed at the front of the region when the bounce starts
     uint32_t* segBack;  // [bounce][region] ... at its back
