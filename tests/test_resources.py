@@ -46,6 +46,17 @@ def test_the_shading_kernel_runs_four_waves_per_simd():
     assert not [m for m in k if m.startswith("k_shade<") and m.count(",") > 1]      # (the shadow-tracing variants are gone: they lost, round 4)
 
 
+def test_the_paired_pipelines_kernel_runs_four_waves_without_scratch_where_it_is_the_default():
+    """k_step<LDS, WONLY, MIXED> (tn_paired.h): AUTO picks the paired pipeline only where every mesh is walked by k_walk, i.e. the WONLY variants --
+    those hold a path's shadow resolve, its closest hit and its shading in 128 VGPRs without a byte of scratch; the others (a mesh walked inline)
+    may park a few registers."""
+    k = _resources()
+    for n in ("k_step<1,1,1>", "k_step<0,1,0>"):
+        assert k[n]["waves_per_simd"] == 4 and k[n]["vgprs"] <= 128 and k[n]["scratch_bytes"] == 0, (n, k[n])
+    for n in ("k_step<1,0,1>", "k_step<1,0,0>", "k_step<0,0,0>"):
+        assert k[n]["waves_per_simd"] == 4 and k[n]["scratch_bytes"] <= 64, (n, k[n])
+
+
 def test_the_library_carries_no_foreign_kernels():
     """405 kernel instantiations, most of them rocprim trampolines for other architectures.  The sort and the scan of the BVH
     builder are the library's own now (tn_sort.h): every kernel in the object is one of tn::k_*."""
