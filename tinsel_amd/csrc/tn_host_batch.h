@@ -985,6 +985,16 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
                 if (launch_walk(r, st, a, r->ss.segFront + (size_t)bounce*W, /*shadowRays*/ !first && K > 0, /*mixed*/ !first && !last && K > 0))
                     return -1;
             }
+            // k_step's region groups longest first (k_region_order) where paths are deep: by bounce 6 most regions are nearly empty and the few
+            // full ones should not start last -- transmission.tin (depth 16) k_step 13.45 -> 11.81 ms, 1329 -> 1396 Msamples/s; at depth 4 the sort's
+            // launch costs what it saves (the 524k-triangle config 2562 / 2555: profiles/r06_r_ab_step_order.md)
+            if (bounce > 0 && fp.maxDepth >= 6 && gridPersist > r->numCUs*2)
+            {
+                ScopedTimer t(r, KN_SEG, st);
+                hipLaunchKernelGGL(k_region_order, dim3(1), dim3(kOrderBlock), 0, st, (const uint32_t*)(r->ss.segFront + (size_t)bounce*W), (const uint32_t*)(r->ss.segBack + (size_t)bounce*W),
+                                   a.ss.numRegions, r->regionOrder);
+                a.order = r->regionOrder;
+            }
             ScopedTimer t(r, KN_STEP, st);
             a.grid = gridPersist;
             a.ldsBytes = ldsTrace;
