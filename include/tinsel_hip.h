@@ -168,9 +168,8 @@ enum { TINSEL_PIPELINE_WAVEFRONT = 0, TINSEL_PIPELINE_MEGAKERNEL = 1, TINSEL_PIP
        /* PAIRED: the split pipeline re-cut for scenes with meshes in HBM -- a bounce's shadow rays and the next bounce's extension rays are
         * walked in ONE k_walk launch, ONE streaming kernel per bounce does the rest (tn_paired.h); same arithmetic, same bits */
        TINSEL_PIPELINE_WAVEFRONT_PAIRED = 4,
-       /* default: WAVEFRONT (fused bounce kernel) when the whole scene is LDS-resident and a bounce casts at
-        * most two NEE rays, else WAVEFRONT_SPLIT, whose trace-only kernels run at twice the occupancy
-        * (measured crossover: DESIGN.md section 5) */
+       /* default: WAVEFRONT (fused bounce kernel) when the whole scene is LDS-resident; else WAVEFRONT_PAIRED where every mesh is walked by
+        * k_walk, nothing moves and no light is a large mesh (measured: DESIGN.md section 5), else WAVEFRONT_SPLIT */
        TINSEL_PIPELINE_AUTO = 3 };
 
 /* Replaces GpuRenderer::GpuRenderer (render.cu:989-1053): deep-copies the scene
