@@ -213,7 +213,7 @@ typedef struct tinsel_hip_tuning {
     int32_t walk_refill_min;    /* 0 default (24) | idle lanes of a wave that trigger k_walk's refill */
     int32_t walk_leaf_min;      /* 0 default (8) | lanes waiting at a leaf that trigger k_walk's triangle phase */
     int32_t walk_grid_mult;     /* 0 default (1) | k_walk's grid in resident sets of workgroups: each workgroup a contiguous 1/grid of the work list */
-    int32_t _reserved;
+    int32_t quads_in_scan;      /* -1 auto | 0: a quad (two-triangle mesh: a lamp) beside meshes walked by k_walk sends the scene to the general scan kernels (inline mesh walk compiled in) */
 } tinsel_hip_tuning;
 enum { TINSEL_ACCUMULATE_AUTO = 0, TINSEL_ACCUMULATE_TILED = 1, TINSEL_ACCUMULATE_WIDE = 2, TINSEL_ACCUMULATE_PIPED = 3 };
 

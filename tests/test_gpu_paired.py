@@ -35,9 +35,13 @@ def _render_paired(scene, cam, opt, passes, first_pass=0, tuning=None, batch=Non
 
 
 WALK_ALL = dict(walk_min_tris=0, small_mesh_bytes=0)        # every mesh of every fixture through k_walk's mixed mode
+# quads (two-triangle meshes: 216 B) stay in the arena and are tested in the scan, every other mesh is walked: the lean kernels' second
+# level (SceneT<.., 2, ..>: k_step<1,2,1>, k_extend<0,1,2,1>, k_shadow<0,1,2,1>) -- what glass.tin gets by default
+QUADS_IN_SCAN = dict(walk_min_tris=0, small_mesh_bytes=256)
 
 
-@pytest.mark.parametrize("tune", [None, WALK_ALL, dict(walk_min_tris=0, small_mesh_bytes=0, walk_single=0), dict(lds_scene=0)], ids=["default", "walk-all", "walk-all-rays-kernel", "arena-in-hbm"])
+@pytest.mark.parametrize("tune", [None, WALK_ALL, dict(walk_min_tris=0, small_mesh_bytes=0, walk_single=0), dict(lds_scene=0), QUADS_IN_SCAN, dict(quads_in_scan=0)],
+                         ids=["default", "walk-all", "walk-all-rays-kernel", "arena-in-hbm", "quads-in-scan", "quads-general-kernels"])
 @pytest.mark.parametrize("name", SCENES)
 def test_paired_pipeline_matches_the_reference(name, tune):
     scene, cam, opt, g = _load(name)
@@ -49,6 +53,29 @@ def test_paired_pipeline_matches_the_reference(name, tune):
     assert st["samples"] == passes*opt.width*opt.height
     if name != "many_spheres":          # (203 primitives: beyond the flat scan, the paired pipeline hands over to the split one)
         assert "k_step" in kernels and "k_shade" not in kernels and "k_extend" not in kernels, sorted(kernels)
+
+
+def test_quads_in_the_scan_beside_walked_meshes_split_pipeline():
+    """the same second level of the lean kernels in the SPLIT pipeline (k_extend / k_shadow), every fixture; AUTO keeps glass.tin's shape
+    (sphere and cube walked, the lamp a quad in the arena) on the split pipeline, with or without quads_in_scan"""
+    from tinsel_amd import create_gpu_renderer
+    for name in SCENES:
+        scene, cam, opt, g = _load(name)
+        r = create_gpu_renderer(scene, 0, abi.Tuning(**QUADS_IN_SCAN))
+        r.set_pipeline(abi.PIPELINE_WAVEFRONT_SPLIT)
+        r.init(opt.width, opt.height)
+        out = r.render(cam, opt, passes=int(g["passes"]))
+        r.close()
+        assert np.array_equal(out, g["accum"]), name
+    scene, cam, opt, g = _load("glass")
+    for tune, want in ((None, "k_shade"), (abi.Tuning(quads_in_scan=0), "k_shade")):
+        r = create_gpu_renderer(scene, 0, tune)
+        r.init(opt.width, opt.height)
+        r.enable_kernel_timing(True)
+        out = r.render(cam, opt, passes=int(g["passes"]))
+        kernels = r.kernel_times()
+        r.close()
+        assert np.array_equal(out, g["accum"]) and want in kernels, sorted(kernels)
 
 
 def test_paired_runs_one_walk_per_bounce():

@@ -31,7 +31,7 @@ SETTINGS = [
     {"walk": 0}, {"walk_min_tris": 1}, {"walk_min_tris": 1, "small_mesh_bytes": 0},
     {"walk_lds_stack": 0}, {"walk_lds_stack": 2}, {"walk_block": 256}, {"walk_single": 0},
     {"walk_lds_stack": 2, "walk_min_tris": 1, "small_mesh_bytes": 0},
-    {"walk_refill_min": 1, "walk_leaf_min": 1}, {"walk_refill_min": 64, "walk_leaf_min": 64}, {"walk_grid_mult": 3},
+    {"walk_refill_min": 1, "walk_leaf_min": 1}, {"walk_refill_min": 64, "walk_leaf_min": 64}, {"walk_grid_mult": 3}, {"quads_in_scan": 0},
     {"tail_split": 0}, TAIL(0.4, 8), TAIL(0.05, 2), TAIL(0.125, 4),
     # a batch's passes as two overlapped chunks on two streams (render_impl): every fixture, both pipelines; with several batches per call; off
     {"overlap": 1}, {"overlap": 1, "batch_paths": 65536}, {"overlap": 0},

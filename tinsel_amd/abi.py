@@ -127,12 +127,12 @@ class Tuning(C.Structure):
                 ("tail_split", C.c_int32), ("tail_share", C.c_float), ("tail_divide", C.c_int32),
                 ("shade_sorted", C.c_int32), ("overlap", C.c_int32), ("scene_walk", C.c_int32), ("swalk_lds", C.c_int32), ("accumulate", C.c_int32),
                 ("walk_block", C.c_int32), ("walk_single", C.c_int32), ("walk_lds_stack", C.c_int32), ("walk_refill_min", C.c_int32), ("walk_leaf_min", C.c_int32),
-                ("walk_grid_mult", C.c_int32), ("_reserved", C.c_int32)]
+                ("walk_grid_mult", C.c_int32), ("quads_in_scan", C.c_int32)]
     CREATE_FIELDS = ("flat_scan", "lds_scene", "walk", "inline_max_tris", "walk_min_tris", "small_mesh_bytes", "arena_lds_limit")
     _DEFAULTS = dict(flat_scan=-1, lds_scene=-1, walk=-1, inline_max_tris=-1, walk_min_tris=-1, small_mesh_bytes=-1, arena_lds_limit=-1,
                      batch_paths=0, grid_mult=0, bounce_share=-1, repack=-1, tail_split=-1, tail_share=0.0, tail_divide=4,
                      shade_sorted=-1, overlap=-1, scene_walk=-1, swalk_lds=-1, accumulate=0,
-                     walk_block=0, walk_single=-1, walk_lds_stack=-1, walk_refill_min=0, walk_leaf_min=0, walk_grid_mult=0)
+                     walk_block=0, walk_single=-1, walk_lds_stack=-1, walk_refill_min=0, walk_leaf_min=0, walk_grid_mult=0, quads_in_scan=-1)
 
     def __init__(self, **over):
         super().__init__()

@@ -609,6 +609,10 @@ int tinsel_hip_rebuild_scene(tinsel_hip* r, int mode, const tinsel_bvh_node* nod
         HIP_TRY(hipMemcpy(const_cast<float4*>(r->scene.planeEq), eq.data(), eq.size()*sizeof(float), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemcpy(arenaDev + r->arenaOffBoxes, boxes.data(), sizeof(PrimBox)*(size_t)P, hipMemcpyHostToDevice));
+    r->scene.scanMask = 0;
+    for (int k = 0; k < P && k < 64; ++k)
+        if (boxes[(size_t)k].alwaysHit != 2u)
+            r->scene.scanMask |= 1ull << k;
     r->scene.root = sceneBvh.root;
     r->sceneStackNeed = sceneBvh.maxLeafDepth + 1;
     r->stackNeed = stack;

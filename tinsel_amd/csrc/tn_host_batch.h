@@ -42,6 +42,32 @@ int grid_mult(const tinsel_hip* r) { return r->tune.grid_mult > 0 ? r->tune.grid
 // the paired pipeline (tn_paired.h) takes flat-scan scenes without detail counting; anything else asked of it runs the split pipeline
 bool paired_can(const tinsel_hip* r) { return r->scene.flatScan != 0 && !r->countDetail; }
 
+// Which scan variants a scene gets (LaunchArgs::walkedOnly): 1 = every mesh primitive is walked by k_walk -- the lean kernels, compiled without
+// the inline mesh walk; 2 = every mesh primitive is walked OR is a quad (one internal node over two triangles: a lamp, a card), which the scan
+// tests with ray_mesh_two_leaves -- no stack, no loop -- where the arena is staged (glass.tin: sphere and cube walked, the lamp a quad);
+// 0 = some mesh is walked inline: the general kernels.
+int walked_only_level(const tinsel_hip* r)
+{
+    if (!r->walkEnabled || r->walkPrims.count == 0 || r->countDetail || r->scene.allInArena)
+        return 0;
+    int meshPrims = 0, quads = 0;
+    for (size_t i = 0; i < r->primMesh.size(); ++i)
+    {
+        const int m = r->primMesh[i];
+        if (m < 0)
+            continue;
+        ++meshPrims;
+        if (!(r->primsHost[i].flags & kPrimWalked) && r->meshesNow[(size_t)m].twoLeaves)
+            ++quads;
+    }
+    if (meshPrims == r->walkPrims.count)
+        return 1;
+    const bool mixedArena = r->scene.arenaLdsBytes != 0 && r->scene.arenaLdsBytes == r->scene.arenaBytes;
+    if (r->tune.quads_in_scan != 0 && mixedArena && meshPrims == r->walkPrims.count + quads)
+        return 2;
+    return 0;
+}
+
 // AUTO's choice between the split pipeline and its paired re-cut, by what was measured (profiles/r06_h_ab_paired.md, Msamples/s split -> paired):
 // k_step runs a path's shadow resolve, its closest hit and its shading in ONE kernel at four waves per SIMD, so it wins where all three are lean --
 // every mesh walked by k_walk (the scan kernels' WONLY variants: no inline mesh walk, no deep stack), nothing moving (no pose interpolated per ray),
@@ -50,12 +76,9 @@ bool paired_can(const tinsel_hip* r) { return r->scene.flatScan != 0 && !r->coun
 // motionblur 1488 -> 1410 (a moving mesh), meshlight.tin 1471 -> 1380 (a 36,752-triangle light: a CDF search per sample).
 bool paired_preferred(const tinsel_hip* r)
 {
-    if (!paired_can(r) || r->walkPrims.count == 0 || !r->walkEnabled)
-        return false;
-    int meshPrims = 0;
-    for (int m : r->primMesh)
-        meshPrims += m >= 0 ? 1 : 0;
-    if (meshPrims != r->walkPrims.count)
+    // (level 2 -- a quad tested in the scan beside the walked meshes, glass.tin -- stays with the split pipeline: 1662 against 1601 Msamples/s,
+    // profiles/r06_2d_ab_glass.md; its k_step is not short of registers any more, it has 2x the instructions per path-step of the 524k-triangle config's)
+    if (!paired_can(r) || r->walkPrims.count == 0 || !r->walkEnabled || walked_only_level(r) != 1)
         return false;
     for (const Prim64& p : r->primsHost)
         if (p.flags & kPrimMoving)
@@ -954,13 +977,11 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     {
         // ONE k_walk and ONE streaming kernel per bounce (tn_paired.h): walk { shadow rays of bounce b - 1, extension rays of bounce b }, then k_step(b)
         const bool walk = walk_records(r) != nullptr;
-        int meshPrims = 0;
-        for (int m : r->primMesh)
-            meshPrims += m >= 0 ? 1 : 0;
-        const bool walkedOnly = walk && meshPrims == r->walkPrims.count && !r->scene.allInArena;
+        const int walkedLevel = walk ? walked_only_level(r) : 0;
+        const bool walkedOnly = walkedLevel != 0;
         const int stackScan = walkedOnly ? std::max(1, pick_stack(r->sceneStackNeed)) : r->stackNeed;
         const uint32_t ldsTrace = walkedOnly ? (uint32_t)(((size_t)stackScan*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes) : a.ldsBytes;
-        a.walkedOnly = walkedOnly ? 1 : 0;
+        a.walkedOnly = walkedLevel;
         if (r->walkList != nullptr)
             gridPersist = std::max(1, std::min(gridPersist, (int)(seg_prefix_max_regions(r)/(kBlock/kWave))));
         if (cut_regions(r, a, slots, &gridPersist, (size_t)0))
@@ -1006,10 +1027,8 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
     {
         const bool walk = walk_records(r) != nullptr;
         // every mesh primitive walked by k_walk: the scan kernels run their lean variants with the scene-level stack only
-        int meshPrims = 0;
-        for (int m : r->primMesh)
-            meshPrims += m >= 0 ? 1 : 0;
-        const bool walkedOnly = walk && meshPrims == r->walkPrims.count && !r->scene.allInArena;
+        const int walkedLevel = walk ? walked_only_level(r) : 0;
+        const bool walkedOnly = walkedLevel != 0;
         const int stackScan = walkedOnly ? std::max(1, pick_stack(r->sceneStackNeed)) : r->stackNeed;
         const uint32_t ldsTrace = walkedOnly ? (uint32_t)(((size_t)stackScan*kBlock + kScanWords)*sizeof(uint32_t) + r->scene.arenaLdsBytes) : a.ldsBytes;
         // k_shade has no traversal stacks in LDS and reads a material per path: an arena too large to sit beside the stacks of the
@@ -1019,7 +1038,7 @@ int render_batch(tinsel_hip* r, hipStream_t st, const CameraParams& cam, FramePa
         const uint32_t arenaLdsTrace = r->scene.arenaLdsBytes;
         const uint32_t arenaLdsShade = (arenaLdsTrace == 0 && r->scene.arenaBytes <= 61440u && r->tune.lds_scene != 0) ? r->scene.arenaBytes : arenaLdsTrace;
         const uint32_t ldsShade = r->scene.allInArena ? r->scene.arenaBytes : arenaLdsShade;
-        a.walkedOnly = walkedOnly ? 1 : 0;
+        a.walkedOnly = walkedLevel;
         const bool noSceneWalkEarly = r->tune.scene_walk == 0;
         // the lean k_extend draws the light samples itself (tn_launch.h launches it when walkedOnly and not counting)
         // ... and so does the variant for a staged arena with meshes in HBM (glass): without the SLP vectoriser it fits 128 VGPRs and

@@ -303,6 +303,19 @@ tinsel_hip* tinsel_hip_create_tuned(const tinsel_scene_desc* desc, int device_in
                         r->walkPrims.prim[r->walkPrims.count++] = k;
                     }
                 }
+        // quads that ride in the arena: where their node, triangles and normals are goes into the primitive record, so that the scan reaches them
+        // without the mesh table's record in between (one dependent fetch less per ray that enters the quad's box: every shadow ray of cornell)
+        for (int k = 0; k < P; ++k)
+            if (prims[(size_t)k].type == kPrimMesh && meshes[prims[(size_t)k].mesh].twoLeaves && meshes[prims[(size_t)k].mesh].inArena)
+            {
+                const DevMesh& qm = meshes[prims[(size_t)k].mesh];
+                if (((qm.offNodes | qm.offTris | qm.offNormals | qm.offCdf) & 127u) != 0u || ((qm.offNodes | qm.offTris | qm.offNormals | qm.offCdf) >> 7) > 0xffffu)
+                    continue;
+                Prim64& qp = prims[(size_t)k];
+                qp.flags |= kPrimQuadArena;
+                const uint32_t w0 = (qm.offNodes >> 7) | ((qm.offTris >> 7) << 16), w1 = (qm.offNormals >> 7) | ((qm.offCdf >> 7) << 16);
+                memcpy(&qp.g0, &w0, 4); memcpy(&qp.g1, &w1, 4);
+            }
         r->walkEnabled = tune.walk != 0;
 #ifdef TN_WALK_PROF
         if (hipMalloc((void**)&r->walkProf, 16*sizeof(unsigned long long)) == hipSuccess)
@@ -396,6 +409,10 @@ tinsel_hip* tinsel_hip_create_tuned(const tinsel_scene_desc* desc, int device_in
             sc.planeEq = reinterpret_cast<const float4*>(arenaDev + offPlaneEq);
             sc.planeIdx = reinterpret_cast<const int32_t*>(arenaDev + offPlaneIdx);
             sc.numPlanes = (int32_t)r->planeTablePrims.size();
+            sc.scanMask = 0;
+            for (int k = 0; k < P && k < 64; ++k)
+                if (boxes[(size_t)k].alwaysHit != 2u)
+                    sc.scanMask |= 1ull << k;
             r->sceneBvhHost.assign(desc->bvh_nodes, desc->bvh_nodes + desc->num_bvh_nodes);
             r->arenaOffNodes = offNodes;
             r->arenaOffBoxes = offBoxes;

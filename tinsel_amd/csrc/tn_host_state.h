@@ -17,7 +17,7 @@ inline tinsel_hip_tuning tuning_defaults()
     t.tail_divide = 4;
     t.accumulate = TINSEL_ACCUMULATE_AUTO;
     t.walk_block = 0;
-    t.walk_single = t.walk_lds_stack = -1;
+    t.walk_single = t.walk_lds_stack = t.quads_in_scan = -1;
     t.walk_refill_min = t.walk_leaf_min = t.walk_grid_mult = 0;
     return t;
 }

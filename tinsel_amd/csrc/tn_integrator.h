@@ -128,6 +128,9 @@ struct NeeGeo
 };
 
 // PrimitiveSample (intersection.h:855-904) for light `prim`
+// (Every active lane of a light loop samples the same light, so its record, the cursor's and nee_sum's reads could take the scalar path: built
+// in round 6 with a light table behind the primitive records, and slower -- cornell 5776 -> 5680 cursor only, 5702 with the record in SGPRs,
+// profiles/r06_2f_ab_light_table.md: k_bounce is short of SGPRs before it is short of LDS round trips.)
 template <class SC>
 TN_D void primitive_sample(const SC& sc, int index, float time, V3& pos, V3& normal, Rng& rng)
 {
@@ -143,9 +146,28 @@ TN_D void primitive_sample(const SC& sc, int index, float time, V3& pos, V3& nor
     }
     else if (p.type == kPrimMesh)
     {
+        const Tri48* mtris;
+        const float* nr;
+        int tri;
+        float r = rng.randf();
+#if TN_QUAD_RECORD
+        if (p.flags & kPrimQuadArena)
+        {
+            // a quad in the arena (tn_isect.h): its arrays through the offsets in the record; LowerBound over two entries written down
+            // (mid = 1 first: cdf[1] < r -> lo = 2 -> clamped to 1; else mid = 0: cdf[0] < r -> 1, else 0) -- both entries in one round trip
+            const unsigned char* base = (SC::kLds || sc.arenaLdsBytes != 0u) ? sc.ldsBase : sc.arena;
+            const QuadOffsets q = quad_offsets(__float_as_uint(p.g0), __float_as_uint(p.g1));
+            const float* mcdf = reinterpret_cast<const float*>(base + q.cdf);
+            const float c0 = mcdf[0], c1 = mcdf[1];
+            tri = (c1 < r) ? 1 : (c0 < r) ? 1 : 0;
+            mtris = reinterpret_cast<const Tri48*>(base + q.tris);
+            nr = reinterpret_cast<const float*>(base + q.normals);
+        }
+        else
+#endif
+        {
         const DevMesh m = sc.meshes[p.mesh];
         const float* mcdf = mesh_cdf(sc, m);
-        float r = rng.randf();
 
         // LowerBound(cdf, cdf+numTris, r) (probe.h:162-183), clamped (intersection.h:880-881)
         int lo = 0, hi = m.numTris;
@@ -157,16 +179,18 @@ TN_D void primitive_sample(const SC& sc, int index, float time, V3& pos, V3& nor
             else
                 hi = mid;
         }
-        int tri = minI(lo, m.numTris - 1);
+        tri = minI(lo, m.numTris - 1);
+        mtris = mesh_tris(sc, m);
+        nr = mesh_normals(sc, m);
+        }
 
         float u, v;
         uniform_sample_triangle(rng, u, v);
 
-        const float4* tp = reinterpret_cast<const float4*>(mesh_tris(sc, m) + tri);
+        const float4* tp = reinterpret_cast<const float4*>(mtris + tri);
         float4 ta = tp[0], tb = tp[1], tc = tp[2];
         V3 a(ta.x, ta.y, ta.z), b(tb.x, tb.y, tb.z), c(tc.x, tc.y, tc.z);
         int i0 = __float_as_int(ta.w), i1 = __float_as_int(tb.w), i2 = __float_as_int(tc.w);
-        const float* nr = mesh_normals(sc, m);
         V3 n1(nr[i0*3 + 0], nr[i0*3 + 1], nr[i0*3 + 2]);
         V3 n2(nr[i1*3 + 0], nr[i1*3 + 1], nr[i1*3 + 2]);
         V3 n3(nr[i2*3 + 0], nr[i2*3 + 1], nr[i2*3 + 2]);

@@ -11,6 +11,17 @@
 
 namespace tn {
 
+// A/B arms of the flat scan's fetch order (trace_flat, prim_intersect below); every setting gives the same results
+#ifndef TN_SCAN_MASK
+#define TN_SCAN_MASK 1
+#endif
+#ifndef TN_QUAD_RECORD
+#define TN_QUAD_RECORD 1
+#endif
+#ifndef TN_SCAN_AHEAD
+#define TN_SCAN_AHEAD 1
+#endif
+
 // Per-lane traversal stack living in LDS as stack[entry][lane] (conflict-free: consecutive
 // lanes hit consecutive banks).  `base` already points at this lane's column.
 template <int STRIDE>
@@ -404,9 +415,10 @@ TN_D Prim64 load_prim_uniform(ConstF4 prims, int idx)
 // UNIFORM: `index` is the same in every lane (the flat scan's loop counter)
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false, bool UNIFORM = false>
 TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f,
-                         const V3* rcpWorld = nullptr)
+                         const V3* rcpWorld = nullptr, const Prim64* fetched = nullptr)
 {
-    const Prim64 p = UNIFORM ? load_prim_uniform(sc.kPrims, index) : load_prim(sc.prims, index);
+    // (`fetched`: the flat scan's record, requested together with the leaf box)
+    const Prim64 p = fetched ? *fetched : UNIFORM ? load_prim_uniform(sc.kPrims, index) : load_prim(sc.prims, index);
     if (COUNT) ctr.prims++;
 
     if (p.type == kPrimPlane)
@@ -429,10 +441,29 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
     V3 lo, ld, lrcp;
     pose_inv_ray(p, x, o, d, lo, ld, lrcp, rcpWorld);
 
-    const DevMesh m = sc.meshes[p.mesh];
-    const Tri48* mtris = mesh_tris(sc, m);
     MeshHit h;
-    if (SC::kWalkedOnly || (!COUNT && sc.walkRec != nullptr && (p.flags & kPrimWalked)))
+    const Tri48* mtris;
+    const float* nr;
+#if TN_QUAD_RECORD
+    if (!(SC::kWalkedOnly && !SC::kQuadsInline) && (p.flags & kPrimQuadArena))
+    {
+        // a quad in the arena: node, triangles and normals at the offsets its primitive record carries (no mesh-table record in between)
+        const unsigned char* base = (SC::kLds || sc.arenaLdsBytes != 0u) ? sc.ldsBase : sc.arena;
+        const QuadOffsets q = quad_offsets(__float_as_uint(p.g0), __float_as_uint(p.g1));
+        mtris = reinterpret_cast<const Tri48*>(base + q.tris);
+        nr = reinterpret_cast<const float*>(base + q.normals);
+        if (!ray_mesh_two_leaves<COUNT>(reinterpret_cast<const Node64*>(base + q.nodes), mtris, 0u, lo, ld, lrcp, h, ctr))
+            return false;
+    }
+    else
+#endif
+    {
+    const DevMesh m = sc.meshes[p.mesh];
+    mtris = mesh_tris(sc, m);
+    nr = mesh_normals(sc, m);
+    const bool fromRecord = SC::kQuadsInline ? (p.flags & kPrimWalked) != 0u
+                          : SC::kWalkedOnly || (!COUNT && sc.walkRec != nullptr && (p.flags & kPrimWalked));
+    if (fromRecord)
     {
         // the mesh-space closest hit of this (ray, primitive) was computed by k_walk with the same ray_mesh arithmetic
         // on the same lo / ld (tn_walk.h); t == FLT_MAX marks "no hit" (ray_mesh's own `closestT < FLT_MAX`)
@@ -446,20 +477,22 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
         h.n = V3(rb.x, rb.y, rb.z);
         h.tri = __float_as_int(rb.w);
     }
-    else if (SC::kWalkedOnly)
+    else if (SC::kWalkedOnly && !SC::kQuadsInline)
         return false;
     else if (m.twoLeaves)
     {
         if (!ray_mesh_two_leaves<COUNT>(mesh_nodes(sc, m), mtris, m.root, lo, ld, lrcp, h, ctr))
             return false;
     }
+    else if (SC::kWalkedOnly)
+        return false;               // (the host runs these variants only where every other mesh is walked by k_walk)
     else if (!ray_mesh<Stack, COUNT, ANYHIT>(mesh_nodes(sc, m), mtris, m.root, st, sp, lo, ld, lrcp, h, ctr, tStop))
         return false;
+    }
 
     // interpolate vertex normals (intersection.h:996-1012)
     const float4* tp = reinterpret_cast<const float4*>(mtris + h.tri);
     const int i0 = __float_as_int(tp[0].w), i1 = __float_as_int(tp[1].w), i2 = __float_as_int(tp[2].w);
-    const float* nr = mesh_normals(sc, m);
     V3 n1(nr[i0*3 + 0], nr[i0*3 + 1], nr[i0*3 + 2]);
     V3 n2(nr[i1*3 + 0], nr[i1*3 + 1], nr[i1*3 + 2]);
     V3 n3(nr[i2*3 + 0], nr[i2*3 + 1], nr[i2*3 + 2]);
@@ -485,6 +518,12 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
 // no stack traffic -- and reports `tie` when two accepted hits are (nearly) equal; the caller then
 // re-traces that ray with the BVH walk, which IS the oracle's order.  Results are therefore identical
 // to the BVH walk in all cases.
+TN_D unsigned long long wave_uniform64(unsigned long long v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false>
 TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, float& outT, V3& outN, bool& tie, TraceCounters& ctr, float tStop = 0.0f)
 {
@@ -563,12 +602,33 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
                 accept(__float_as_int(left == 1 ? id.x : id.z), t0, V3(e0.x, e0.y, e0.z));
         }
     }
+    // The primitives that are not in the plane table (DevScene::scanMask), as a scalar bit loop: the loop over all primitives fetched a table
+    // plane's leaf box only to read "pass by" (-DTN_SCAN_MASK=0: the A/B arm).  And a visited primitive's RECORD is requested together with its
+    // box, one scalar round trip instead of two dependent ones (-DTN_SCAN_AHEAD=0: fetched behind the box test).
+#if TN_SCAN_MASK
+    for (unsigned long long todo = wave_uniform64(sc.scanMask); todo != 0ull; todo &= todo - 1ull)
+    {
+        const int i = (int)__builtin_ctzll(todo);
+#else
     for (int i = 0; i < sc.numPrims; ++i)
     {
+#endif
         TN_TTICK(ctr, 4)
-        const ConstF4V b0 = sc.kBoxes[i*2], b1 = sc.kBoxes[i*2 + 1];
+        ConstF4V b0 = sc.kBoxes[i*2], b1 = sc.kBoxes[i*2 + 1];
+#if TN_SCAN_AHEAD
+        ConstF4V ra = sc.kPrims[i*4], rb = sc.kPrims[i*4 + 1], rc = sc.kPrims[i*4 + 2], rd = sc.kPrims[i*4 + 3];
+        asm volatile("" : "+s"(b0), "+s"(b1), "+s"(ra), "+s"(rb), "+s"(rc), "+s"(rd));        // (all six in flight before the first is used)
+        Prim64 rec;
+        rec.px = ra.x; rec.py = ra.y; rec.pz = ra.z; rec.s = ra.w;
+        rec.rx = rb.x; rec.ry = rb.y; rec.rz = rb.z; rec.rw = rb.w;
+        rec.g0 = rc.x; rec.g1 = rc.y; rec.g2 = rc.z; rec.g3 = rc.w;
+        rec.type = __float_as_uint(rd.x); rec.flags = __float_as_uint(rd.y);
+        rec.mesh = __float_as_uint(rd.z); rec.moving = __float_as_uint(rd.w);
+#endif
+#if !TN_SCAN_MASK
         if (__float_as_uint(b1.z) == 2u)
             continue;
+#endif
         if (__float_as_uint(b1.z) == 0u)
         {
             float tb;
@@ -576,14 +636,22 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
                 continue;
         }
         TN_TTICK(ctr, 0)
+#if TN_SCAN_AHEAD
+        if (SC::kDefer != 0 && (SC::kDefer == 1 || sc.deferMeshes) && rec.type == (uint32_t)kPrimMesh)
+#else
         if (SC::kDefer != 0 && (SC::kDefer == 1 || sc.deferMeshes) && __float_as_uint(sc.kPrims[i*4 + 3].x) == (uint32_t)kPrimMesh)
+#endif
         {
             meshes |= 1ull << i;
             continue;
         }
         float t;
         V3 n;
+#if TN_SCAN_AHEAD
+        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, &rcp, &rec);
+#else
         const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, &rcp);
+#endif
 #ifdef TN_PROFILE_TRACE
         { const uint32_t ty = __builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float4*>(sc.prims + i)[3].x)); TN_TTICK(ctr, ty == kPrimPlane ? 1 : ty == kPrimSphere ? 2 : 3) }
 #endif

@@ -40,7 +40,7 @@ struct LaunchArgs
     int walkSingle;                 // PK_WALK: ONE walked primitive: k_walk<.., kWalkSingle>; else k_walk_rays (tn_walk.h)
     int shadeSorted;                // PK_SHADE: k_shade_sorted (paths taken class by class) instead of k_shade
     int lightsInExtend;             // PK_EXTEND, arena staged + meshes in HBM: the variant that draws the light samples too (A/B)
-    int walkedOnly;                 // PK_EXTEND / PK_SHADOW: every mesh of the scene is walked by k_walk -> the lean scan variants
+    int walkedOnly;                 // PK_EXTEND / PK_SHADOW / PK_STEP: every mesh of the scene is walked by k_walk (2: or is a quad tested in the scan) -> the lean scan variants
     int bounce;
     int bounceEnd;                  // PK_BOUNCE: the launch covers the bounces [bounce, bounceEnd)
     int stackEntries;
@@ -66,24 +66,28 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
             if (count) { if (lds) hipLaunchKernelGGL((KERNEL<true, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<true, false>), __VA_ARGS__); } \
             else       { if (lds) hipLaunchKernelGGL((KERNEL<false, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, false>), __VA_ARGS__); } \
         } while (0)
-        if (a.walkedOnly && mixed)
-            hipLaunchKernelGGL((k_extend<false, true, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
+        if (a.walkedOnly == 2 && mixed)
+            hipLaunchKernelGGL((k_extend<false, true, 2, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
+        else if (a.walkedOnly && mixed)
+            hipLaunchKernelGGL((k_extend<false, true, 1, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         else if (a.walkedOnly && !count && !lds)
-            hipLaunchKernelGGL((k_extend<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
+            hipLaunchKernelGGL((k_extend<false, false, 1>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         else if (mixed && a.lightsInExtend)
-            hipLaunchKernelGGL((k_extend<false, true, false, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
+            hipLaunchKernelGGL((k_extend<false, true, 0, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         else if (mixed)
-            hipLaunchKernelGGL((k_extend<false, true, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
+            hipLaunchKernelGGL((k_extend<false, true, 0, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         else
             TN_LAUNCH2(k_extend, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order);
         break;
     case PK_SHADOW:
-        if (a.walkedOnly && mixed)
-            hipLaunchKernelGGL((k_shadow<false, true, true, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
+        if (a.walkedOnly == 2 && mixed)
+            hipLaunchKernelGGL((k_shadow<false, true, 2, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
+        else if (a.walkedOnly && mixed)
+            hipLaunchKernelGGL((k_shadow<false, true, 1, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
         else if (a.walkedOnly && !count && !lds)
-            hipLaunchKernelGGL((k_shadow<false, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
+            hipLaunchKernelGGL((k_shadow<false, false, 1>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
         else if (mixed)
-            hipLaunchKernelGGL((k_shadow<false, true, false, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
+            hipLaunchKernelGGL((k_shadow<false, true, 0, true>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
         else
             TN_LAUNCH2(k_shadow, grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.stackEntries, a.walkRec, a.walkPrims, a.order);
         break;
@@ -131,11 +135,12 @@ inline void launch_path_kernel(int which, const LaunchArgs& a, hipStream_t st)
         // (LDS, WONLY, MIXED) as k_extend's variants: every mesh walked + arena staged / every mesh walked, generic pointers / arena staged, some
         // meshes inline / whole scene in LDS / generic pointers
 #define TN_LAUNCH_STEP(L, W, M) hipLaunchKernelGGL((k_step<L, W, M>), grid, block, a.ldsBytes, st, a.scene, a.ss, a.ctl, a.bounce, a.fp.maxDepth, a.fp.rrStart, a.stackEntries, a.walkRec, a.walkPrims, a.bins, a.order)
-        if (a.walkedOnly && mixed) TN_LAUNCH_STEP(true, true, true);
-        else if (a.walkedOnly && !lds) TN_LAUNCH_STEP(false, true, false);
-        else if (mixed) TN_LAUNCH_STEP(true, false, true);
-        else if (lds) TN_LAUNCH_STEP(true, false, false);
-        else TN_LAUNCH_STEP(false, false, false);
+        if (a.walkedOnly == 2 && mixed) TN_LAUNCH_STEP(true, 2, true);
+        else if (a.walkedOnly && mixed) TN_LAUNCH_STEP(true, 1, true);
+        else if (a.walkedOnly && !lds) TN_LAUNCH_STEP(false, 1, false);
+        else if (mixed) TN_LAUNCH_STEP(true, 0, true);
+        else if (lds) TN_LAUNCH_STEP(true, 0, false);
+        else TN_LAUNCH_STEP(false, 0, false);
 #undef TN_LAUNCH_STEP
         break;
     case PK_SWALK_EXTEND:

@@ -37,7 +37,7 @@ TN_D bool g_is_probe(float dist) { return dist < 0.0f; }     // NeeGeo::dist < 0
 // records per position of bounce `bounce`'s walk: bounce 0 has extension rays only, the step after the last bounce shadow rays only
 TN_D uint32_t paired_per(int bounce, int maxDepth, int K) { return bounce == 0 ? 1u : bounce >= maxDepth ? (uint32_t)K : (uint32_t)K + 1u; }
 
-template <bool LDS, bool WONLY, bool MIXED>
+template <bool LDS, int WONLY, bool MIXED>
 __global__ __launch_bounds__(kBlock, TN_WAVES_STEP) void k_step(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int maxDepth, int rrStart, int stackEntries,
                                                                 const float4* __restrict__ walkRec, uint32_t walkPrims, BinPrims bp, const uint32_t* __restrict__ order)
 {

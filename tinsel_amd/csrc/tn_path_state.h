@@ -118,7 +118,7 @@ TN_D void wave_add_stat(unsigned long long* stats, int word, uint32_t v)
 //                 kernel-argument pointers are global, and global + delta would be issued as a global
 //                 load of an LDS aperture address.
 // MUST be reached by every thread of the block.
-template <bool LDS, bool WONLY, int DEFER, bool MIXED>
+template <bool LDS, int WONLY, int DEFER, bool MIXED>
 TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER, MIXED>& sc, const DevScene& in, uint32_t* ldsWords, uint32_t blockSize = kBlock)
 {
     static_cast<DevScene&>(sc) = in;

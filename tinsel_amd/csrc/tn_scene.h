@@ -53,6 +53,7 @@ enum : uint32_t
 {
     kPrimMoving = 1u,           // startTransform != endTransform: interpolate per ray
     kPrimWalked = 2u,           // mesh in HBM whose closest hit k_walk (tn_walk.h) computes ahead of the scan kernels
+    kPrimQuadArena = 8u,        // a mesh that is ONE internal node over two triangles (a quad) and rides in the arena: g0 / g1 = where its node, triangles, normals and cdf are (quad_offsets)
     kPrimNoRot = 4u,            // static pose whose rotation is exactly the quaternion (+0, +0, +0, 1): Rotate() written down (tn_isect.h)
     kPrimWalkLaneShift = 8,     // bits 8..10: which of the (up to 7) walked primitives this is = its record lane
 };
@@ -62,13 +63,21 @@ struct alignas(64) Prim64
     // pose at ray time for static primitives == InterpolateTransform(start, end, t) for any t
     float px, py, pz, s;
     float rx, ry, rz, rw;
-    float g0, g1, g2, g3;       // sphere: radius,-,-,- ; plane: the four coefficients ; static mesh: -,-,-,1.0f/s (divided on the host)
+    float g0, g1, g2, g3;       // sphere: radius,-,-,- ; plane: the four coefficients ; static mesh: -,-,-,1.0f/s (divided on the host); kPrimQuadArena: g0, g1 = QuadOffsets (bits)
     uint32_t type;
     uint32_t flags;
     uint32_t mesh;              // index into DevScene::meshes (kPrimMesh)
     uint32_t moving;            // index into DevScene::moving (kPrimMoving)
 };
 static_assert(sizeof(Prim64) == 64, "Prim64");
+
+// kPrimQuadArena: the arena offsets of the quad's four arrays, in 128-B units (what ArenaBuilder aligns to), two per word
+struct QuadOffsets { uint32_t nodes, tris, normals, cdf; };         // bytes
+TN_HD QuadOffsets quad_offsets(uint32_t w0, uint32_t w1)
+{
+    QuadOffsets q = { (w0 & 0xffffu) << 7, (w0 >> 16) << 7, (w1 & 0xffffu) << 7, (w1 >> 16) << 7 };
+    return q;
+}
 
 struct alignas(64) Moving64
 {
@@ -174,13 +183,17 @@ struct DevScene
     const float4* planeEq;
     const int32_t* planeIdx;
     int32_t numPlanes;              // (the table is padded to a multiple of four)
+    // the primitives the flat scan's loop visits: bit i clear = primitive i is a plane of the table above, tested ahead of the loop (the loop
+    // used to fetch such a primitive's leaf box only to read "pass by": five of cornell's eight scalar round trips per ray)
+    unsigned long long scanMask;
 };
 
 // Compile-time view of where the scene lives.  SceneT<true>: the whole scene (arena incl. every mesh)
 // has been staged into LDS and all accessors resolve to LDS addresses at compile time (ds_read);
 // SceneT<false>: generic pointers (HBM, or an LDS copy reached through flat loads).
 // WALKED_ONLY: every mesh primitive of the scene has its closest hits precomputed by k_walk (tn_walk.h), so the scan
-// kernels are compiled without the inline mesh walk (no deep stack, half the registers, twice the waves).
+// kernels are compiled without the inline mesh walk (no deep stack, half the registers, twice the waves).  2: or is a QUAD
+// (DevMesh::twoLeaves: a lamp, a card) tested in the scan by ray_mesh_two_leaves, which needs neither stack nor loop.
 // DEFER: trace_flat's deferred mesh walks (tn_isect.h) compiled out (0), in (1), or behind DevScene::deferMeshes (2).  The
 // fused kernel is built both ways -- the second loop costs 2 % where there is nothing to defer (cornell).
 typedef float ConstF4V __attribute__((ext_vector_type(4)));
@@ -189,12 +202,13 @@ typedef const __attribute__((address_space(4))) ConstF4V* ConstF4;
 // MIXED (with LDS): the arena is staged whole and every scene record resolves to LDS at compile time, but some meshes live in
 // HBM -- the split pipeline's scenes (glass, the 524k-triangle config).  Only the mesh accessors below then choose per mesh;
 // without it those kernels reach everything through generic pointers (flat loads, which wait on both memory counters).
-template <bool LDS, bool WALKED_ONLY = false, int DEFER = 2, bool MIXED = false>
+template <bool LDS, int WALKED_ONLY = 0, int DEFER = 2, bool MIXED = false>
 struct SceneT : DevScene
 {
     static constexpr bool kLds = LDS;
     static constexpr bool kMixed = MIXED;
-    static constexpr bool kWalkedOnly = WALKED_ONLY;
+    static constexpr bool kWalkedOnly = WALKED_ONLY != 0;
+    static constexpr bool kQuadsInline = WALKED_ONLY == 2;
     static constexpr int kDefer = DEFER;
     const unsigned char* ldsBase;
     // The flat scan reads primitive records and leaf boxes at a wave-uniform index: through these pointers (the arena's copy

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_generate(SplitState ss, QueueCtl 
 // ---------------------------------------------------------------------------
 // k_extend: closest hit of every live path
 
-// WONLY: every mesh of the scene is walked by k_walk: the kernel is the flat scan + record reads, built for more waves
+// WONLY: every mesh of the scene is walked by k_walk (2: or is a quad, SceneT): the kernel is the flat scan + record reads, built for more waves
 #ifndef TN_WAVES_SCAN
 #define TN_WAVES_SCAN 6
 #endif
@@ -218,7 +218,7 @@ TN_D void draw_shadow_rays(const SC& sc, const SplitState& ss, const BinPrims& b
 #ifndef TN_WAVES_EXTEND_LIGHTS
 #define TN_WAVES_EXTEND_LIGHTS 5
 #endif
-template <bool COUNT, bool LDS, bool WONLY = false, bool MIXED = false, bool LIGHTS = WONLY>
+template <bool COUNT, bool LDS, int WONLY = 0, bool MIXED = false, bool LIGHTS = (WONLY != 0)>
 __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN_EXTEND : LIGHTS ? TN_WAVES_EXTEND_LIGHTS : TN_WAVES_TRACE) void k_extend(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
                                                                   const float4* __restrict__ walkRec, uint32_t walkPrims, BinPrims bp, const uint32_t* __restrict__ order)
 {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock, TN_WAVES_LIGHTS) void k_lights(DevScene scI
 
 // k_shadow: the Trace() calls of SampleLights (render.cpp:117, 172) and the tests that follow them (:118, :175-196): one
 // lane per path traces its K shadow rays and leaves, per ray, the primitive whose emission arrives (or -1) and its t.
-template <bool COUNT, bool LDS, bool WONLY = false, bool MIXED = false>
+template <bool COUNT, bool LDS, int WONLY = 0, bool MIXED = false>
 __global__ __launch_bounds__(kBlock, WONLY ? TN_WAVES_SCAN : TN_WAVES_TRACE) void k_shadow(DevScene scIn, SplitState ss, QueueCtl q, int bounce, int stackEntries,
                                                                   const float4* __restrict__ walkRec, uint32_t walkPrims, const uint32_t* __restrict__ order)
 {
