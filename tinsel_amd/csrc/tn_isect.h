@@ -360,7 +360,7 @@ TN_D V3 pose_xform_point(const Prim64& p, const Xform& x, V3 v) { return x.p + p
 // InverseTransformPoint(o), InverseTransformVector(d) (maths.h:611-619): a mesh primitive's ray into mesh space, and the reciprocal of its
 // direction (MeshQuery, intersection.h:669) -- which IS the world ray's, `rcpWorld` = rcp3_cr(d) (Trace computes it for the scene-level
 // boxes), where the mesh-space direction is d bit for bit: no rotation and 1.0f/s == 1 (1.0f*x is x)
-TN_D void pose_inv_ray(const Prim64& p, const Xform& x, V3 o, V3 d, V3& lo, V3& ld, V3& lrcp, const V3* rcpWorld = nullptr)
+TN_D void pose_inv_ray(const Prim64& p, const Xform& x, V3 o, V3 d, V3& lo, V3& ld, V3& lrcp, V3 rcpWorld = V3(0.0f), bool haveRcpWorld = false)
 {
     // 1.0f/s: a static mesh has it in its record
     const float rs = (p.flags & kPrimMoving) ? rcpf_cr(x.s) : p.g3;
@@ -369,9 +369,9 @@ TN_D void pose_inv_ray(const Prim64& p, const Xform& x, V3 o, V3 d, V3& lo, V3& 
     {
         lo = rs*op;
         ld = rs*d;
-        if (rcpWorld != nullptr && __all(rs == 1.0f))
+        if (haveRcpWorld && __all(rs == 1.0f))
         {
-            lrcp = *rcpWorld;
+            lrcp = rcpWorld;
             return;
         }
     }
@@ -415,7 +415,7 @@ TN_D Prim64 load_prim_uniform(ConstF4 prims, int idx)
 // UNIFORM: `index` is the same in every lane (the flat scan's loop counter)
 template <class SC, class Stack, bool COUNT, bool ANYHIT = false, bool UNIFORM = false>
 TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d, float time, float& outT, V3& outN, TraceCounters& ctr, float tStop = 0.0f,
-                         const V3* rcpWorld = nullptr, const Prim64* fetched = nullptr)
+                         V3 rcpWorld = V3(0.0f), bool haveRcpWorld = false, const Prim64* fetched = nullptr)
 {
     // (`fetched`: the flat scan's record, requested together with the leaf box)
     const Prim64 p = fetched ? *fetched : UNIFORM ? load_prim_uniform(sc.kPrims, index) : load_prim(sc.prims, index);
@@ -439,7 +439,7 @@ TN_D bool prim_intersect(const SC& sc, int index, Stack& st, int sp, V3 o, V3 d,
 
     // mesh: ray into mesh space
     V3 lo, ld, lrcp;
-    pose_inv_ray(p, x, o, d, lo, ld, lrcp, rcpWorld);
+    pose_inv_ray(p, x, o, d, lo, ld, lrcp, rcpWorld, haveRcpWorld);
 
     MeshHit h;
     const Tri48* mtris;
@@ -648,9 +648,9 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
         float t;
         V3 n;
 #if TN_SCAN_AHEAD
-        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, &rcp, &rec);
+        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, rcp, true, &rec);
 #else
-        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, &rcp);
+        const bool primHit = prim_intersect<SC, Stack, COUNT, ANYHIT, true>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, rcp, true);
 #endif
 #ifdef TN_PROFILE_TRACE
         { const uint32_t ty = __builtin_amdgcn_readfirstlane(__float_as_uint(reinterpret_cast<const float4*>(sc.prims + i)[3].x)); TN_TTICK(ctr, ty == kPrimPlane ? 1 : ty == kPrimSphere ? 2 : 3) }
@@ -671,7 +671,7 @@ TN_D int trace_flat(const SC& sc, Stack& st, V3 o, V3 d, V3 rcp, float time, flo
             meshes &= meshes - 1ull;
             float t;
             V3 n;
-            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, &rcp))
+            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, i, st, 0, o, d, time, t, n, ctr, tStop, rcp, true))
                 accept(i, t, n);
             if (ANYHIT && minT < tStop)
                 break;
@@ -758,7 +758,7 @@ TN_D int trace(const SC& sc, Stack& st, V3 o, V3 d, float time, float& outT, V3&
             float t;
             V3 n;
             const int index = (int)(ref & ~kLeafBit);
-            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, index, st, sp, o, d, time, t, n, ctr, tStop, &rcp))
+            if (prim_intersect<SC, Stack, COUNT, ANYHIT>(sc, index, st, sp, o, d, time, t, n, ctr, tStop, rcp, true))
             {
                 if (t < minT && t > 0.0f)
                 {

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk(DevScene sc, WalkJob job)
                         if (!single)
                             p = load_prim(sc.prims, index);
                         const Xform x = prim_pose(sc, p, time);
-                        pose_inv_ray(p, x, wo, wd, o, d, rcp, &wrcp);
+                        pose_inv_ray(p, x, wo, wd, o, d, rcp, wrcp, true);
                         if (SINGLE)
                             ref = mesh0root;
                         else if (single)
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_walk_rays(DevScene sc, WalkJob
                         const uint32_t* const entry = s_prim + kb*kWalkPrimWords;
                         const Prim64 p = load_prim(reinterpret_cast<const Prim64*>(entry), 0);
                         const Xform x = prim_pose(sc, p, time);
-                        pose_inv_ray(p, x, wo, wd, o, d, rcp, &wrcp);
+                        pose_inv_ray(p, x, wo, wd, o, d, rcp, wrcp, true);
                         {
                             const uint4 tr = *reinterpret_cast<const uint4*>(entry + 16);
                             mnodes = (GlobalF4)(uintptr_t)((unsigned long long)tr.x | ((unsigned long long)tr.y << 32));
