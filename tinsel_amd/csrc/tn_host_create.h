@@ -327,7 +327,10 @@ tinsel_hip* tinsel_hip_create_tuned(const tinsel_scene_desc* desc, int device_in
         const size_t offPrims = arena.add(prims.data(), prims.size());
         const size_t offMats = arena.add(mats.data(), mats.size());
         const size_t offMoving = arena.add(moving.data(), moving.size());
-        const size_t offLights = arena.add(lights.data(), lights.size());
+        std::vector<LightRec> lightRecs(lights.size());
+        for (size_t l = 0; l < lights.size(); ++l)
+            lightRecs[l] = { lights[l], mats[(size_t)lights[l]].lightSamples, mats[(size_t)lights[l]].rcpLightSamples, 0 };
+        const size_t offLights = arena.add(lightRecs.data(), lightRecs.size());
         const size_t offMeshes = arena.add(meshes.data(), meshes.size());
 
         // The always-hit planes once more, four by four, for the flat scan (trace_flat): four IntersectRayPlane calls in a block are four
@@ -401,7 +404,7 @@ tinsel_hip* tinsel_hip_create_tuned(const tinsel_scene_desc* desc, int device_in
             sc.prims = reinterpret_cast<const Prim64*>(arenaDev + offPrims);
             sc.mats = reinterpret_cast<const Mat128*>(arenaDev + offMats);
             sc.moving = reinterpret_cast<const Moving64*>(arenaDev + offMoving);
-            sc.lights = reinterpret_cast<const int32_t*>(arenaDev + offLights);
+            sc.lights = reinterpret_cast<const LightRec*>(arenaDev + offLights);
             sc.meshes = reinterpret_cast<const DevMesh*>(arenaDev + offMeshes);
             sc.numMeshes = (int)meshes.size();
             r->sceneStackNeed = sceneBvh.maxLeafDepth + 1;

@@ -306,15 +306,32 @@ TN_D V3 nee_contrib_probe(const Mat& surf, const HitCtx& h, V3 wi, V3 skyColor, 
     return L;
 }
 
+#ifndef TN_LIGHT_RECS
+#define TN_LIGHT_RECS 1
+#endif
 // Which light does NEE ray k belong to?  Rays arrive in order (probe first, then lights x samples): the cursor walks along.
 struct LightCursor
 {
     int li = 0, sInLight = 0;
     TN_D int next(const DevScene& sc)
     {
-        while (sInLight >= sc.mats[sc.lights[li]].lightSamples) { ++li; sInLight = 0; }
+#if TN_LIGHT_RECS
+        for (;;)
+        {
+            const int4 e = *reinterpret_cast<const int4*>(sc.lights + li);      // {primitive, lightSamples, ..}: one fetch
+            if (sInLight < e.y)
+            {
+                ++sInLight;
+                return e.x;
+            }
+            ++li;
+            sInLight = 0;
+        }
+#else
+        while (sInLight >= sc.mats[sc.lights[li].prim].lightSamples) { ++li; sInLight = 0; }
         ++sInLight;
-        return sc.lights[li];
+        return sc.lights[li].prim;
+#endif
     }
 };
 
@@ -332,11 +349,21 @@ TN_D V3 nee_sum(const DevScene& sc, Contrib contrib)
     }
     for (int li = 0; li < sc.numLights; ++li)
     {
-        const int numSamples = sc.mats[sc.lights[li]].lightSamples;
+#if TN_LIGHT_RECS
+        const int4 e = *reinterpret_cast<const int4*>(sc.lights + li);
+        const int numSamples = e.y;
+        const float rcpSamples = __int_as_float(e.z);
+#else
+        const int numSamples = sc.mats[sc.lights[li].prim].lightSamples;
+#endif
         V3 L(0.0f);
         for (int s = 0; s < numSamples; ++s)
             L = L + contrib(k++);
-        sum = sum + L*sc.mats[sc.lights[li]].rcpLightSamples;     // L*(1.0f/numSamples), render.cpp:223: divided on the host (Mat128)
+#if TN_LIGHT_RECS
+        sum = sum + L*rcpSamples;                                       // L*(1.0f/numSamples), render.cpp:223: divided on the host
+#else
+        sum = sum + L*sc.mats[sc.lights[li].prim].rcpLightSamples;
+#endif
     }
     return sum;
 }

@@ -165,7 +165,7 @@ TN_D void stage_scene_lds(SceneT<LDS, WONLY, DEFER, MIXED>& sc, const DevScene& 
     sc.mats = reinterpret_cast<const Mat128*>(rebase(in.mats));
     sc.moving = reinterpret_cast<const Moving64*>(rebase(in.moving));
     sc.meshes = reinterpret_cast<const DevMesh*>(rebase(in.meshes));
-    sc.lights = reinterpret_cast<const int32_t*>(rebase(in.lights));
+    sc.lights = reinterpret_cast<const LightRec*>(rebase(in.lights));
     sc.primBoxes = reinterpret_cast<const PrimBox*>(rebase(in.primBoxes));
 }
 

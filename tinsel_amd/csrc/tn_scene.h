@@ -118,6 +118,16 @@ struct alignas(32) PrimBox
 };
 static_assert(sizeof(PrimBox) == 32, "PrimBox");
 
+// One light of the scene as the light loops read it (LightCursor, nee_sum: tn_integrator.h): ONE 16-B record instead of the primitive index and,
+// behind it, two words of that primitive's 128-B material record
+struct alignas(16) LightRec
+{
+    int32_t prim;
+    int32_t lightSamples;
+    float rcpLightSamples;      // 1.0f/lightSamples, divided on the host (Mat128)
+    int32_t pad;
+};
+
 struct DevMesh
 {
     const Node64* nodes;
@@ -157,7 +167,7 @@ struct DevScene
     const Mat128* mats;         // one per primitive, same index
     const Moving64* moving;
     const DevMesh* meshes;
-    const int32_t* lights;      // primitive indices with lightSamples > 0, in primitive order
+    const LightRec* lights;     // the primitives with lightSamples > 0, in primitive order
     uint32_t root;
     int32_t numPrims;
     int32_t numLights;
