@@ -153,7 +153,9 @@ def primitive(rng, kind, mat, light_samples):
     return "\n".join(lines)
 
 
-def scene_text(seed):
+def scene_text(seed, nprim=None, max_planes=3):
+    """nprim / max_planes: override the number of non-light primitives (default: 3-10, drawn) and the cap on planes -- the large flat-scan scenes of
+    tests/test_fuzz.py (up to 64 primitives); the random stream is the same either way"""
     rng = np.random.default_rng(1000 + seed)
     W, H = int(rng.choice([24, 32, 40])), int(rng.choice([16, 24, 32]))
     out = ["# fuzz scene %d" % seed, "options", "{", "\twidth %d" % W, "\theight %d" % H,
@@ -174,14 +176,15 @@ def scene_text(seed):
     for m in range(nlight):
         out.append(material(rng, "e%d" % m, True))
     out.append(MESHES)
-    nprim = int(rng.integers(3, 11))
+    drawn = int(rng.integers(3, 11))
+    nprim = drawn if nprim is None else int(nprim)
     kinds = ["plane", "sphere", "sphere", "quad", "tetra", "wedge"]
     planes = 0
     for k in range(nprim):
         kind = kinds[int(rng.integers(0, len(kinds)))]
         if kind == "plane":
             planes += 1
-            if planes > 3:
+            if planes > max_planes:
                 kind = "sphere"
         out.append(primitive(rng, kind, "m%d" % int(rng.integers(0, nmat)), 0))
     for m in range(nlight):
