@@ -33,14 +33,15 @@ WORK = {
 
 def one(lib, work, steps):
     """lib: a library path, or `tuning:{json}` for the in-tree library under a tinsel_hip_tuning"""
-    tuning, extra = None, []
-    if lib.startswith("tuning:") or lib.startswith("args:"):
-        for part in lib.split(";"):
-            if part.startswith("tuning:"):
-                tuning = part[len("tuning:"):]
-            elif part.startswith("args:"):
-                extra = part[len("args:"):].split()
-        lib = ""
+    tuning, extra, path = None, [], ""
+    for part in lib.split(";"):         # `path`, `tuning:{json}`, `args:...`, or several joined by ';'
+        if part.startswith("tuning:"):
+            tuning = part[len("tuning:"):]
+        elif part.startswith("args:"):
+            extra = part[len("args:"):].split()
+        else:
+            path = part
+    lib = path
     env = dict(os.environ, TINSEL_HIP_LIB=lib) if lib else dict(os.environ)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "5", "--no-pmc", "--no-fast", "--no-api", "--no-ubench",
            "--no-cpu-baseline", "--no-second-config", "--no-more-configs"] + WORK[work] + (["--tuning", tuning] if tuning else []) + extra

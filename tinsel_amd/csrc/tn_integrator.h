@@ -306,8 +306,14 @@ TN_D V3 nee_contrib_probe(const Mat& surf, const HitCtx& h, V3 wi, V3 skyColor, 
     return L;
 }
 
+// One fetch per light in the light loops (LightRec, tn_scene.h) -- the parity arm only: cornell +0.3-0.8 % there, while the tolerance arm's k_bounce
+// loses its register allocation to it (56 VGPRs spilled: cornell 7147 -> 5812 Msamples/s, profiles/r06_2t_ab_fast_arm.md)
 #ifndef TN_LIGHT_RECS
+#ifdef TN_FAST
+#define TN_LIGHT_RECS 0
+#else
 #define TN_LIGHT_RECS 1
+#endif
 #endif
 // Which light does NEE ray k belong to?  Rays arrive in order (probe first, then lights x samples): the cursor walks along.
 struct LightCursor
