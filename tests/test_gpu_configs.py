@@ -166,10 +166,10 @@ def test_silhouette_window_at_a_late_pass_is_bit_identical(label, pack, W, H, de
 FULL_FRAMES = [
     # label, pack, W, H, maxDepth, spp: what the reference's own PathTrace does in seconds on the GPU box's host threads
     ("cfg2 cornell 1024x1024 spp 256 (the config's own spp)", os.path.join(oa.GOLDEN, "cornell.pack"), 1024, 1024, 4, 256),
-    ("cfg3 ajax stand-in 524288 tris 1920x1080 spp 8", LARGE, 1920, 1080, 4, 8),
-    ("cfg3-aphrodite ajax.tin + Aphrodite 427384 tris 1920x1080 spp 8", APHRODITE, 1920, 1080, 4, 8),
-    ("cfg4 glass 1920x1080 depth 12 spp 4", os.path.join(oa.GOLDEN, "glass.pack"), 1920, 1080, 12, 4),
-    ("cfg5 veach 3840x2160 spp 2", os.path.join(oa.GOLDEN, "veach.pack"), 3840, 2160, 4, 2),
+    ("cfg3 ajax stand-in 524288 tris 1920x1080 spp 32", LARGE, 1920, 1080, 4, 32),
+    ("cfg3-aphrodite ajax.tin + Aphrodite 427384 tris 1920x1080 spp 32", APHRODITE, 1920, 1080, 4, 32),
+    ("cfg4 glass 1920x1080 depth 12 spp 16", os.path.join(oa.GOLDEN, "glass.pack"), 1920, 1080, 12, 16),
+    ("cfg5 veach 3840x2160 spp 8", os.path.join(oa.GOLDEN, "veach.pack"), 3840, 2160, 4, 8),
 ]
 
 
