@@ -19,6 +19,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -772,6 +773,12 @@ static vec3 sky_eval(const scene_t* sc, vec3 dir)                               
 
 /* ------------------------------------------------------------------------- render.cpp */
 
+/* developer trace of ONE path (port_set_trace(1), scratch/path_probe.py): every decision of the loop as hex floats on stderr */
+static int g_trace = 0;
+void port_set_trace(int on) { g_trace = on; }
+#define TRC(...) do { if (g_trace) fprintf(stderr, __VA_ARGS__); } while (0)
+static unsigned fbits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+
 static vec3 sample_lights(const scene_t* sc, const tinsel_primitive* surf, float etaI, float etaO, vec3 surfacePos,
                           vec3 surfaceNormal, vec3 shadingNormal, vec3 wo, float time, rng_t* rand, counters* ct)  /* :103-227 */
 {
@@ -828,6 +835,8 @@ static vec3 sample_lights(const scene_t* sc, const tinsel_primitive* surf, float
             ray_t ray = { vadd(surfacePos, vscale(face_forward(surfaceNormal, wi), kRayEpsilon)), wi, time };
             ct->shadow++;
             const tinsel_primitive* hit = trace(sc, &ray, &t, &n, ct);
+            TRC("    light %d sample %d: pos %08x %08x %08x nrm %08x %08x %08x wi %08x %08x %08x dist %08x -> hit %d t %08x (%g vs %g)\n", i, s, fbits(lightPos.x), fbits(lightPos.y), fbits(lightPos.z),
+                fbits(lightNormal.x), fbits(lightNormal.y), fbits(lightNormal.z), fbits(wi.x), fbits(wi.y), fbits(wi.z), fbits(sqrtf(dSq)), hit ? (int)(hit - sc->prims) : -1, fbits(t), t, sqrtf(dSq));
             if (hit)
             {
                 float tSq = t*t;
@@ -841,6 +850,7 @@ static vec3 sample_lights(const scene_t* sc, const tinsel_primitive* surf, float
                     float lightPdf = ((1.0f/lightArea)*tSq)/nl;
                     float bsdfPdf = bsdf_pdf(&surf->material, etaI, etaO, shadingNormal, wo, wi);
                     vec3 f = bsdf_eval(&surf->material, etaI, etaO, shadingNormal, wo, wi);
+                    TRC("      in tolerance: nl %08x bsdfPdf %08x etaI %08x etaO %08x wo %08x %08x %08x n %08x %08x %08x\n", fbits(nl), fbits(bsdfPdf), fbits(etaI), fbits(etaO), fbits(wo.x), fbits(wo.y), fbits(wo.z), fbits(shadingNormal.x), fbits(shadingNormal.y), fbits(shadingNormal.z));
                     if (bsdfPdf > 0.0f)
                     {
                         int N = (int)(light->light_samples + kBsdfSamples);
@@ -849,6 +859,7 @@ static vec3 sample_lights(const scene_t* sc, const tinsel_primitive* surf, float
                         float weight = clight*lightPdf/(cbsdf*bsdfPdf + clight*lightPdf);
                         vec3 em = v3(hit->material.emission.x, hit->material.emission.y, hit->material.emission.z);
                         L = vadd(L, vscale(vmul(vscale(f, weight), em), absT(vdot(wi, shadingNormal))/maxT(1.e-3f, lightPdf)));
+                        TRC("      arrives: nl %08x lightPdf %08x bsdfPdf %08x f %08x %08x %08x weight %08x L %08x %08x %08x\n", fbits(nl), fbits(lightPdf), fbits(bsdfPdf), fbits(f.x), fbits(f.y), fbits(f.z), fbits(weight), fbits(L.x), fbits(L.y), fbits(L.z));
                     }
                 }
             }
@@ -880,6 +891,9 @@ static vec3 path_trace(const scene_t* sc, vec3 startOrigin, vec3 startDir, float
     {
         ray_t ray = { rayOrigin, rayDir, rayTime };
         const tinsel_primitive* hit = trace(sc, &ray, &t, &n, ct);
+        TRC("bounce %d: o %08x %08x %08x d %08x %08x %08x -> hit %d t %08x n %08x %08x %08x | thr %08x %08x %08x rad %08x %08x %08x rng %08x %08x\n", i, fbits(rayOrigin.x), fbits(rayOrigin.y), fbits(rayOrigin.z),
+            fbits(rayDir.x), fbits(rayDir.y), fbits(rayDir.z), hit ? (int)(hit - sc->prims) : -1, fbits(t), fbits(n.x), fbits(n.y), fbits(n.z), fbits(pathThroughput.x), fbits(pathThroughput.y), fbits(pathThroughput.z),
+            fbits(totalRadiance.x), fbits(totalRadiance.y), fbits(totalRadiance.z), rand->seed1, rand->seed2);
         if (hit)
         {
             float outEta;
@@ -931,6 +945,7 @@ static vec3 path_trace(const scene_t* sc, vec3 startOrigin, vec3 startDir, float
             vec3 bsdfDir = v3s(0.0f);
             int bsdfType = eReflected;
             bsdf_sample(&hit->material, rayEta, outEta, u, v, n, vneg(rayDir), &bsdfDir, &bsdfPdf, &bsdfType, rand);
+            TRC("  bsdf sample: dir %08x %08x %08x pdf %08x type %d rad %08x %08x %08x\n", fbits(bsdfDir.x), fbits(bsdfDir.y), fbits(bsdfDir.z), fbits(bsdfPdf), bsdfType, fbits(totalRadiance.x), fbits(totalRadiance.y), fbits(totalRadiance.z));
             if (bsdfPdf <= 0.0f)
                 break;
 

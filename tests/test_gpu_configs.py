@@ -171,6 +171,13 @@ FULL_FRAMES = [
     ("cfg4 glass 1920x1080 depth 12 spp 16", os.path.join(oa.GOLDEN, "glass.pack"), 1920, 1080, 12, 16),
     ("cfg5 veach 3840x2160 spp 8", os.path.join(oa.GOLDEN, "veach.pack"), 3840, 2160, 4, 8),
 ]
+# TINSEL_TEST_FULL_SPP=1 (a test-size switch, read here only): config 3 at its own 512 spp, glass at 256, veach 4K at 64 -- seven minutes of the
+# box's host threads instead of one; the run of round 6 is profiles/r06_3d_full_spp_parity.txt
+# TINSEL_TEST_FULL_SPP=big: 2e9 paths per configuration (half an hour): the hunt for one-in-a-billion events that found the path of
+# test_the_path_that_meets_a_light_at_exactly_grazing_incidence below
+if os.environ.get("TINSEL_TEST_FULL_SPP"):
+    _spp = (2048, 1024, 1024, 1024, 256) if os.environ["TINSEL_TEST_FULL_SPP"] == "big" else (256, 512, 512, 256, 64)
+    FULL_FRAMES = [(c[0].rsplit(" spp ", 1)[0] + " spp %d" % s,) + c[1:5] + (s,) for c, s in zip(FULL_FRAMES, _spp)]
 
 
 @pytest.mark.parametrize("label,pack,W,H,depth,spp", FULL_FRAMES, ids=[c[0].split()[0] + "-full" for c in FULL_FRAMES])
@@ -206,6 +213,32 @@ def test_whole_frame_equals_the_reference(label, pack, W, H, depth, spp):
         label, type(O).__name__, l2, 100.0*same, t_gpu, t_cpu, trace_s, os.cpu_count() or 1))
     assert np.array_equal(out, want), "%s: %d pixels differ, L2 %.3e" % (label, int((out != want).any(axis=-1).sum()), l2)
     assert np.isfinite(out).all() and (out[..., 3] > 0).mean() > 0.99      # (at 2 spp a pixel may sit between every footprint)
+
+
+def test_the_path_that_meets_a_light_at_exactly_grazing_incidence():
+    """veach.tin at 3840 x 2160, pass 28, pixel (1866, 0): the path's second ray meets a light sphere with Dot(n, V) == 0.0f, the light's index of
+    refraction equals the ray's, and Fr() (disney.h:79-96) divides 0 by 0: BSDFPdf is NaN, `bsdfPdf > 0` is false, the light samples of that hit
+    contribute nothing (render.cpp:196-219).  The HIP path skipped Fr() for opaque materials -- finite F or not -- until round 6 and added them: ONE
+    path in 5.3e8, two pixels of the 64-spp frame (found by TINSEL_TEST_FULL_SPP).  Every pipeline, the row of the frame that holds it."""
+    import tinsel_amd
+    pack = os.path.join(oa.GOLDEN, "veach.pack")
+    scene = tinsel_amd.Scene.load_pack(pack)
+    cam, opt = scene.camera, scene.options.copy()
+    opt.width, opt.height, opt.max_depth, opt.mode = 3840, 2160, 4, abi.MODE_PATHTRACE
+    O = _oracle()
+    h = O.load_pack(pack)
+    _, want, _ = O.render_seeded(h, cam, opt, 28, 1, window=(1800, 0, 1930, 1), want_accum=False, want_radiance=True)
+    O.free(h)
+    assert want[0, 0, 66].view(np.uint32).tolist() == [997647725, 999854181, 1001026314]       # (the reference's value for that path: no NaN in it)
+    for pipeline in (abi.PIPELINE_AUTO, abi.PIPELINE_WAVEFRONT_SPLIT, abi.PIPELINE_MEGAKERNEL):
+        r = tinsel_amd.create_gpu_renderer(scene)
+        r.set_pipeline(pipeline)
+        r.init(opt.width, opt.height)
+        r.set_pass_index(28)
+        r.render(cam, opt, passes=1, readback=False)
+        got = r.batch_radiance(1, opt.height, opt.width)[0, 0:1, 1800:1930]
+        r.close()
+        assert np.array_equal(got, want[0]), (pipeline, got[0, 66], want[0, 0, 66])
 
 
 @pytest.mark.skipif(not os.path.exists(APHRODITE), reason="tests/golden/large/ajax_aphrodite.pack not generated (make_large.py aphrodite)")

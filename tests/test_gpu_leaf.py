@@ -95,6 +95,28 @@ def test_bsdf_eval_pdf_sample(scene_name, prims):
     r.close(); R.free(h)
 
 
+def test_bsdf_pdf_where_fresnel_is_not_finite():
+    """BSDFPdf computes Fr(Dot(n, V), etaI, etaO) for every material and multiplies it by transmission == 0 for an opaque one: NaN where Fr divides
+    0 by 0 -- V exactly in the surface's plane, etaI == etaO -- and the pdf is NaN.  The HIP path's shortcut for opaque materials must not hide that:
+    rows with Dot(n, V) == 0 (and just above, where Fr is finite and the shortcut applies), equal and unequal indices, against the reference."""
+    scene, r, R, h = _setup("cornell")
+    rows = []
+    for V in ([1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.6, 0.0, 0.8], [1.0, 1e-7, 0.0], [0.99, 0.14106736, 0.0]):
+        for L in ([0.0, 1.0, 0.0], [0.3, 0.9, 0.31622777], [-0.5, 0.70710678, 0.5]):
+            for eta in ([1.0, 1.0], [1.5, 1.5], [1.0, 1.5], [1.5, 1.0]):
+                rows.append([0.0, 1.0, 0.0] + V + L + eta)
+    rows = np.array(rows, np.float32)
+    for prim in (0, 6, 7):                                      # a wall, the glossy sphere, the metal one: all opaque
+        mat = R.primitive(h, prim).material
+        out = r.leaf(2, prim, len(rows), 4, rows=rows)
+        f, pdf = R.bsdf_eval(mat, rows)
+        assert np.isnan(pdf).any() and not np.isnan(pdf).all()  # (the rows hold both cases)
+        assert np.array_equal(np.isnan(out[:, 3]), np.isnan(pdf)), (prim, np.nonzero(np.isnan(out[:, 3]) != np.isnan(pdf)))
+        ok = ~np.isnan(pdf)
+        assert np.array_equal(out[ok, 3].view(np.uint32), pdf[ok].view(np.uint32)), prim
+    r.close(); R.free(h)
+
+
 @pytest.mark.parametrize("scene_name,prims", [("features", [0, 2, 3, 4, 5, 6, 7]), ("cornell", [0, 5, 6]), ("ajax_standin_96", [0, 1])])
 def test_primitive_intersect(scene_name, prims):
     scene, r, R, h = _setup(scene_name)

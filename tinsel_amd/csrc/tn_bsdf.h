@@ -100,9 +100,13 @@ TN_D float bsdf_pdf(const Mat& mat, float etaI, float etaO, V3 n, V3 V, V3 L)
     }
     else
     {
-        // F only enters through Lerp(brdfPdf, pdfSpec*F, transmission): with transmission == 0 that is
-        // brdfPdf + (finite)*0 == brdfPdf for any F in [0,1], so opaque materials skip the Fresnel term
-        float F = (mat.transmission != 0.0f) ? fresnel_dielectric(dot(n, V), etaI, etaO) : 1.0f;
+        // F only enters through Lerp(brdfPdf, pdfSpec*F, transmission): with transmission == 0 that is brdfPdf + (finite)*0 == brdfPdf for any
+        // FINITE F, so opaque materials skip the Fresnel term -- where it is finite.  Fr() divides by VDotN + eta*LDotN and LDotN + eta*VDotN
+        // (disney.h:79-96): with a face-forwarded normal VDotN >= 0, and both are > 0 unless VDotN is not: at VDotN == 0 with etaI == etaO the
+        // reference computes 0/0, its pdf is NaN and the light sample is dropped (`bsdfPdf > 0` is false).  One path in 5.3e8 of veach 4K meets a
+        // light sphere that exactly (round 6, found by the whole frame at 64 spp: tests/test_gpu_configs.py); so: the shortcut only where VDotN > 0.
+        const float VDotN = dot(n, V);
+        float F = (mat.transmission != 0.0f || !(VDotN > 0.0f)) ? fresnel_dielectric(VDotN, etaI, etaO) : 1.0f;
         const float a = maxT(0.001f, mat.roughness);
         const V3 half = safe_normalize(L + V, V3(0.0f));
         const float cosThetaHalf = absf(dot(half, n));
