@@ -176,8 +176,9 @@ FULL_FRAMES = [
 # TINSEL_TEST_FULL_SPP=big: 2e9 paths per configuration (half an hour): the hunt for one-in-a-billion events that found the path of
 # test_the_path_that_meets_a_light_at_exactly_grazing_incidence below
 if os.environ.get("TINSEL_TEST_FULL_SPP"):
-    _spp = (2048, 1024, 1024, 1024, 256) if os.environ["TINSEL_TEST_FULL_SPP"] == "big" else (256, 512, 512, 256, 64)
-    FULL_FRAMES = [(c[0].rsplit(" spp ", 1)[0] + " spp %d" % s,) + c[1:5] + (s,) for c, s in zip(FULL_FRAMES, _spp)]
+    _v = os.environ["TINSEL_TEST_FULL_SPP"]
+    _spp = (2048, 1024, 1024, 1024, 256) if _v == "big" else tuple(int(x) for x in _v.split(",")) if "," in _v else (256, 512, 512, 256, 64)     # ("a,b,c,d,e": 0 skips)
+    FULL_FRAMES = [(c[0].rsplit(" spp ", 1)[0] + " spp %d" % s,) + c[1:5] + (s,) for c, s in zip(FULL_FRAMES, _spp) if s > 0]
 
 
 @pytest.mark.parametrize("label,pack,W,H,depth,spp", FULL_FRAMES, ids=[c[0].split()[0] + "-full" for c in FULL_FRAMES])
