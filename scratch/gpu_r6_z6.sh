@@ -1,7 +1,7 @@
 #!/bin/bash
-# call z5: the closing evidence run on the final tree (after the BSDFPdf fix) -- the GPU suite, the driver's bench command (plain; under rocprofv3 --kernel-trace --stats),
+# call z6: the closing evidence run on the final tree (after the two parity fixes of the hunt at scale) -- the GPU suite, the driver's bench command (plain; under rocprofv3 --kernel-trace --stats),
 # per-kernel counters of every configuration, k_walk's section profile, the animation's per-frame cost, the spread over fresh processes
-O=gpurun_out/r6z5; mkdir -p $O
+O=gpurun_out/r6z6; mkdir -p $O
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
 ( time python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err ) 2>&1 | grep real; cp bench_detail.json $O/bench_detail.json
 python scratch/roofline_table.py $O/bench_detail.json > $O/roofline_inputs.md
@@ -16,7 +16,7 @@ python scratch/ab_rates.py --repeat 5 glass cfg3 aphrodite > $O/spread.md 2> /de
 python scratch/ab_rates.py --repeat 1 cornell veach4k cfg1 many_spheres motionblur table transmission meshlight > $O/other_rates.md 2> /dev/null; cat $O/other_rates.md
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/r6z5/bench_default.json'))
+d=json.load(open('gpurun_out/r6z6/bench_default.json'))
 print('headline', d['value'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], len(json.dumps(d)))
 for c in d.get('configs', []): print(c['workload'][:60], c.get('value'), c.get('kernel'), c.get('frac'), c.get('job_counter_over_compulsory'))
 PY
